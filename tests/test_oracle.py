@@ -1,0 +1,237 @@
+"""CPU tests that PIN the oracle: reference known-answer tests, hand-derived
+fixture answers, and an independent PyTorch-CPU/autograd cross-check."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_ref as R, loss_ref as L, optim_ref as O, data_ref as D, torch_ref as T
+
+
+def mesh(n):
+    i = np.arange(n)
+    return (i[:, None] + i[None, :]).astype(np.float32)
+
+
+# ---- reference KATs: src/slim_dir/nets/resnet_v1_test.py:58-152 -------------
+def test_slim_subsample_kats():
+    x = np.arange(9, dtype=np.float32).reshape(1, 3, 3, 1)
+    assert R.subsample(x, 2).flatten().tolist() == [0, 2, 6, 8]
+    x = np.arange(16, dtype=np.float32).reshape(1, 4, 4, 1)
+    assert R.subsample(x, 2).flatten().tolist() == [0, 2, 8, 10]
+
+
+def test_slim_conv2d_same_even_kat():
+    x = mesh(4).reshape(1, 4, 4, 1)
+    w = mesh(3).reshape(3, 3, 1, 1)
+    y1 = R.conv2d_same(x, w)
+    exp = np.array([[14, 28, 43, 26], [28, 48, 66, 37], [43, 66, 84, 46], [26, 37, 46, 22]], np.float32)
+    np.testing.assert_allclose(y1[0, :, :, 0], exp)
+    np.testing.assert_allclose(R.subsample(y1, 2)[0, :, :, 0], [[14, 43], [43, 84]])
+    np.testing.assert_allclose(R.conv2d_same(x, w, stride=2)[0, :, :, 0], [[48, 37], [37, 22]])
+
+
+def test_slim_conv2d_same_odd_kat():
+    x = mesh(5).reshape(1, 5, 5, 1)
+    w = mesh(3).reshape(3, 3, 1, 1)
+    y1 = R.conv2d_same(x, w)
+    exp = np.array([[14, 28, 43, 58, 34], [28, 48, 66, 84, 46], [43, 66, 84, 102, 55],
+                    [58, 84, 102, 120, 64], [34, 46, 55, 64, 30]], np.float32)
+    np.testing.assert_allclose(y1[0, :, :, 0], exp)
+    y2 = [[14, 43, 34], [43, 84, 55], [34, 55, 30]]
+    np.testing.assert_allclose(R.subsample(y1, 2)[0, :, :, 0], y2)
+    np.testing.assert_allclose(R.conv2d_same(x, w, stride=2)[0, :, :, 0], y2)
+
+
+# ---- reference fixture tests/testImg2Anno.xml, hand-derived ----
+def test_label_encode_fixture(golden_dir):
+    xml = open(os.path.join(golden_dir, "testImg2Anno.xml")).read()
+    w, h, objs = D.parse_voc_xml(xml)
+    assert (w, h) == (353, 500)
+    lab = D.encode_boxes(objs, h, w, 224, 7)
+    assert sorted(map(tuple, np.argwhere(lab[..., 0] == 1))) == [(3, 3), (4, 2)]
+    np.testing.assert_allclose(lab[4, 2, 1:5], [76.4646, 136.416, 93.2805, 58.688], atol=1e-4)
+    np.testing.assert_allclose(lab[3, 3, 1:5], [113.5864, 113.792, 218.289, 217.728], atol=1e-4)
+    assert lab[4, 2, 5 + 11] == 1 and lab[3, 3, 5 + 14] == 1 and lab[..., 5:].sum() == 2
+    lab = D.encode_boxes(objs, h, w, 416, 13)
+    np.testing.assert_allclose(lab[7, 4, 1:5], [142.0057, 253.344, 173.2351, 108.992], atol=1e-4)
+    np.testing.assert_allclose(lab[6, 6, 1:5], [210.9462, 211.328, 405.3938, 404.352], atol=1e-4)
+
+
+def test_grid_offset():
+    off = L.yolo_grid_offset(7, 2)
+    assert off.shape == (7, 7, 2)
+    assert off[0, :, 0].tolist() == list(range(7)) and off[:, 0, 0].tolist() == [0] * 7
+    assert (off[..., 0] == off[..., 1]).all()
+    off = L.yolo_grid_offset(13, 2)
+    assert (off == np.arange(13)[None, :, None]).all()
+
+
+# ---- cross-check against torch (independent implementation + autograd) -------
+def _tiny_spec():
+    return [(3, 3, 8, True), (3, 8, 16, False), (1, 16, 8, True), (3, 8, 16, False)]
+
+
+def test_stack_forward_backward_vs_torch():
+    rng = np.random.default_rng(1)
+    spec = _tiny_spec()
+    params = R.init_params(spec, seed=3)
+    for p in params:   # non-trivial BN affine
+        p["gamma"] = rng.uniform(0.5, 1.5, p["gamma"].shape).astype(np.float32)
+        p["beta"] = rng.uniform(-0.3, 0.3, p["beta"].shape).astype(np.float32)
+    x = rng.uniform(-1, 1, (3, 12, 12, 3)).astype(np.float32)
+    out, caches, movings = R.run_stack(x, params, spec, True, np.float64)
+    dout = rng.standard_normal(out.shape)
+    dx, grads = R.run_stack_backward(params, caches, dout, np.float64, need_input_grad=True)
+
+    tp = T.to_torch_params(params, torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ot, stats = T.run_stack(xt, tp, spec, True)
+    np.testing.assert_allclose(out, ot.detach().numpy(), rtol=1e-9, atol=1e-10)
+    ot.backward(torch.tensor(dout))
+    np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-7, atol=1e-9)
+    for g, p in zip(grads, tp):
+        for k in ("W", "gamma", "beta"):
+            np.testing.assert_allclose(g[k], p[k].grad.numpy(), rtol=1e-7, atol=1e-9)
+        # conv bias gradient is mathematically zero under training-mode BN
+        assert np.abs(g["b"]).max() < 1e-9 and p["b"].grad.abs().max() < 1e-9
+    # moving stats: 0.99*old + 0.01*batch
+    mm, mv = movings[0]
+    np.testing.assert_allclose(mm, 0.01 * stats[0][0].detach().numpy(), rtol=1e-9)
+    np.testing.assert_allclose(mv, 0.99 + 0.01 * stats[0][1].detach().numpy(), rtol=1e-9)
+
+
+def test_stack_inference_mode_vs_torch():
+    rng = np.random.default_rng(2)
+    spec = _tiny_spec()
+    params = R.init_params(spec, seed=4)
+    for p in params:
+        p["moving_mean"] = rng.uniform(-0.2, 0.2, p["moving_mean"].shape).astype(np.float32)
+        p["moving_var"] = rng.uniform(0.5, 2.0, p["moving_var"].shape).astype(np.float32)
+    x = rng.uniform(-1, 1, (2, 8, 8, 3)).astype(np.float32)
+    out, _, _ = R.run_stack(x, params, spec, False, np.float64)
+    ot, _ = T.run_stack(torch.tensor(x, dtype=torch.float64), T.to_torch_params(params, torch.float64), spec, False)
+    np.testing.assert_allclose(out, ot.numpy(), rtol=1e-9, atol=1e-10)
+
+
+def test_maxpool_odd_same_padding():
+    x = np.random.default_rng(0).standard_normal((1, 5, 7, 2))
+    y = R.max_pool_2x2(x)
+    yt = torch.nn.functional.max_pool2d(torch.tensor(x).permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+    np.testing.assert_allclose(y, yt.numpy())
+    assert y.shape == (1, 3, 4, 2)
+
+
+def make_labels(rng, n, S, image_size, num_class=20):
+    labels = np.zeros((n, S, S, 5 + num_class), np.float32)
+    for i in range(n):
+        objs = []
+        for _ in range(rng.integers(1, 4)):
+            x1, y1 = rng.uniform(1, image_size * 0.7, 2)
+            bw, bh = rng.uniform(image_size * 0.05, image_size * 0.3, 2)
+            objs.append((x1, y1, x1 + bw, y1 + bh, int(rng.integers(0, num_class))))
+        labels[i] = D.encode_boxes(objs, image_size, image_size, image_size, S, num_class)
+    return labels
+
+
+@pytest.mark.parametrize("S,image_size,n", [(7, 224, 3), (13, 416, 2)])
+def test_loss_forward_backward_vs_torch(S, image_size, n):
+    rng = np.random.default_rng(5)
+    B, C = 2, 20
+    net = rng.uniform(-0.5, 1.2, (n, S, S, C + 5 * B)).astype(np.float32)
+    labels = make_labels(rng, n, S, image_size)
+    off = L.yolo_grid_offset(S, B)
+    tot, ious, mask, parts = L.get_loss(net, labels, C, n, image_size, S, B, off, np.float64)
+    dnet = L.get_loss_backward(net, labels, C, n, image_size, S, B, off, np.float64)
+    nt = torch.tensor(net, dtype=torch.float64, requires_grad=True)
+    tt, it, mt, pt = T.get_loss(nt, torch.tensor(labels, dtype=torch.float64), C, n, image_size, S, B, off)
+    tt.backward()
+    np.testing.assert_allclose(tot, tt.item(), rtol=1e-12)
+    np.testing.assert_allclose(ious, it.detach().numpy(), rtol=1e-12, atol=1e-15)
+    assert (mask == mt.numpy()).all()
+    for k in parts:
+        np.testing.assert_allclose(parts[k], pt[k].item(), rtol=1e-12)
+    np.testing.assert_allclose(dnet, nt.grad.numpy(), rtol=1e-9, atol=1e-12)
+    assert mask.sum() >= n  # at least one responsible box per image
+    # some IoUs are non-trivial so the through-IoU gradient path is exercised
+    assert (ious > 0.01).sum() > 0
+
+
+def test_loss_numeric_gradient():
+    rng = np.random.default_rng(6)
+    S, B, C, n, image_size = 3, 2, 4, 2, 96
+    net = rng.uniform(0.1, 0.9, (n, S, S, C + 5 * B))
+    labels = make_labels(rng, n, S, image_size, C).astype(np.float64)
+    off = L.yolo_grid_offset(S, B)
+    f = lambda z: L.get_loss(z, labels, C, n, image_size, S, B, off, np.float64)[0]
+    g = L.get_loss_backward(net, labels, C, n, image_size, S, B, off, np.float64)
+    num = np.zeros_like(net)
+    eps = 1e-6
+    it = np.nditer(net, flags=["multi_index"])
+    for _ in it:
+        idx = it.multi_index
+        a = net.copy(); a[idx] += eps
+        b = net.copy(); b[idx] -= eps
+        num[idx] = (f(a) - f(b)) / (2 * eps)
+    np.testing.assert_allclose(g, num, rtol=2e-4, atol=1e-6)
+
+
+def test_softmax_ce_vs_torch():
+    rng = np.random.default_rng(7)
+    logits = rng.standard_normal((6, 11))
+    labels = rng.integers(0, 11, 6)
+    loss, dl = R.sparse_softmax_cross_entropy_mean(logits, labels)
+    lt = torch.tensor(logits, requires_grad=True)
+    l2 = torch.nn.functional.cross_entropy(lt, torch.tensor(labels))
+    l2.backward()
+    np.testing.assert_allclose(loss, l2.item(), rtol=1e-12)
+    np.testing.assert_allclose(dl, lt.grad.numpy(), rtol=1e-10, atol=1e-14)
+
+
+def test_adam_momentum_vs_torch():
+    rng = np.random.default_rng(8)
+    var = rng.standard_normal(50).astype(np.float32)
+    m = np.zeros(50, np.float32); v = np.zeros(50, np.float32)
+    vt = torch.tensor(var.copy(), requires_grad=True)
+    opt = torch.optim.Adam([vt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    for t in range(1, 4):
+        g = rng.standard_normal(50).astype(np.float32)
+        var, m, v = O.adam_step(var, m, v, g, t)
+        vt.grad = torch.tensor(g); opt.step()
+    # torch uses eps outside the bias correction (non "epsilon-hat"): agree to O(eps)
+    np.testing.assert_allclose(var, vt.detach().numpy(), rtol=0, atol=1e-6)
+    var = rng.standard_normal(50).astype(np.float32); acc = np.zeros(50, np.float32)
+    vt = torch.tensor(var.copy(), requires_grad=True)
+    opt = torch.optim.SGD([vt], lr=1e-3, momentum=0.9)
+    for t in range(3):
+        g = rng.standard_normal(50).astype(np.float32)
+        var, acc = O.momentum_step(var, acc, g)
+        vt.grad = torch.tensor(g); opt.step()
+    np.testing.assert_allclose(var, vt.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_decode_known_answer():
+    S, B, C = 7, 2, 20
+    p = np.zeros((S, S, C + 5 * B), np.float32)
+    # cell row 4, col 2, box 1: conf 0.9; x,y offsets .5,.25 ; sqrt(w),sqrt(h)= .5,.6 ; class 11
+    p[4, 2, C + 1] = 0.9
+    p[4, 2, C + B + 4:C + B + 8] = [0.5, 0.25, 0.5, 0.6]
+    p[4, 2, 11] = 3.0
+    p[0, 0, C] = 0.5          # == threshold: NOT kept (strict >)
+    dets = L.decode_detections(p, im_w=353, im_h=500, num_class=C, S=S, B=B)
+    assert len(dets) == 1
+    ulx, uly, w, h, cls, conf, r, c, b = dets[0]
+    # x=(0.5+2)/7*353=126.07->126 ; y=(0.25+4)/7*500=303.57->303 ; w=.25*353=88 ; h=.36*500=180 (float32 .36 -> 179.99..)
+    assert (w, cls, r, c, b) == (88, 11, 4, 2, 1)
+    assert h == int(float(np.float32(0.6) ** 2) * 500)
+    assert ulx == 126 - 44 and uly == 303 - h // 2
+
+
+def test_resize_identity_and_range():
+    img = np.random.default_rng(0).integers(0, 256, (10, 12, 3), dtype=np.uint8)
+    assert (D.resize_bilinear_u8(img, 10, 12) == img).all()
+    up = D.resize_bilinear_u8(img, 20, 24)
+    assert up.shape == (20, 24, 3) and up.min() >= img.min() and up.max() <= img.max()
+    x = D.normalise(img)
+    assert x.dtype == np.float32 and x.min() >= -1 and x.max() <= 1
