@@ -1,0 +1,119 @@
+/* libyolo2_hip.so -- C ABI of the MI355X (gfx950) Darknet-19 / YOLO grid-detector path.
+ *
+ * The reference (wenxichen/tensorflow_yolo2) has no FFI: its boundary is a set of
+ * Python functions that build TF1 graph nodes.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference root).  The
+ * Python mirrors of those functions (tensorflow_yolo2_amd/yolo2_nets/) bind
+ * these symbols with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions: plain C types only; every function returns 0 on success or a
+ * negative error code (message: y2_last_error()); the CALLER owns every device
+ * buffer (parameters, gradients, BN state, workspace, inputs, outputs); no hidden
+ * device allocation; all work is enqueued on the hipStream_t passed as `stream`
+ * (void*, NULL = default stream) and is asynchronous w.r.t. the host; one context
+ * per thread/device (thread-compatible, not thread-safe).
+ * Tensors are NHWC fp32 at the boundary (as the reference feeds TF); filters HWIO.
+ */
+#ifndef YOLO2_HIP_H
+#define YOLO2_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct y2_ctx y2_ctx;
+
+/* arithmetic type of the MFMA contractions / stored activations */
+#define Y2_F32 0  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode        */
+#define Y2_F16 1  /* fp16 operands, fp32 accumulate                              */
+#define Y2_BF16 2 /* bf16 operands, fp32 accumulate                              */
+
+#define Y2_TAIL_NONE 0    /* output = last layer activation [N,Ho,Wo,Cout]       */
+#define Y2_TAIL_AVGPOOL 1 /* + average_pooling2d(k,k) + reshape -> [N,Cout]      */
+
+#define Y2_OK 0
+#define Y2_ERR_ARG -1
+#define Y2_ERR_HIP -2
+#define Y2_ERR_STATE -3
+
+const char* y2_last_error(void);
+int y2_version(void);
+
+/* Layer list of the reference networks, 4 ints per layer (filter_size, in_chl,
+ * out_chl, maxpool_after).  kind 0: darknet19_core (src/yolo2_nets/darknet.py:126-179),
+ * kind 1: core + darknet19_detection(output_filter) (darknet.py:182-201),
+ * kind 2: darknet19 classifier (darknet.py:61-123).  Returns the layer count. */
+int y2_darknet19_spec(int kind, int output_filter, int* spec, int max_layers);
+
+/* ---- network context (replaces the TF graph + variables built by
+ *      conv_bn_layer, src/yolo2_nets/darknet.py:32-46) ------------------------ */
+int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers, int tail, int tail_k,
+                  int batch, int height, int width, int dtype);
+void y2_ctx_destroy(y2_ctx* ctx);
+int y2_num_layers(const y2_ctx* ctx);
+/* info: k, cin, cout, pool, H, W (conv input = output spatial size), Ho, Wo */
+int y2_layer_info(const y2_ctx* ctx, int layer, int info[8]);
+/* trainable floats in reference creation order per layer: W (HWIO), b, gamma, beta */
+size_t y2_param_count(const y2_ctx* ctx);
+/* BN moving statistics per layer: moving_mean, moving_variance */
+size_t y2_state_count(const y2_ctx* ctx);
+/* off[0..3]: W, b, gamma, beta offsets (floats) into params/grads; off[4..5]: moving_mean, moving_variance into state */
+int y2_param_offsets(const y2_ctx* ctx, int layer, size_t off[6]);
+int y2_output_shape(const y2_ctx* ctx, int shape[4]);
+size_t y2_workspace_bytes(const y2_ctx* ctx, int training);
+int y2_bind(y2_ctx* ctx, float* params, float* grads, float* state, void* workspace, size_t workspace_bytes,
+            int training, void* stream);
+/* loss-scale applied to half-precision gradients (1 = none); moving-variance Bessel switch */
+int y2_set_options(y2_ctx* ctx, float grad_scale, int bessel_moving_var);
+/* weight_variable / bias_variable / BN initial values (darknet.py:10-17): truncated
+ * normal(0.1) re-drawn beyond 2 sigma, 0.1, gamma 1, beta 0, moving 0 / 1 */
+int y2_init_params(y2_ctx* ctx, uint64_t seed, void* stream);
+/* call after params were changed from outside (load / optimizer on a foreign buffer) */
+int y2_params_changed(y2_ctx* ctx);
+
+/* darknet19_core / darknet19_detection / darknet19 forward
+ * (darknet.py:61-201): images [N,H,W,3] fp32 -> out (shape: y2_output_shape) */
+int y2_forward(y2_ctx* ctx, const float* images, int is_training_core, int is_training_head, float* out,
+               void* stream);
+/* TF autodiff of the stack (tf.train.*Optimizer().minimize, pascal_train_darknet.py:49-51):
+ * dout has the output's shape; gradients are written to the bound `grads` buffer
+ * for layers [layer_lo, layer_hi) walking downwards; call with (0, num_layers)
+ * for the whole net, or in slices to overlap the all-reduce of finished layers. */
+int y2_backward(y2_ctx* ctx, const float* dout, int layer_lo, int layer_hi, void* stream);
+/* copy a layer's saved activation (post BN+leaky+pool input of `layer`, or conv output) for tests */
+int y2_debug_read(y2_ctx* ctx, int layer, int what, float* dst, void* stream);
+
+/* ---- get_loss / get_iou / show_yolo_detection (src/yolo2_nets/net_utils.py:222-439) */
+size_t y2_yolo_loss_workspace_bytes(int batch, int S);
+/* loss[5] = class, object, noobject, coord, total; dnet may be NULL */
+int y2_yolo_loss(const float* net, const float* labels, int num_class, int batch, float image_size, int S, int B,
+                 float lambda_coord, float lambda_noobj, float* loss, float* ious, float* object_mask,
+                 float* dnet, void* workspace, void* stream);
+int y2_get_iou(const float* boxes1, const float* boxes2, float* iou, int n_boxes, void* stream);
+/* det[(cell*B+b)*8 + {keep, upper_left_x, upper_left_y, w, h, class, cell_row, cell_col}] */
+int y2_decode_detections(const float* predict, int S, int B, int num_class, int im_w, int im_h,
+                         float object_thresh, int* det, float* conf, void* stream);
+/* sparse_softmax_cross_entropy_with_logits + reduce_mean (imagenet_train_darknet.py:51-53) */
+int y2_softmax_cross_entropy(const float* logits, const int* labels, int batch, int classes, float* loss,
+                             float* dlogits, void* stream);
+
+/* ---- optimizers on flat buffers (pascal_train_darknet.py:51, imagenet_train_darknet.py:58) */
+int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n, int step, float lr,
+                 float beta1, float beta2, float eps, float grad_mult, void* stream);
+int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, float lr, float momentum,
+                     float grad_mult, void* stream);
+
+/* ---- single-op entry points (tf.nn.conv2d 'SAME' stride 1, darknet.py:20-21) used by the
+ *      per-op parity tests; channel counts are padded internally to the kernels' granularity */
+size_t y2_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int k, int dtype);
+int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
+              int Cout, int k, int dtype, void* workspace, void* stream);
+int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int N, int H,
+                       int W, int Cin, int Cout, int k, int dtype, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -39,8 +39,8 @@ def scaled_spec(spec, width_div):
         return list(spec)
     out = []
     for (k, ci, co, p) in spec:
-        ci2 = ci if ci == 3 else max(ci // width_div, 8)
-        co2 = max(co // width_div, 8)
+        ci2 = ci if ci == 3 else max(ci // width_div, 32)
+        co2 = max(co // width_div, 32)
         out.append((k, ci2, co2, p))
     return out
 

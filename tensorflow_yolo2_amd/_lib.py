@@ -1,0 +1,90 @@
+"""ctypes binding of libyolo2_hip.so (C ABI: include/yolo2_hip.h).
+
+There is NO fallback: if the HIP library is missing or a symbol is absent the
+import fails loudly.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C tensorflow_yolo2_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo2_hip.so")
+
+Y2_F32, Y2_F16, Y2_BF16 = 0, 1, 2
+Y2_TAIL_NONE, Y2_TAIL_AVGPOOL = 0, 1
+DTYPES = {"f32": Y2_F32, "fp32": Y2_F32, "float32": Y2_F32,
+          "f16": Y2_F16, "fp16": Y2_F16, "float16": Y2_F16,
+          "bf16": Y2_BF16, "bfloat16": Y2_BF16}
+
+_vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+_pi = C.POINTER(C.c_int)
+_psz = C.POINTER(C.c_size_t)
+
+# name -> (restype, argtypes); must list every symbol include/yolo2_hip.h declares
+SIGNATURES = {
+    "y2_last_error": (C.c_char_p, []),
+    "y2_version": (_i, []),
+    "y2_darknet19_spec": (_i, [_i, _i, _pi, _i]),
+    "y2_ctx_create": (_i, [C.POINTER(_vp), _pi, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "y2_ctx_destroy": (None, [_vp]),
+    "y2_num_layers": (_i, [_vp]),
+    "y2_layer_info": (_i, [_vp, _i, _pi]),
+    "y2_param_count": (_sz, [_vp]),
+    "y2_state_count": (_sz, [_vp]),
+    "y2_param_offsets": (_i, [_vp, _i, _psz]),
+    "y2_output_shape": (_i, [_vp, _pi]),
+    "y2_workspace_bytes": (_sz, [_vp, _i]),
+    "y2_bind": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "y2_set_options": (_i, [_vp, _f, _i]),
+    "y2_init_params": (_i, [_vp, _u64, _vp]),
+    "y2_params_changed": (_i, [_vp]),
+    "y2_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "y2_backward": (_i, [_vp, _vp, _i, _i, _vp]),
+    "y2_debug_read": (_i, [_vp, _i, _i, _vp, _vp]),
+    "y2_yolo_loss_workspace_bytes": (_sz, [_i, _i]),
+    "y2_yolo_loss": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "y2_get_iou": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "y2_decode_detections": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "y2_softmax_cross_entropy": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "y2_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
+    "y2_momentum_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
+    "y2_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "y2_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "y2_conv2d_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+}
+
+
+class Y2Error(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Y2Error("HIP extension not built: %s is missing (run __graft_entry__.build())" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is absent
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Y2Error("libyolo2_hip: error %d: %s" % (rc, load().y2_last_error().decode()))
+
+
+def darknet19_spec(kind, output_filter=30):
+    buf = (C.c_int * (4 * 32))()
+    n = load().y2_darknet19_spec(kind, output_filter, buf, 32)
+    if n < 0:
+        check(n)
+    return [tuple(buf[i * 4 + j] for j in range(4)) for i in range(n)]

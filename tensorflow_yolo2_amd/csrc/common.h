@@ -1,0 +1,109 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// wave = 64 lanes; MFMA 32x32 tiles; LDS 160 KiB/CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace y2 {
+
+typedef _Float16 half_t;
+typedef __bf16 bf16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define Y2_DEV __device__ __forceinline__
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------
+// Element traits.  A "fragment" is always 16 bytes per lane: 8 halfs / 8 bf16 /
+// 4 floats.  One 32-byte k-group of a row feeds lanes h=0 (bytes 0..15) and
+// h=1 (bytes 16..31) of a 32x32 MFMA:
+//   f16/bf16: one v_mfma_f32_32x32x16  (k = 16 per group)
+//   f32     : four v_mfma_f32_32x32x2  (k = 8 per group; component s of the
+//             fragment pairs k = s (h=0) with k = 4+s (h=1): a k-permutation
+//             applied identically to both operands, so the sum is unchanged)
+// ---------------------------------------------------------------------------
+template <typename T> struct Elem;
+
+template <> struct Elem<float> {
+    typedef f32x4 frag;
+    static constexpr int kPerFrag = 4;
+    static constexpr int kId = 0;
+    static Y2_DEV float to_f32(float v) { return v; }
+    static Y2_DEV float from_f32(float v) { return v; }
+};
+template <> struct Elem<half_t> {
+    typedef f16x8 frag;
+    static constexpr int kPerFrag = 8;
+    static constexpr int kId = 1;
+    static Y2_DEV float to_f32(half_t v) { return (float)v; }
+    static Y2_DEV half_t from_f32(float v) { return (half_t)v; }
+};
+template <> struct Elem<bf16_t> {
+    typedef bf16x8 frag;
+    static constexpr int kPerFrag = 8;
+    static constexpr int kId = 2;
+    static Y2_DEV float to_f32(bf16_t v) { return (float)v; }
+    static Y2_DEV bf16_t from_f32(float v) { return (bf16_t)v; }
+};
+
+// acc[rows(regs)][cols(lanes)] += A(rows x k) * B(k x cols)
+// C/D layout (all dtypes): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+Y2_DEV void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[3], acc, 0, 0, 0);
+}
+Y2_DEV void mma32(f32x16& acc, const f16x8& a, const f16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
+}
+Y2_DEV void mma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+// row index inside a 32x32 accumulator tile held by (reg q, lane half h)
+Y2_DEV int acc_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+
+// 16-byte vector of T (a "chunk"): load/store + per-element float access
+template <typename T> struct Chunk {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+template <typename T> Y2_DEV Chunk<T> ld_chunk(const void* p) {
+    Chunk<T> c;
+    *reinterpret_cast<u32x4*>(c.v) = *reinterpret_cast<const u32x4*>(p);
+    return c;
+}
+template <typename T> Y2_DEV void st_chunk(void* p, const Chunk<T>& c) {
+    *reinterpret_cast<u32x4*>(p) = *reinterpret_cast<const u32x4*>(c.v);
+}
+
+// async global -> LDS, 16 B per lane.  LDS destination = lds_base + lane*16
+// (wave-uniform base: hardware rule); the GLOBAL address is per lane.
+Y2_DEV void glds16(const void* gptr, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gptr,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+Y2_DEV float wave_sum_xor(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
+
+Y2_DEV float leaky01(float z) { return fmaxf(0.1f * z, z); }
+// TF maximum(alpha*z, z): gradient to alpha*z where alpha*z >= z, i.e. z <= 0
+Y2_DEV float leaky01_slope(float z) { return (0.1f * z >= z) ? 0.1f : 1.0f; }
+
+// fast unsigned division by a runtime constant via 32-bit magic (valid for n < 2^31)
+struct FastDiv {
+    uint32_t d, m, s;  // q = (hi32(n*m) + n) >> s  (round-up method)
+};
+
+}  // namespace y2

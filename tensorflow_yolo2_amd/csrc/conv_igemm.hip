@@ -1,0 +1,318 @@
+// Implicit-GEMM stride-1 SAME convolution (3x3 or 1x1) on MFMA, gfx950.
+//
+// Replaces tf.nn.conv2d(x, W, [1,1,1,1], 'SAME') + bias add
+// (reference src/yolo2_nets/darknet.py:20-21,32-36) and, with tap-flipped
+// transposed weights, its Conv2DBackpropInput (dgrad).
+//
+// Layout (MI355X-first, not TF's):
+//   x   : zero-bordered NHWC  [N][H+2][W+2][C]   -> no bounds checks, every tap
+//         of every pixel row is one contiguous BKB-byte read
+//   w   : packed [Cout_pad][taps][C] (K contiguous per output channel)
+//   y   : [M = N*H*W][ldy]
+// GEMM view: D[cout][pixel] += Wp[cout][k] * X[pixel][k], k = (tap, c).
+// The accumulator tile keeps the pixel on the lane and 4 consecutive couts in
+// 4 consecutive registers, so the epilogue packs 4 couts per LDS store, then
+// re-reads whole 16-byte chunks per pixel row and stores full lines to HBM.
+// Batch-norm sufficient statistics (per block: count, mean, M2 about that
+// mean -- Chan/Welford form, never E[x^2]-E[x]^2) are produced by the same
+// epilogue from the values as stored.
+//
+// Staging: global_load_lds 16 B/lane, double-buffered LDS, XOR swizzle applied
+// on the per-lane SOURCE address and on the ds_read (LDS image stays linear,
+// cdna guide rule 21), conflict-free for ds_read_b128.
+#include "common.h"
+#include "kernels.h"
+
+namespace y2 {
+
+template <typename T, int WP, int WC, int TP, int TC, int BKB>
+struct ConvCfg {
+    static constexpr int NW = WP * WC;
+    static constexpr int NT = NW * 64;
+    static constexpr int BP = WP * TP * 32;  // pixels per block
+    static constexpr int BC = WC * TC * 32;  // output channels per block
+    static constexpr int SZ = sizeof(T);
+    static constexpr int LPR = BKB / 16;     // lanes per staged row
+    static constexpr int RPI = 64 / LPR;     // rows per glds wave-instruction
+    static constexpr int RPB = 256 / BKB;    // rows per 256-B LDS bank row
+    static constexpr int NI_P = BP / RPI;
+    static constexpr int NI_C = BC / RPI;
+    static constexpr int NI = NI_P + NI_C;
+    static constexpr int IPW = (NI + NW - 1) / NW;
+    static constexpr int STAGE = (BP + BC) * BKB;
+    static constexpr int KG = BKB / 32;
+    // epilogue staging: per wave [TP*32 pixels][TC*32 couts] + 16 B row pad
+    static constexpr int EROW = TC * 32 * SZ + 16;
+    static constexpr int EPW = TP * 32 * EROW;
+    static constexpr int ESTAT = NW * TC * 32 * 2 * 4;
+    static constexpr int LDS_MAIN = 2 * STAGE;
+    static constexpr int LDS_EPI = NW * EPW + ESTAT;
+    static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
+    static_assert(NI_P % NW == 0, "pixel rows must split evenly over waves");
+};
+
+template <typename T, int WP, int WC, int TP, int TC, int BKB>
+__global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
+    typedef ConvCfg<T, WP, WC, TP, TC, BKB> Cfg;
+    typedef typename Elem<T>::frag frag_t;
+    constexpr int NW = Cfg::NW, BP = Cfg::BP, BC = Cfg::BC, SZ = Cfg::SZ;
+    constexpr int LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB, IPW = Cfg::IPW, KG = Cfg::KG;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w / WC, wc = w % WC;
+    const int nCT = (a.Cout + BC - 1) / BC;
+    const int ct = blockIdx.x % nCT, pt = blockIdx.x / nCT;
+    const int m0 = pt * BP, n0 = ct * BC;
+    const int Ktot = a.taps * a.C;  // elements per packed weight row
+    const char* __restrict__ xg = (const char*)a.x;
+    const char* __restrict__ wg = (const char*)a.w;
+
+    // ---- per-lane source offsets for the staging loads
+    uint32_t voff[IPW];
+    const int lrow = lane / LPR, lslot = lane % LPR;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int ii = i * NW + w;
+        const int row = ii * RPI + lrow;
+        if (i * NW < Cfg::NI_P) {  // pixel rows (compile-time per i)
+            const int p = m0 + row;
+            uint32_t base = 0;
+            if (p < a.M) {
+                const int hw = a.H * a.W;
+                const int n = p / hw, rem = p - n * hw;
+                const int h = rem / a.W, ww = rem - h * a.W;
+                base = (uint32_t)((n * (a.H + 2) + h) * (a.W + 2) + ww) * (uint32_t)(a.C * SZ);
+            }
+            voff[i] = base + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+        } else {
+            const int r = row - BP;
+            voff[i] = (uint32_t)(n0 + r) * (uint32_t)(Ktot * SZ) + (uint32_t)((lslot ^ ((r / RPB) % LPR)) * 16);
+        }
+    }
+    const int cpt = (a.C * SZ) / BKB;  // k-chunks per tap
+    const int nK = a.taps * cpt;
+    const int rowpitch = (a.W + 2) * a.C * SZ;
+
+    auto stage = [&](int kk, int buf) {
+        const int t = kk / cpt, c = kk - t * cpt;
+        int tapoff;
+        if (a.taps == 9) {
+            const int kh = t / 3, kw = t - kh * 3;
+            tapoff = kh * rowpitch + kw * a.C * SZ;
+        } else {
+            tapoff = rowpitch + a.C * SZ;
+        }
+        const char* xs = xg + tapoff + c * BKB;
+        const char* ws = wg + (size_t)(t * a.C * SZ + c * BKB);
+        char* lbase = smem + buf * Cfg::STAGE;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int ii = i * NW + w;
+            if (i * NW < Cfg::NI_P) {
+                glds16(xs + voff[i], lbase + ii * 1024);
+            } else if ((i + 1) * NW <= Cfg::NI || ii < Cfg::NI) {
+                glds16(ws + voff[i], lbase + ii * 1024);
+            }
+        }
+    };
+
+    // ---- fragment read offsets (swizzle term is tile-independent: rows differ by 32)
+    const int r32 = lane & 31, hh = lane >> 5;
+    int foff[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) foff[g] = r32 * BKB + (((2 * g + hh) ^ ((r32 / RPB) % LPR)) * 16);
+    const int pbase = (wp * TP) * 32 * BKB;
+    const int cbase = BP * BKB + (wc * TC) * 32 * BKB;
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    stage(0, 0);
+    __syncthreads();  // hipcc drains vmcnt(0) before the barrier
+    for (int kk = 0; kk < nK; ++kk) {
+        const int buf = kk & 1;
+        if (kk + 1 < nK) stage(kk + 1, buf ^ 1);
+        const char* lb = smem + buf * Cfg::STAGE;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            frag_t fc[TC], fp[TP];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) fc[i] = *(const frag_t*)(lb + cbase + i * 32 * BKB + foff[g]);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) fp[j] = *(const frag_t*)(lb + pbase + j * 32 * BKB + foff[g]);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) mma32(acc[i][j], fc[i], fp[j]);
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    constexpr int EROW = Cfg::EROW;
+    char* ew = smem + w * Cfg::EPW;
+    const int cw0 = n0 + wc * TC * 32;  // first cout of this wave
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int cl = i * 32 + 8 * q4 + 4 * hh;  // local cout of register 4*q4
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b4[j] = (cw0 + cl + j < a.Cout) ? a.bias[cw0 + cl + j] : 0.f;
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < TP; ++j2) {
+                T o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = Elem<T>::from_f32(acc[i][j2][4 * q4 + j] + b4[j]);
+                char* dst = ew + (j2 * 32 + r32) * EROW + cl * SZ;
+                if (SZ == 2) *(u32x2*)dst = *(const u32x2*)o;
+                else *(u32x4*)dst = *(const u32x4*)o;
+            }
+        }
+    }
+    __syncthreads();
+
+    constexpr int EPC = 16 / SZ;                 // elements per chunk
+    constexpr int CPR = TC * 32 / EPC;           // chunks per pixel row
+    constexpr int RPIe = 64 / CPR;               // pixel rows per read instruction
+    constexpr int NIT = TP * 32 / RPIe;
+    const int ch = lane % CPR, prow0 = lane / CPR;
+    const int mw0 = m0 + wp * TP * 32;           // first pixel of this wave
+    const int cch = cw0 + ch * EPC;              // first cout of this lane's chunk
+    float vals[NIT][EPC];
+    float s[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int prow = it * RPIe + prow0;
+        Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
+        const bool pv = (mw0 + prow) < a.M;
+        if (pv && cch < a.ldy) st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            vals[it][e] = pv ? Elem<T>::to_f32(c.v[e]) : 0.f;
+            s[e] += vals[it][e];
+        }
+    }
+    if (a.part_mean) {
+        int cntw = a.M - mw0;
+        cntw = cntw < 0 ? 0 : (cntw > TP * 32 ? TP * 32 : cntw);
+        const float inv = cntw > 0 ? 1.0f / (float)cntw : 0.f;
+        float mean[EPC], m2[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+#pragma unroll
+            for (int msk = CPR; msk < 64; msk <<= 1) s[e] = wave_sum_xor(s[e], msk);
+            mean[e] = s[e] * inv;
+            m2[e] = 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const bool pv = (mw0 + it * RPIe + prow0) < a.M;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float d = pv ? vals[it][e] - mean[e] : 0.f;
+                m2[e] += d * d;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+#pragma unroll
+            for (int msk = CPR; msk < 64; msk <<= 1) m2[e] = wave_sum_xor(m2[e], msk);
+        // combine the WP waves that share these channels (Chan's parallel update)
+        float* st = (float*)(smem + NW * Cfg::EPW);
+        if (prow0 == 0) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                st[(w * TC * 32 + ch * EPC + e) * 2 + 0] = mean[e];
+                st[(w * TC * 32 + ch * EPC + e) * 2 + 1] = m2[e];
+            }
+        }
+        __syncthreads();
+        if (wp == 0 && prow0 == 0) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                float n_acc = 0.f, mean_acc = 0.f, m2_acc = 0.f;
+                for (int k = 0; k < WP; ++k) {
+                    int cntk = a.M - (m0 + k * TP * 32);
+                    cntk = cntk < 0 ? 0 : (cntk > TP * 32 ? TP * 32 : cntk);
+                    if (cntk == 0) continue;
+                    const int wk = k * WC + wc;
+                    const float mk = st[(wk * TC * 32 + ch * EPC + e) * 2 + 0];
+                    const float vk = st[(wk * TC * 32 + ch * EPC + e) * 2 + 1];
+                    const float nn = n_acc + (float)cntk;
+                    const float dlt = mk - mean_acc;
+                    mean_acc += dlt * ((float)cntk / nn);
+                    m2_acc += vk + dlt * dlt * (n_acc * (float)cntk / nn);
+                    n_acc = nn;
+                }
+                const int co = cch + e;
+                if (co < a.ldy) {
+                    a.part_mean[(size_t)pt * a.ldy + co] = mean_acc;
+                    a.part_m2[(size_t)pt * a.ldy + co] = m2_acc;
+                }
+            }
+        }
+        if (tid == 0 && ct == 0) {
+            int cb = a.M - m0;
+            a.part_cnt[pt] = (float)(cb > BP ? BP : cb);
+        }
+    }
+}
+
+template <typename T, int WP, int WC, int TP, int TC, int BKB>
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
+    typedef ConvCfg<T, WP, WC, TP, TC, BKB> Cfg;
+    auto kern = conv_igemm_kernel<T, WP, WC, TP, TC, BKB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nPT = (a.M + Cfg::BP - 1) / Cfg::BP;
+    const int nCT = (a.Cout + Cfg::BC - 1) / Cfg::BC;
+    hipLaunchKernelGGL(kern, dim3(nPT * nCT), dim3(Cfg::NT), Cfg::LDS, s, a);
+    return hipGetLastError();
+}
+
+// tile choice by output-channel count; rows-per-partial (BP) is reported back
+template <typename T>
+static hipError_t launch_T(const ConvArgs& a, hipStream_t s) {
+    const int kb = a.C * (int)sizeof(T);  // bytes per tap per pixel
+    const bool k128 = (kb % 128) == 0;
+    if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
+    if (a.Cout > 64) {
+        return k128 ? launch_cfg<T, 2, 2, 2, 2, 128>(a, s) : launch_cfg<T, 2, 2, 2, 2, 64>(a, s);
+    } else if (a.Cout > 32) {
+        return k128 ? launch_cfg<T, 4, 1, 2, 2, 128>(a, s) : launch_cfg<T, 4, 1, 2, 2, 64>(a, s);
+    } else {
+        return k128 ? launch_cfg<T, 4, 1, 2, 1, 128>(a, s) : launch_cfg<T, 4, 1, 2, 1, 64>(a, s);
+    }
+}
+
+int conv_block_pixels(int Cout) { return Cout > 64 ? 128 : 256; }
+int conv_block_couts(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+
+hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
+    switch (dtype) {
+        case 0: return launch_T<float>(a, s);
+        case 1: return launch_T<half_t>(a, s);
+        case 2: return launch_T<bf16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace y2

@@ -1,0 +1,170 @@
+// Internal launcher interface between the network executor (net.hip) and the
+// gfx950 kernels.  dtype: 0 = f32 (parity mode, exact-f32 MFMA), 1 = f16, 2 = bf16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace y2 {
+
+inline size_t dtype_size(int dtype) { return dtype == 0 ? 4 : 2; }
+
+struct ConvArgs {
+    const void* x;      // zero-bordered NHWC [N][H+2][W+2][C]
+    const void* w;      // packed [Cout_pad][taps][C]
+    void* y;            // [M][ldy]
+    const float* bias;  // [Cout] or null
+    float* part_cnt;    // [P]            BN partials (null: no statistics)
+    float* part_mean;   // [P][ldy]
+    float* part_m2;     // [P][ldy]
+    int N, H, W, C;
+    int M;              // N*H*W
+    int Cout;
+    int ldy;
+    int taps;           // 9 (3x3) or 1 (1x1)
+};
+hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);
+int conv_block_pixels(int Cout);
+int conv_block_couts(int Cout);
+
+// ---- first layer (Cin = 3, stored as 4 channels)
+struct Conv1Args {
+    const void* x4;     // [N][H+2][W+2][4]
+    const void* w;      // packed [32][3][16] (kh, then kw*4+c, 12 real + 4 zero)
+    void* y;            // [M][32]
+    const float* bias;
+    float* part_cnt;
+    float* part_mean;
+    float* part_m2;
+    int N, H, W, M;
+    int nblocks;        // persistent grid size == number of partials
+};
+hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s);
+struct Conv1WgradArgs {
+    const void* x4;     // [N][H+2][W+2][4]
+    const void* dy;     // zero-bordered [N][H+2][W+2][32]
+    float* dW;          // [3][3][3][32] fp32, accumulated with atomics (pre-zeroed)
+    int N, H, W, M;
+    float scale;        // 1 / grad_scale
+};
+hipError_t launch_conv1_wgrad(int dtype, const Conv1WgradArgs& a, hipStream_t s);
+
+// ---- weight-gradient GEMM  dW[t][ci][co] += sum_p X[p+t][ci] * dY[p][co]
+struct WgradArgs {
+    const void* x;      // zero-bordered [N][H+2][W+2][Cin]
+    const void* dy;     // zero-bordered [N][H+2][W+2][Cdy]
+    float* dW;          // [taps][Cin][Cout] fp32 (HWIO), accumulated with atomics
+    int N, H, W, M;
+    int Cin, Cdy, Cout; // Cdy = channel stride of dy (>= Cout)
+    int taps;
+    int splitk;
+    float scale;
+};
+hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
+
+// ---- packing
+hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H, int W, hipStream_t s);
+// fwd:  wf[co][t][ci] = W[t][ci][co]           rows co >= Cout zero (Cout_pad rows)
+// dgrad: wd[ci][t'][co] = W[8-t'][ci][co]       rows ci >= Cin zero, cols co >= Cout zero (Cdy cols)
+//   Kc = row length per tap of wf (>= Cin, zero beyond Cin)
+hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, int taps, int Cin, int Cout,
+                               int Cout_pad, int Kc, int Cin_pad, int Cdy, hipStream_t s);
+hipError_t launch_pack_conv1_weights(int dtype, const float* W, void* wp, hipStream_t s);
+hipError_t launch_convert_grad(int dtype, const float* src, void* dst, int M, int C, int ldd, float scale,
+                               hipStream_t s);
+hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H, int W, int C, int Cs,
+                             hipStream_t s);
+hipError_t launch_pack_act(int dtype, const float* in, void* xp, int N, int H, int W, int C, int Cs,
+                           hipStream_t s);
+hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s);
+
+// ---- batch norm
+struct BnFinalizeArgs {
+    const float* part_cnt;
+    const float* part_mean;
+    const float* part_m2;
+    int P, C, ldp;
+    const float* gamma;
+    const float* beta;
+    float* moving_mean;   // updated in place when update_moving
+    float* moving_var;
+    float* scale;         // out: gamma * rsqrt(var + eps)
+    float* shift;         // out: beta - mean * scale
+    float* mean;          // out (saved for backward)
+    float* invstd;        // out
+    float eps, momentum;
+    int update_moving;
+    int bessel;
+};
+hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+hipError_t launch_bn_infer_prepare(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                   float* scale, float* shift, float* mean, float* invstd, int C, float eps,
+                                   hipStream_t s);
+struct BnActArgs {
+    const void* y;        // [M][ldy]
+    const float* scale;
+    const float* shift;
+    void* out;            // zero-bordered [N][Ho+2][Wo+2][C] of T, or (out_f32) float [M][C] compact
+    int N, H, W, C, ldy;
+    int pool;             // 2x2/2 SAME max pool after the activation
+    int out_f32;
+};
+hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t s);
+
+struct BnBwdArgs {
+    const void* dA;       // grad wrt layer output [M_out][ldd] of T (scaled by grad_scale)
+    const void* y;        // conv output [M][ldy]
+    const float* scale;   // gamma*invstd
+    const float* shift;
+    const float* mean;
+    const float* invstd;
+    float* psum;          // [P][2][C] partial sums (dz, dz*xhat)
+    float* dgamma;        // out (unscaled)
+    float* dbeta;
+    float* dbias;         // out: sum(dy) (atomics, pre-zeroed)
+    float* coef;          // [2][C]: c1 = sum(dz)/M, c2 = sum(dz*xhat)/M   (scaled domain)
+    void* dyp;            // out: zero-bordered [N][H+2][W+2][ldy] of T
+    int N, H, W, C, ldy, ldd;
+    int pool;
+    int training;         // batch statistics (1) or moving statistics (0)
+    float inv_grad_scale;
+    int P;                // number of partial blocks (set by launcher)
+};
+int bn_bwd_partials(const BnBwdArgs& a);
+hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s);
+hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
+hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s);
+
+// ---- loss / heads
+struct LossArgs {
+    const float* net;     // [N][S][S][C + 5B]
+    const float* labels;  // [N][S][S][5 + C]
+    float* loss;          // [5]: class, object, noobject, coord, total
+    float* ious;          // [N][S][S][B]
+    float* mask;          // [N][S][S][B]
+    float* dnet;          // [N][S][S][C+5B] or null
+    float* partial;       // [nblocks][4]
+    int N, S, B, C;
+    float image_size;
+    float lambda_coord, lambda_noobj;
+};
+int loss_blocks(int N, int S);
+hipError_t launch_yolo_loss(const LossArgs& a, hipStream_t s);
+hipError_t launch_get_iou(const float* b1, const float* b2, float* out, int n, hipStream_t s);
+hipError_t launch_decode(const float* pred, int S, int B, int C, int im_w, int im_h, float thresh, int* out,
+                         float* out_conf, hipStream_t s);
+hipError_t launch_avgpool_fwd(const float* h, float* out, int N, int H, int W, int C, int k, hipStream_t s);
+hipError_t launch_avgpool_bwd(const float* dout, float* dh, int N, int H, int W, int C, int k, hipStream_t s);
+hipError_t launch_softmax_ce(const float* logits, const int* labels, float* loss, float* dlogits, int N, int C,
+                             hipStream_t s);
+
+// ---- optimizers (flat buffers)
+hipError_t launch_adam(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float b1, float b2,
+                       float eps, float gscale, hipStream_t s);
+hipError_t launch_momentum(float* p, float* acc, const float* g, size_t n, float lr, float mom, float gscale,
+                           hipStream_t s);
+hipError_t launch_init_trunc_normal(float* p, size_t n, float stddev, uint64_t seed, uint64_t stream_id,
+                                    hipStream_t s);
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
+
+}  // namespace y2

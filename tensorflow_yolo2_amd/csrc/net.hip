@@ -1,0 +1,633 @@
+// Network executor + C ABI (include/yolo2_hip.h).
+//
+// Replaces the TF1 graph that src/yolo2_nets/darknet.py builds out of
+// conv_bn_layer (conv2d + bias -> batch_normalization -> leaky -> max_pool) and
+// the autodiff graph behind tf.train.*Optimizer().minimize
+// (src/pascal/pascal_train_darknet.py:49-51).  The executor owns no memory: it
+// plans offsets inside ONE caller-provided workspace sized for MI355X's 288 GB
+// HBM (every layer keeps its own bordered activation, conv output and gradient
+// buffers: nothing is re-zeroed or re-laid-out between steps).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/yolo2_hip.h"
+#include "kernels.h"
+
+using namespace y2;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return fail(Y2_ERR_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                          __FILE__, __LINE__);                                        \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+constexpr float kBnEps = 1e-3f;       // tf.layers.batch_normalization defaults
+constexpr float kBnMomentum = 0.99f;
+
+// zero-bordered NHWC tensor with guard bands (see wgrad.hip): geometry helper
+struct PadGeom {
+    int N, H, W, C;
+    size_t front_px() const { return (size_t)W + 3; }
+    size_t body_px() const { return (size_t)N * (H + 2) * (W + 2); }
+    size_t back_px() const { return (size_t)W + 3 + 256; }
+    size_t bytes(size_t sz) const { return align_up((front_px() + body_px() + back_px()) * C * sz + 64, 256); }
+    size_t base_off(size_t sz) const { return front_px() * C * sz; }
+};
+
+struct Layer {
+    int k, cin, cout, pool;
+    int H, W, Ho, Wo, M;
+    int cin_s;       // channel stride of the bordered input tensor
+    int ldy;         // channel stride of the conv output / its gradient
+    int cout_pad;    // rows of packed forward filter
+    int cin_pad;     // rows of packed dgrad filter
+    bool first3;     // Cin = 3 special layer
+    size_t pW, pb, pg, pbeta;  // float offsets into params / grads
+    size_t smm, smv;           // float offsets into state
+    // byte offsets into the workspace
+    size_t xin, y, stat, wf, wd, dyp;
+};
+
+struct y2_ctx {
+    int N, H, W, dtype, tail, tail_k, core_layers;
+    std::vector<Layer> L;
+    size_t nparams = 0, nstate = 0;
+    int outN, outH, outW, outC;
+    float grad_scale = 1.f;
+    int bessel = 0;
+    // bound memory
+    float* params = nullptr;
+    float* grads = nullptr;
+    float* state = nullptr;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int bound_training = 0;
+    bool weights_dirty = true;
+    bool fwd_saved = false;
+    std::vector<int> fwd_training;  // per layer BN mode of the last forward
+    // shared scratch offsets
+    size_t o_part_cnt, o_part_mean, o_part_m2, o_psum, o_dA0, o_dA1, o_h32, o_dh32, o_xin_last_end;
+    size_t part_rows, part_ld;
+    size_t total_infer = 0, total_train = 0;
+    int dA_cur = 0;
+    size_t sz() const { return dtype_size(dtype); }
+    PadGeom in_geom(int l) const { return PadGeom{N, L[l].H, L[l].W, L[l].cin_s}; }
+    PadGeom dy_geom(int l) const { return PadGeom{N, L[l].H, L[l].W, L[l].ldy}; }
+};
+
+static void plan(y2_ctx* c) {
+    const size_t sz = c->sz();
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    size_t max_part_rows = 1, max_ld = 32, max_dA = 0;
+    for (size_t l = 0; l < c->L.size(); ++l) {
+        Layer& y = c->L[l];
+        y.xin = take(c->in_geom((int)l).bytes(sz));
+        y.y = take((size_t)y.M * y.ldy * sz + 256);
+        y.stat = take((size_t)6 * y.ldy * sizeof(float));  // scale, shift, mean, invstd, coef[2]
+        if (y.first3) {
+            y.wf = take((size_t)32 * 3 * 16 * sz);
+            y.wd = 0;
+        } else {
+            y.wf = take((size_t)y.cout_pad * y.k * y.k * y.cin_s * sz);
+            y.wd = take((size_t)y.cin_pad * y.k * y.k * y.ldy * sz);
+        }
+        size_t prow = y.first3 ? 2048 : (size_t)(y.M + conv_block_pixels(y.cout) - 1) / conv_block_pixels(y.cout);
+        if (prow > max_part_rows) max_part_rows = prow;
+        if ((size_t)y.ldy > max_ld) max_ld = y.ldy;
+        size_t mo = (size_t)c->N * y.Ho * y.Wo * y.ldy;
+        if (mo > max_dA) max_dA = mo;
+        size_t mi = (size_t)y.M * y.cin_s;
+        if (mi > max_dA) max_dA = mi;
+    }
+    c->part_rows = max_part_rows;
+    c->part_ld = max_ld;
+    c->o_part_cnt = take(max_part_rows * sizeof(float));
+    // partial slabs are sized for the worst (rows x channels) product over layers
+    size_t max_slab = 0;
+    for (auto& y : c->L) {
+        size_t prow = y.first3 ? 2048 : (size_t)(y.M + conv_block_pixels(y.cout) - 1) / conv_block_pixels(y.cout);
+        size_t s = prow * y.ldy;
+        if (s > max_slab) max_slab = s;
+    }
+    c->o_part_mean = take(max_slab * sizeof(float));
+    c->o_part_m2 = take(max_slab * sizeof(float));
+    c->o_h32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
+    c->total_infer = off;
+    // ---- training-only buffers
+    for (size_t l = 0; l < c->L.size(); ++l) c->L[l].dyp = take(c->dy_geom((int)l).bytes(sz));
+    c->o_psum = take((size_t)2048 * 2 * max_ld * sizeof(float));
+    c->o_dA0 = take(max_dA * sz + 256);
+    c->o_dA1 = take(max_dA * sz + 256);
+    c->o_dh32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
+    c->total_train = off;
+}
+
+extern "C" {
+
+const char* y2_last_error(void) { return g_err.c_str(); }
+int y2_version(void) { return 1; }
+
+int y2_darknet19_spec(int kind, int output_filter, int* spec, int max_layers) {
+    static const int core[18][4] = {
+        {3, 3, 32, 1},     {3, 32, 64, 1},    {3, 64, 128, 0},   {3, 128, 64, 0},   {3, 64, 128, 1},
+        {3, 128, 256, 0},  {1, 256, 128, 0},  {3, 128, 256, 1},  {3, 256, 512, 0},  {1, 512, 256, 0},
+        {3, 256, 512, 0},  {1, 512, 256, 0},  {3, 256, 512, 1},  {3, 512, 1024, 0}, {1, 1024, 512, 0},
+        {3, 512, 1024, 0}, {1, 1024, 512, 0}, {3, 512, 1024, 0}};
+    int n = 18 + (kind == 1 ? 4 : (kind == 2 ? 1 : 0));
+    if (kind < 0 || kind > 2) return fail(Y2_ERR_ARG, "unknown net kind %d", kind);
+    if (n > max_layers) return fail(Y2_ERR_ARG, "spec buffer too small (%d > %d)", n, max_layers);
+    memcpy(spec, core, sizeof(core));
+    if (kind == 1) {
+        for (int i = 0; i < 3; ++i) {
+            int* s = spec + (18 + i) * 4;
+            s[0] = 3; s[1] = 1024; s[2] = 1024; s[3] = 0;
+        }
+        int* s = spec + 21 * 4;
+        s[0] = 1; s[1] = 1024; s[2] = output_filter; s[3] = 0;
+    } else if (kind == 2) {
+        int* s = spec + 18 * 4;
+        s[0] = 1; s[1] = 1024; s[2] = 1000; s[3] = 0;
+    }
+    return n;
+}
+
+int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers, int tail, int tail_k, int batch,
+                  int height, int width, int dtype) {
+    if (!out || !spec || num_layers <= 0) return fail(Y2_ERR_ARG, "bad arguments");
+    if (dtype < 0 || dtype > 2) return fail(Y2_ERR_ARG, "dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    if (batch <= 0 || height <= 0 || width <= 0) return fail(Y2_ERR_ARG, "bad input shape");
+    y2_ctx* c = new y2_ctx();
+    c->N = batch; c->H = height; c->W = width; c->dtype = dtype;
+    c->tail = tail; c->tail_k = tail_k; c->core_layers = core_layers;
+    int h = height, w = width, cprev = 3;
+    size_t po = 0, so = 0;
+    for (int l = 0; l < num_layers; ++l) {
+        Layer y{};
+        y.k = spec[l * 4 + 0]; y.cin = spec[l * 4 + 1]; y.cout = spec[l * 4 + 2]; y.pool = spec[l * 4 + 3];
+        if ((y.k != 1 && y.k != 3) || y.cin <= 0 || y.cout <= 0) {
+            delete c;
+            return fail(Y2_ERR_ARG, "layer %d: only 1x1 / 3x3 stride-1 SAME convolutions exist in this network", l);
+        }
+        if (l > 0 && y.cin != cprev) {
+            delete c;
+            return fail(Y2_ERR_ARG, "layer %d: in_chl %d does not match previous out_chl %d", l, y.cin, cprev);
+        }
+        y.first3 = (l == 0 && y.cin == 3);
+        if (y.first3 && !(y.k == 3 && y.cout == 32)) {
+            delete c;
+            return fail(Y2_ERR_ARG, "the 3-channel input layer must be 3x3, 3->32 (darknet.py:150)");
+        }
+        if (!y.first3 && (y.cin % 32) != 0) {
+            delete c;
+            return fail(Y2_ERR_ARG, "layer %d: in_chl must be a multiple of 32", l);
+        }
+        if (!y.first3 && y.cin > 128 && (y.cin % 128) != 0) {
+            delete c;
+            return fail(Y2_ERR_ARG, "layer %d: in_chl above 128 must be a multiple of 128", l);
+        }
+        if (l + 1 < num_layers && (y.cout % 32) != 0) {
+            delete c;
+            return fail(Y2_ERR_ARG, "layer %d: inner out_chl must be a multiple of 32", l);
+        }
+        y.H = h; y.W = w; y.M = batch * h * w;
+        y.Ho = y.pool ? (h + 1) / 2 : h;
+        y.Wo = y.pool ? (w + 1) / 2 : w;
+        y.cin_s = y.first3 ? 4 : y.cin;
+        y.ldy = round_up(y.cout, 32);   // 30 -> 32, 1000 -> 1024: K of the dgrad GEMM in 64-byte multiples
+        y.cout_pad = round_up(y.cout, conv_block_couts(y.cout));
+        y.cin_pad = round_up(y.cin, conv_block_couts(y.cin));
+        y.pW = po; po += (size_t)y.k * y.k * y.cin * y.cout;
+        y.pb = po; po += y.cout;
+        y.pg = po; po += y.cout;
+        y.pbeta = po; po += y.cout;
+        y.smm = so; so += y.cout;
+        y.smv = so; so += y.cout;
+        c->L.push_back(y);
+        h = y.Ho; w = y.Wo; cprev = y.cout;
+    }
+    c->nparams = po; c->nstate = so;
+    const Layer& last = c->L.back();
+    if (tail == Y2_TAIL_AVGPOOL) {
+        if (tail_k <= 0 || last.Ho < tail_k || last.Wo < tail_k) {
+            delete c;
+            return fail(Y2_ERR_ARG, "avgpool window %d does not fit %dx%d", tail_k, last.Ho, last.Wo);
+        }
+        c->outN = batch; c->outH = last.Ho / tail_k; c->outW = last.Wo / tail_k; c->outC = last.cout;
+    } else {
+        c->outN = batch; c->outH = last.Ho; c->outW = last.Wo; c->outC = last.cout;
+    }
+    if (last.pool) {
+        delete c;
+        return fail(Y2_ERR_ARG, "the last layer must not pool");
+    }
+    plan(c);
+    c->fwd_training.assign(c->L.size(), 0);
+    *out = c;
+    return Y2_OK;
+}
+
+void y2_ctx_destroy(y2_ctx* ctx) { delete ctx; }
+int y2_num_layers(const y2_ctx* c) { return (int)c->L.size(); }
+int y2_layer_info(const y2_ctx* c, int l, int info[8]) {
+    if (l < 0 || l >= (int)c->L.size()) return fail(Y2_ERR_ARG, "layer out of range");
+    const Layer& y = c->L[l];
+    info[0] = y.k; info[1] = y.cin; info[2] = y.cout; info[3] = y.pool;
+    info[4] = y.H; info[5] = y.W; info[6] = y.Ho; info[7] = y.Wo;
+    return Y2_OK;
+}
+size_t y2_param_count(const y2_ctx* c) { return c->nparams; }
+size_t y2_state_count(const y2_ctx* c) { return c->nstate; }
+int y2_param_offsets(const y2_ctx* c, int l, size_t off[6]) {
+    if (l < 0 || l >= (int)c->L.size()) return fail(Y2_ERR_ARG, "layer out of range");
+    const Layer& y = c->L[l];
+    off[0] = y.pW; off[1] = y.pb; off[2] = y.pg; off[3] = y.pbeta; off[4] = y.smm; off[5] = y.smv;
+    return Y2_OK;
+}
+int y2_output_shape(const y2_ctx* c, int shape[4]) {
+    shape[0] = c->outN; shape[1] = c->outH; shape[2] = c->outW; shape[3] = c->outC;
+    return Y2_OK;
+}
+size_t y2_workspace_bytes(const y2_ctx* c, int training) { return training ? c->total_train : c->total_infer; }
+
+int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspace, size_t workspace_bytes,
+            int training, void* stream) {
+    if (!params || !state || !workspace) return fail(Y2_ERR_ARG, "null buffer");
+    if (training && !grads) return fail(Y2_ERR_ARG, "training needs a gradient buffer");
+    const size_t need = y2_workspace_bytes(c, training);
+    if (workspace_bytes < need) return fail(Y2_ERR_ARG, "workspace too small: %zu < %zu", workspace_bytes, need);
+    c->params = params; c->grads = grads; c->state = state;
+    c->ws = (char*)workspace; c->ws_bytes = workspace_bytes; c->bound_training = training;
+    c->weights_dirty = true; c->fwd_saved = false;
+    // borders, guard bands and channel padding must be (and then stay) zero
+    HIPCHK(hipMemsetAsync(workspace, 0, need, (hipStream_t)stream));
+    return Y2_OK;
+}
+
+int y2_set_options(y2_ctx* c, float grad_scale, int bessel) {
+    if (!(grad_scale > 0.f)) return fail(Y2_ERR_ARG, "grad_scale must be positive");
+    c->grad_scale = grad_scale; c->bessel = bessel;
+    return Y2_OK;
+}
+
+int y2_init_params(y2_ctx* c, uint64_t seed, void* stream) {
+    if (!c->params) return fail(Y2_ERR_STATE, "bind buffers first");
+    hipStream_t s = (hipStream_t)stream;
+    for (size_t l = 0; l < c->L.size(); ++l) {
+        const Layer& y = c->L[l];
+        HIPCHK(launch_init_trunc_normal(c->params + y.pW, (size_t)y.k * y.k * y.cin * y.cout, 0.1f, seed, l, s));
+        HIPCHK(launch_fill(c->params + y.pb, y.cout, 0.1f, s));
+        HIPCHK(launch_fill(c->params + y.pg, y.cout, 1.0f, s));
+        HIPCHK(launch_fill(c->params + y.pbeta, y.cout, 0.0f, s));
+        HIPCHK(launch_fill(c->state + y.smm, y.cout, 0.0f, s));
+        HIPCHK(launch_fill(c->state + y.smv, y.cout, 1.0f, s));
+    }
+    c->weights_dirty = true;
+    return Y2_OK;
+}
+int y2_params_changed(y2_ctx* c) {
+    c->weights_dirty = true;
+    return Y2_OK;
+}
+
+static int pack_all_weights(y2_ctx* c, hipStream_t s) {
+    for (size_t l = 0; l < c->L.size(); ++l) {
+        const Layer& y = c->L[l];
+        if (y.first3) {
+            HIPCHK(launch_pack_conv1_weights(c->dtype, c->params + y.pW, c->ws + y.wf, s));
+        } else {
+            void* wd = (c->bound_training && l > 0) ? (void*)(c->ws + y.wd) : nullptr;
+            HIPCHK(launch_pack_weights(c->dtype, c->params + y.pW, c->ws + y.wf, wd, y.k * y.k, y.cin, y.cout,
+                                       y.cout_pad, y.cin_s, y.cin_pad, y.ldy, s));
+        }
+    }
+    c->weights_dirty = false;
+    return Y2_OK;
+}
+
+int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, float* out, void* stream) {
+    if (!c->ws) return fail(Y2_ERR_STATE, "bind buffers first");
+    if (!images || !out) return fail(Y2_ERR_ARG, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sz = c->sz();
+    if (c->weights_dirty) {
+        int r = pack_all_weights(c, s);
+        if (r) return r;
+    }
+    float* part_cnt = (float*)(c->ws + c->o_part_cnt);
+    float* part_mean = (float*)(c->ws + c->o_part_mean);
+    float* part_m2 = (float*)(c->ws + c->o_part_m2);
+    const int nl = (int)c->L.size();
+    for (int l = 0; l < nl; ++l) {
+        const Layer& y = c->L[l];
+        const int training = (l < c->core_layers) ? train_core : train_head;
+        c->fwd_training[l] = training;
+        char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
+        float* stat = (float*)(c->ws + y.stat);
+        float *scale = stat, *shift = stat + y.ldy, *mean = stat + 2 * y.ldy, *invstd = stat + 3 * y.ldy;
+        int P = 0;
+        if (y.first3) {
+            HIPCHK(launch_pack_input(c->dtype, images, xin, c->N, y.H, y.W, s));
+            Conv1Args a{};
+            a.x4 = xin; a.w = c->ws + y.wf; a.y = c->ws + y.y; a.bias = c->params + y.pb;
+            a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2;
+            a.N = c->N; a.H = y.H; a.W = y.W; a.M = y.M;
+            int nb = (y.M + 127) / 128;
+            a.nblocks = nb > 2048 ? 2048 : nb;
+            P = a.nblocks;
+            HIPCHK(launch_conv1_fwd(c->dtype, a, s));
+        } else {
+            if (l == 0) HIPCHK(launch_pack_act(c->dtype, images, xin, c->N, y.H, y.W, y.cin, y.cin_s, s));
+            ConvArgs a{};
+            a.x = xin; a.w = c->ws + y.wf; a.y = c->ws + y.y; a.bias = c->params + y.pb;
+            if (training) { a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2; }
+            a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.cin_s; a.M = y.M; a.Cout = y.cout; a.ldy = y.ldy;
+            a.taps = y.k * y.k;
+            P = (y.M + conv_block_pixels(y.cout) - 1) / conv_block_pixels(y.cout);
+            HIPCHK(launch_conv_igemm(c->dtype, a, s));
+        }
+        if (training) {
+            BnFinalizeArgs f{};
+            f.part_cnt = part_cnt; f.part_mean = part_mean; f.part_m2 = part_m2;
+            f.P = P; f.C = y.cout; f.ldp = y.first3 ? 32 : y.ldy;
+            f.gamma = c->params + y.pg; f.beta = c->params + y.pbeta;
+            f.moving_mean = c->state + y.smm; f.moving_var = c->state + y.smv;
+            f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
+            f.eps = kBnEps; f.momentum = kBnMomentum; f.update_moving = 1; f.bessel = c->bessel;
+            HIPCHK(launch_bn_finalize(f, s));
+        } else {
+            HIPCHK(launch_bn_infer_prepare(c->params + y.pg, c->params + y.pbeta, c->state + y.smm, c->state + y.smv,
+                                           scale, shift, mean, invstd, y.cout, kBnEps, s));
+        }
+        BnActArgs b{};
+        b.y = c->ws + y.y; b.scale = scale; b.shift = shift;
+        b.N = c->N; b.H = y.H; b.W = y.W; b.C = y.cout; b.ldy = y.ldy; b.pool = y.pool;
+        if (l + 1 < nl) {
+            b.out = c->ws + c->L[l + 1].xin + c->in_geom(l + 1).base_off(sz);
+            b.out_f32 = 0;
+        } else {
+            b.out = (c->tail == Y2_TAIL_AVGPOOL) ? (void*)(c->ws + c->o_h32) : (void*)out;
+            b.out_f32 = 1;
+        }
+        HIPCHK(launch_bn_act(c->dtype, b, s));
+    }
+    if (c->tail == Y2_TAIL_AVGPOOL) {
+        const Layer& y = c->L.back();
+        HIPCHK(launch_avgpool_fwd((const float*)(c->ws + c->o_h32), out, c->N, y.Ho, y.Wo, y.cout, c->tail_k, s));
+    }
+    c->fwd_saved = true;
+    return Y2_OK;
+}
+
+int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* stream) {
+    if (!c->ws || !c->bound_training) return fail(Y2_ERR_STATE, "bind with training=1 first");
+    if (!c->fwd_saved) return fail(Y2_ERR_STATE, "run y2_forward before y2_backward");
+    const int nl = (int)c->L.size();
+    if (layer_lo < 0 || layer_hi > nl || layer_lo >= layer_hi) return fail(Y2_ERR_ARG, "bad layer range");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sz = c->sz();
+    const float inv_gs = 1.0f / c->grad_scale;
+    char* dA[2] = {c->ws + c->o_dA0, c->ws + c->o_dA1};
+    if (layer_hi == nl) {
+        if (!dout) return fail(Y2_ERR_ARG, "null output gradient");
+        const Layer& y = c->L.back();
+        const float* src = dout;
+        if (c->tail == Y2_TAIL_AVGPOOL) {
+            float* dh = (float*)(c->ws + c->o_dh32);
+            HIPCHK(launch_avgpool_bwd(dout, dh, c->N, y.Ho, y.Wo, y.cout, c->tail_k, s));
+            src = dh;
+        }
+        c->dA_cur = 0;
+        HIPCHK(launch_convert_grad(c->dtype, src, dA[0], y.M, y.cout, y.ldy, c->grad_scale, s));
+        // weight/bias gradients are accumulated with atomics: clear the whole flat buffer once per step
+        HIPCHK(hipMemsetAsync(c->grads, 0, c->nparams * sizeof(float), s));
+    }
+    float* psum = (float*)(c->ws + c->o_psum);
+    for (int l = layer_hi - 1; l >= layer_lo; --l) {
+        const Layer& y = c->L[l];
+        float* stat = (float*)(c->ws + y.stat);
+        char* dyp = c->ws + y.dyp + c->dy_geom(l).base_off(sz);
+        BnBwdArgs b{};
+        b.dA = dA[c->dA_cur]; b.y = c->ws + y.y;
+        b.scale = stat; b.shift = stat + y.ldy; b.mean = stat + 2 * y.ldy; b.invstd = stat + 3 * y.ldy;
+        b.coef = stat + 4 * y.ldy;
+        b.psum = psum;
+        b.dgamma = c->grads + y.pg; b.dbeta = c->grads + y.pbeta; b.dbias = c->grads + y.pb;
+        b.dyp = dyp;
+        b.N = c->N; b.H = y.H; b.W = y.W; b.C = y.cout; b.ldy = y.ldy;
+        b.ldd = y.ldy;
+        b.pool = y.pool; b.training = c->fwd_training[l]; b.inv_grad_scale = inv_gs;
+        HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
+        HIPCHK(launch_bn_bwd_finalize(b, s));
+        HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
+        char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
+        if (y.first3) {
+            Conv1WgradArgs g{};
+            g.x4 = xin; g.dy = dyp; g.dW = c->grads + y.pW;
+            g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M; g.scale = inv_gs;
+            HIPCHK(launch_conv1_wgrad(c->dtype, g, s));
+        } else {
+            WgradArgs g{};
+            g.x = xin; g.dy = dyp; g.dW = c->grads + y.pW;
+            g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M;
+            g.Cin = y.cin_s; g.Cdy = y.ldy; g.Cout = y.cout; g.taps = y.k * y.k; g.splitk = 0; g.scale = inv_gs;
+            HIPCHK(launch_wgrad(c->dtype, g, s));
+            if (l > 0) {
+                ConvArgs a{};
+                a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
+                a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.ldy; a.M = y.M; a.Cout = y.cin; a.ldy = y.cin;
+                a.taps = y.k * y.k;
+                HIPCHK(launch_conv_igemm(c->dtype, a, s));
+                c->dA_cur ^= 1;
+            }
+        }
+    }
+    return Y2_OK;
+}
+
+// what: 0 = bordered input of `layer` (post BN+leaky+pool of the previous layer), [N,H,W,cin]
+//       1 = conv output (+bias) of `layer`, [N,H,W,cout]
+//       2 = dy (gradient wrt the conv output, times grad_scale), [N,H,W,cout]
+int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
+    if (l < 0 || l >= (int)c->L.size()) return fail(Y2_ERR_ARG, "layer out of range");
+    const Layer& y = c->L[l];
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sz = c->sz();
+    if (what == 0) {
+        const int C = y.first3 ? 3 : y.cin;
+        HIPCHK(launch_unpack_act(c->dtype, c->ws + y.xin + c->in_geom(l).base_off(sz), dst, c->N, y.H, y.W, C,
+                                 y.cin_s, s));
+    } else if (what == 1) {
+        HIPCHK(launch_cast_to_f32(c->dtype, c->ws + y.y, dst, (size_t)y.M, y.cout, y.ldy, s));
+    } else if (what == 2) {
+        if (!c->bound_training) return fail(Y2_ERR_STATE, "no gradients in inference binding");
+        HIPCHK(launch_unpack_act(c->dtype, c->ws + y.dyp + c->dy_geom(l).base_off(sz), dst, c->N, y.H, y.W, y.cout,
+                                 y.ldy, s));
+    } else {
+        return fail(Y2_ERR_ARG, "unknown selector");
+    }
+    return Y2_OK;
+}
+
+// ---------------------------------------------------------------------------
+size_t y2_yolo_loss_workspace_bytes(int batch, int S) { return (size_t)loss_blocks(batch, S) * 4 * sizeof(float) + 256; }
+
+int y2_yolo_loss(const float* net, const float* labels, int num_class, int batch, float image_size, int S, int B,
+                 float lambda_coord, float lambda_noobj, float* loss, float* ious, float* object_mask, float* dnet,
+                 void* workspace, void* stream) {
+    if (!net || !labels || !loss || !ious || !object_mask || !workspace) return fail(Y2_ERR_ARG, "null tensor");
+    if (B < 1 || B > 8 || num_class < 1 || S < 1 || batch < 1) return fail(Y2_ERR_ARG, "bad loss geometry");
+    LossArgs a{};
+    a.net = net; a.labels = labels; a.loss = loss; a.ious = ious; a.mask = object_mask; a.dnet = dnet;
+    a.partial = (float*)workspace;
+    a.N = batch; a.S = S; a.B = B; a.C = num_class; a.image_size = image_size;
+    a.lambda_coord = lambda_coord; a.lambda_noobj = lambda_noobj;
+    HIPCHK(launch_yolo_loss(a, (hipStream_t)stream));
+    return Y2_OK;
+}
+int y2_get_iou(const float* b1, const float* b2, float* iou, int n, void* stream) {
+    if (!b1 || !b2 || !iou || n < 0) return fail(Y2_ERR_ARG, "bad arguments");
+    if (n == 0) return Y2_OK;
+    HIPCHK(launch_get_iou(b1, b2, iou, n, (hipStream_t)stream));
+    return Y2_OK;
+}
+int y2_decode_detections(const float* predict, int S, int B, int num_class, int im_w, int im_h, float thresh,
+                         int* det, float* conf, void* stream) {
+    if (!predict || !det || !conf) return fail(Y2_ERR_ARG, "null tensor");
+    HIPCHK(launch_decode(predict, S, B, num_class, im_w, im_h, thresh, det, conf, (hipStream_t)stream));
+    return Y2_OK;
+}
+int y2_softmax_cross_entropy(const float* logits, const int* labels, int batch, int classes, float* loss,
+                             float* dlogits, void* stream) {
+    if (!logits || !labels || !loss) return fail(Y2_ERR_ARG, "null tensor");
+    HIPCHK(launch_softmax_ce(logits, labels, loss, dlogits, batch, classes, (hipStream_t)stream));
+    return Y2_OK;
+}
+
+int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n, int step, float lr, float beta1,
+                 float beta2, float eps, float grad_mult, void* stream) {
+    if (!params || !m || !v || !grads || step < 1) return fail(Y2_ERR_ARG, "bad arguments");
+    // TF: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+    const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    HIPCHK(launch_adam(params, m, v, grads, n, (float)lr_t, beta1, beta2, eps, grad_mult, (hipStream_t)stream));
+    return Y2_OK;
+}
+int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, float lr, float momentum,
+                     float grad_mult, void* stream) {
+    if (!params || !accum || !grads) return fail(Y2_ERR_ARG, "bad arguments");
+    HIPCHK(launch_momentum(params, accum, grads, n, lr, momentum, grad_mult, (hipStream_t)stream));
+    return Y2_OK;
+}
+
+// ---------------------------------------------------------------------------
+// single-op conv2d (+ backward) on fp32 NHWC / HWIO tensors
+// ---------------------------------------------------------------------------
+struct OpPlan {
+    int Cin_p, Cdy, Cout_pad, Cin_pad, ldy;
+    size_t xp, wf, wd, y, dyp, dx, dw, total;
+};
+static OpPlan op_plan(int N, int H, int W, int Cin, int Cout, int k, int dtype) {
+    OpPlan p{};
+    const size_t sz = dtype_size(dtype);
+    p.Cin_p = round_up(Cin, 32);
+    if (p.Cin_p > 128) p.Cin_p = round_up(Cin, 128);
+    p.ldy = round_up(Cout, 32);
+    p.Cdy = p.ldy;
+    p.Cout_pad = round_up(Cout, conv_block_couts(Cout));
+    p.Cin_pad = round_up(p.Cin_p, conv_block_couts(p.Cin_p));
+    size_t off = 0;
+    auto take = [&](size_t b) { size_t o = off; off += align_up(b, 256); return o; };
+    p.xp = take(PadGeom{N, H, W, p.Cin_p}.bytes(sz));
+    p.wf = take((size_t)p.Cout_pad * k * k * p.Cin_p * sz);
+    p.wd = take((size_t)p.Cin_pad * k * k * p.Cdy * sz);
+    p.y = take((size_t)N * H * W * p.ldy * sz + 256);
+    p.dyp = take(PadGeom{N, H, W, p.Cdy}.bytes(sz));
+    p.dx = take((size_t)N * H * W * p.Cin_p * sz + 256);
+    p.dw = take((size_t)k * k * p.Cin_p * Cout * sizeof(float));
+    p.total = off;
+    return p;
+}
+size_t y2_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int k, int dtype) {
+    return op_plan(N, H, W, Cin, Cout, k, dtype).total;
+}
+int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
+              int k, int dtype, void* workspace, void* stream) {
+    if (!x || !w || !y || !workspace) return fail(Y2_ERR_ARG, "null tensor");
+    if (k != 1 && k != 3) return fail(Y2_ERR_ARG, "filter size must be 1 or 3");
+    if (dtype < 0 || dtype > 2) return fail(Y2_ERR_ARG, "bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sz = dtype_size(dtype);
+    OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
+    char* ws = (char*)workspace;
+    HIPCHK(hipMemsetAsync(ws, 0, p.total, s));
+    PadGeom g{N, H, W, p.Cin_p};
+    char* xp = ws + p.xp + g.base_off(sz);
+    HIPCHK(launch_pack_act(dtype, x, xp, N, H, W, Cin, p.Cin_p, s));
+    HIPCHK(launch_pack_weights(dtype, w, ws + p.wf, nullptr, k * k, Cin, Cout, p.Cout_pad, p.Cin_p, 0, 0, s));
+    ConvArgs a{};
+    a.x = xp; a.w = ws + p.wf; a.y = ws + p.y; a.bias = bias;
+    a.N = N; a.H = H; a.W = W; a.C = p.Cin_p; a.M = N * H * W; a.Cout = Cout; a.ldy = p.ldy; a.taps = k * k;
+    HIPCHK(launch_conv_igemm(dtype, a, s));
+    HIPCHK(launch_cast_to_f32(dtype, ws + p.y, y, (size_t)N * H * W, Cout, p.ldy, s));
+    return Y2_OK;
+}
+int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int N, int H, int W,
+                       int Cin, int Cout, int k, int dtype, void* workspace, void* stream) {
+    if (!x || !w || !dy || !workspace) return fail(Y2_ERR_ARG, "null tensor");
+    if (k != 1 && k != 3) return fail(Y2_ERR_ARG, "filter size must be 1 or 3");
+    if (dtype < 0 || dtype > 2) return fail(Y2_ERR_ARG, "bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t sz = dtype_size(dtype);
+    OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
+    char* ws = (char*)workspace;
+    HIPCHK(hipMemsetAsync(ws, 0, p.total, s));
+    PadGeom gx{N, H, W, p.Cin_p}, gy{N, H, W, p.Cdy};
+    char* xp = ws + p.xp + gx.base_off(sz);
+    char* dyp = ws + p.dyp + gy.base_off(sz);
+    HIPCHK(launch_pack_act(dtype, x, xp, N, H, W, Cin, p.Cin_p, s));
+    HIPCHK(launch_pack_act(dtype, dy, dyp, N, H, W, Cout, p.Cdy, s));
+    if (dx) {
+        HIPCHK(launch_pack_weights(dtype, w, nullptr, ws + p.wd, k * k, Cin, Cout, 0, 0, p.Cin_pad, p.Cdy, s));
+        ConvArgs a{};
+        a.x = dyp; a.w = ws + p.wd; a.y = ws + p.dx;
+        a.N = N; a.H = H; a.W = W; a.C = p.Cdy; a.M = N * H * W; a.Cout = p.Cin_p; a.ldy = p.Cin_p; a.taps = k * k;
+        HIPCHK(launch_conv_igemm(dtype, a, s));
+        HIPCHK(launch_cast_to_f32(dtype, ws + p.dx, dx, (size_t)N * H * W, Cin, p.Cin_p, s));
+    }
+    if (dw) {
+        WgradArgs g{};
+        g.x = xp; g.dy = dyp; g.dW = (float*)(ws + p.dw);
+        g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = p.Cin_p; g.Cdy = p.Cdy; g.Cout = Cout;
+        g.taps = k * k; g.splitk = 0; g.scale = 1.f;
+        HIPCHK(launch_wgrad(dtype, g, s));
+        for (int t = 0; t < k * k; ++t)
+            HIPCHK(hipMemcpyAsync(dw + (size_t)t * Cin * Cout, (float*)(ws + p.dw) + (size_t)t * p.Cin_p * Cout,
+                                  (size_t)Cin * Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return Y2_OK;
+}
+
+}  // extern "C"

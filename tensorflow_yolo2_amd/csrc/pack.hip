@@ -1,0 +1,224 @@
+// Layout/precision conversion passes between the reference's tensors
+// (fp32 NHWC activations, fp32 HWIO filters -- darknet.py:10-21) and the
+// MI355X-side layouts (zero-bordered NHWC of T, K-contiguous packed filters).
+#include "common.h"
+#include "kernels.h"
+
+namespace y2 {
+
+// image fp32 [N][H][W][3] -> x4 [N][H+2][W+2][4] of T (channel 3 = 0); border pre-zeroed
+template <typename T>
+__global__ void pack_input_kernel(const float* __restrict__ img, T* __restrict__ x4, int N, int H, int W) {
+    const size_t total = (size_t)N * H * W;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const int n = (int)(p / ((size_t)W * H));
+        const float* s = img + p * 3;
+        T* d = x4 + (((size_t)(n * (H + 2) + h + 1) * (W + 2)) + w + 1) * 4;
+        d[0] = Elem<T>::from_f32(s[0]);
+        d[1] = Elem<T>::from_f32(s[1]);
+        d[2] = Elem<T>::from_f32(s[2]);
+        d[3] = Elem<T>::from_f32(0.f);
+    }
+}
+template <typename T>
+static hipError_t pack_input_T(const float* img, void* x4, int N, int H, int W, hipStream_t s) {
+    size_t total = (size_t)N * H * W;
+    size_t nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pack_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, img, (T*)x4, N, H, W);
+    return hipGetLastError();
+}
+hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H, int W, hipStream_t s) {
+    switch (dtype) {
+        case 0: return pack_input_T<float>(img, x4, N, H, W, s);
+        case 1: return pack_input_T<half_t>(img, x4, N, H, W, s);
+        case 2: return pack_input_T<bf16_t>(img, x4, N, H, W, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// generic fp32 NHWC [N][H][W][C] <-> zero-bordered [N][H+2][W+2][C] of T (op-level API)
+// C = channels of the fp32 tensor, Cs = channel stride of the bordered tensor (>= C, extra = 0)
+template <typename T, bool PACK>
+__global__ void act_pack_kernel(const float* in, T* xp, float* out, int N, int H, int W, int C, int Cs) {
+    const int Ci = PACK ? Cs : C;
+    const size_t total = (size_t)N * H * W * Ci;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Ci);
+        const size_t p = i / Ci;
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const int n = (int)(p / ((size_t)W * H));
+        const size_t po = (((size_t)(n * (H + 2) + h + 1) * (W + 2)) + w + 1) * Cs + c;
+        if (PACK) xp[po] = Elem<T>::from_f32(c < C ? in[p * C + c] : 0.f);
+        else out[i] = Elem<T>::to_f32(xp[po]);
+    }
+}
+template <typename T, bool PACK>
+static hipError_t act_pack_T(const float* in, void* xp, float* out, int N, int H, int W, int C, int Cs,
+                             hipStream_t s) {
+    size_t total = (size_t)N * H * W * (PACK ? Cs : C);
+    size_t nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL((act_pack_kernel<T, PACK>), dim3((unsigned)nb), dim3(256), 0, s, in, (T*)xp, out, N, H, W, C,
+                       Cs);
+    return hipGetLastError();
+}
+hipError_t launch_pack_act(int dtype, const float* in, void* xp, int N, int H, int W, int C, int Cs,
+                           hipStream_t s) {
+    switch (dtype) {
+        case 0: return act_pack_T<float, true>(in, xp, nullptr, N, H, W, C, Cs, s);
+        case 1: return act_pack_T<half_t, true>(in, xp, nullptr, N, H, W, C, Cs, s);
+        case 2: return act_pack_T<bf16_t, true>(in, xp, nullptr, N, H, W, C, Cs, s);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H, int W, int C, int Cs,
+                             hipStream_t s) {
+    switch (dtype) {
+        case 0: return act_pack_T<float, false>(nullptr, (void*)xp, out, N, H, W, C, Cs, s);
+        case 1: return act_pack_T<half_t, false>(nullptr, (void*)xp, out, N, H, W, C, Cs, s);
+        case 2: return act_pack_T<bf16_t, false>(nullptr, (void*)xp, out, N, H, W, C, Cs, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// [rows][lds] of T -> fp32 [rows][C]
+template <typename T>
+__global__ void cast_f32_kernel(const T* src, float* dst, size_t rows, int C, int lds) {
+    const size_t total = rows * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / C;
+        const int c = (int)(i % C);
+        dst[i] = Elem<T>::to_f32(src[r * lds + c]);
+    }
+}
+hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s) {
+    size_t total = rows * C;
+    size_t nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    if (nb < 1) nb = 1;
+    dim3 g((unsigned)nb), b(256);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(cast_f32_kernel<float>, g, b, 0, s, (const float*)src, dst, rows, C, lds); break;
+        case 1: hipLaunchKernelGGL(cast_f32_kernel<half_t>, g, b, 0, s, (const half_t*)src, dst, rows, C, lds); break;
+        case 2: hipLaunchKernelGGL(cast_f32_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)src, dst, rows, C, lds); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// fp32 [M][C] * scale -> T [M][ldd] (columns >= C zero)
+template <typename T>
+__global__ void convert_grad_kernel(const float* src, T* dst, int M, int C, int ldd, float scale) {
+    const size_t total = (size_t)M * ldd;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / ldd;
+        const int c = (int)(i % ldd);
+        dst[i] = Elem<T>::from_f32(c < C ? src[r * C + c] * scale : 0.f);
+    }
+}
+hipError_t launch_convert_grad(int dtype, const float* src, void* dst, int M, int C, int ldd, float scale,
+                               hipStream_t s) {
+    size_t total = (size_t)M * ldd;
+    size_t nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    if (nb < 1) nb = 1;
+    dim3 g((unsigned)nb), b(256);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(convert_grad_kernel<float>, g, b, 0, s, src, (float*)dst, M, C, ldd, scale); break;
+        case 1: hipLaunchKernelGGL(convert_grad_kernel<half_t>, g, b, 0, s, src, (half_t*)dst, M, C, ldd, scale); break;
+        case 2: hipLaunchKernelGGL(convert_grad_kernel<bf16_t>, g, b, 0, s, src, (bf16_t*)dst, M, C, ldd, scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// filters: W fp32 HWIO [taps][Cin][Cout]
+//   wf[co][t][ci]  (rows co in [0,Cout_pad), zero beyond Cout)           forward
+//   wd[ci][t][co]  = W[taps-1-t][ci][co]  (rows ci in [0,Cin_pad), cols co in [0,Cdy)) dgrad
+// Tiled transpose through LDS so both the fp32 reads and the T writes coalesce.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_wf_kernel(const float* __restrict__ W, T* __restrict__ wf, int taps,
+                                                      int Cin, int Cout, int Cout_pad, int Kc) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < Cin && co < Cout) ? W[((size_t)t * Cin + ci) * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < Cout_pad && ci < Kc) wf[((size_t)co * taps + t) * Kc + ci] = Elem<T>::from_f32(tile[tx][r]);
+    }
+}
+template <typename T>
+__global__ void pack_wd_kernel(const float* __restrict__ W, T* __restrict__ wd, int taps, int Cin, int Cout,
+                               int Cin_pad, int Cdy) {
+    const size_t total = (size_t)Cin_pad * taps * Cdy;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cdy);
+        const int t = (int)((i / Cdy) % taps);
+        const int ci = (int)(i / ((size_t)Cdy * taps));
+        float v = 0.f;
+        if (ci < Cin && co < Cout) v = W[((size_t)(taps - 1 - t) * Cin + ci) * Cout + co];
+        wd[i] = Elem<T>::from_f32(v);
+    }
+}
+template <typename T>
+static hipError_t pack_weights_T(const float* W, void* wf, void* wd, int taps, int Cin, int Cout, int Cout_pad,
+                                 int Kc, int Cin_pad, int Cdy, hipStream_t s) {
+    if (wf) {
+        dim3 g((Cout_pad + 31) / 32, (Kc + 31) / 32, taps);
+        hipLaunchKernelGGL(pack_wf_kernel<T>, g, dim3(256), 0, s, W, (T*)wf, taps, Cin, Cout, Cout_pad, Kc);
+    }
+    if (wd) {
+        size_t total = (size_t)Cin_pad * taps * Cdy;
+        size_t nb = (total + 255) / 256;
+        if (nb > 16384) nb = 16384;
+        hipLaunchKernelGGL(pack_wd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, W, (T*)wd, taps, Cin, Cout, Cin_pad,
+                           Cdy);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, int taps, int Cin, int Cout,
+                               int Cout_pad, int Kc, int Cin_pad, int Cdy, hipStream_t s) {
+    switch (dtype) {
+        case 0: return pack_weights_T<float>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, s);
+        case 1: return pack_weights_T<half_t>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, s);
+        case 2: return pack_weights_T<bf16_t>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// conv1: W [3][3][3][32] -> wp[co][kh][16]: element kw*4+c (c<3), zero elsewhere
+template <typename T>
+__global__ void pack_conv1_kernel(const float* W, T* wp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 32 * 3 * 16) return;
+    const int e = i % 16, kh = (i / 16) % 3, co = i / 48;
+    const int kw = e / 4, c = e % 4;
+    float v = 0.f;
+    if (kw < 3 && c < 3) v = W[((kh * 3 + kw) * 3 + c) * 32 + co];
+    wp[i] = Elem<T>::from_f32(v);
+}
+hipError_t launch_pack_conv1_weights(int dtype, const float* W, void* wp, hipStream_t s) {
+    dim3 g(6), b(256);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(pack_conv1_kernel<float>, g, b, 0, s, W, (float*)wp); break;
+        case 1: hipLaunchKernelGGL(pack_conv1_kernel<half_t>, g, b, 0, s, W, (half_t*)wp); break;
+        case 2: hipLaunchKernelGGL(pack_conv1_kernel<bf16_t>, g, b, 0, s, W, (bf16_t*)wp); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace y2

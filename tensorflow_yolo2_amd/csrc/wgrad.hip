@@ -1,0 +1,248 @@
+// Weight-gradient GEMM (TF Conv2DBackpropFilter of darknet.py:20-21):
+//     dW[t][ci][co] = sum_p X[p (+) t][ci] * dY[p][co]
+// Both operands are pixel-major in HBM (NHWC) and the reduction runs over
+// pixels, so the MFMA k index is the slow memory index of BOTH operands.
+// gfx950 answer: stage [pixels][channels] tiles with global_load_lds and read
+// the fragments with ds_read_b64_tr_b16 (hardware transpose) -- no transposed
+// copies of the activations are ever written to HBM.
+//
+// K runs LINEARLY over the zero-bordered pixel space [0, N*(H+2)*(W+2)):
+// dY's border is zero, so border positions contribute nothing and no
+// per-pixel index arithmetic is needed (row addresses are affine in k).  The
+// tap shift is a constant offset on X; guard bands around the tensors keep the
+// shifted reads in finite memory.
+// Split-K over blocks; partial tiles are accumulated into the fp32 HWIO
+// gradient with float atomics (256-byte row segments per wave-instruction).
+#include "common.h"
+#include "kernels.h"
+
+namespace y2 {
+
+template <typename T, int WI, int WO, int TI, int TO>
+struct WgCfg {
+    static constexpr int NW = WI * WO, NT = NW * 64;
+    static constexpr int SZ = sizeof(T);
+    static constexpr int BI = WI * TI * 32, BO = WO * TO * 32;
+    static constexpr int BKP = (SZ == 2) ? 64 : 32;  // pixels per K step
+    static constexpr int ROWX = BI * SZ, ROWY = BO * SZ;
+    static constexpr int LPRX = ROWX / 16, LPRY = ROWY / 16;
+    static constexpr int RPIX = 64 / LPRX, RPIY = 64 / LPRY;
+    static constexpr int NIX = BKP / RPIX, NIY = BKP / RPIY;
+    static constexpr int IPWX = NIX / NW, IPWY = NIY / NW;
+    static constexpr int XS = BKP * ROWX, YS = BKP * ROWY;
+    static constexpr int STAGE = XS + YS;
+    static constexpr int LDS = 2 * STAGE;
+    static_assert(NIX % NW == 0 && NIY % NW == 0, "staging must split evenly over waves");
+};
+
+// swizzle: rows q = row&3 of a transposed 4x16 read must land in distinct
+// 64-byte bank segments of the 256-byte LDS bank row
+template <int ROWB, int SZ>
+Y2_DEV int wg_swz(int row) {
+    if (SZ != 2) return 0;
+    if (ROWB >= 256) return (row & 3) << 2;
+    if (ROWB == 128) return ((row & 3) >> 1) << 2;
+    return 0;
+}
+
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T>
+Y2_DEV typename Elem<T>::frag tr_frag(const char* p0, const char* p1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename Elem<T>::frag, both);
+}
+
+template <typename T, int WI, int WO, int TI, int TO>
+__global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
+    typedef WgCfg<T, WI, WO, TI, TO> Cfg;
+    constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
+    constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = w / WO, wo = w % WO;
+
+    const int nIT = (a.Cin + BI - 1) / BI, nOT = (a.Cout + BO - 1) / BO;
+    int b = blockIdx.x;
+    const int ot = b % nOT; b /= nOT;
+    const int it = b % nIT; b /= nIT;
+    const int tap = b % a.taps;
+    const int split = b / a.taps;
+    const int ci0 = it * BI, co0 = ot * BO;
+
+    const long Mp = (long)a.N * (a.H + 2) * (a.W + 2);
+    const long ksteps = (Mp + BKP - 1) / BKP;
+    const long spb = (ksteps + a.splitk - 1) / a.splitk;
+    const long s_begin = (long)split * spb;
+    long s_end = s_begin + spb;
+    if (s_end > ksteps) s_end = ksteps;
+    const int nsteps = (int)(s_end > s_begin ? s_end - s_begin : 0);
+
+    int toff;  // tap shift in pixels relative to the centre
+    if (a.taps == 9) {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        toff = (kh - 1) * (a.W + 2) + (kw - 1);
+    } else {
+        toff = 0;
+    }
+    const long kb = s_begin * BKP;
+    const char* xg = (const char*)a.x + ((kb + toff) * a.Cin + ci0) * SZ;
+    const char* yg = (const char*)a.dy + (kb * a.Cdy + co0) * SZ;
+    const long xstep = (long)BKP * a.Cin * SZ, ystep = (long)BKP * a.Cdy * SZ;
+
+    uint32_t voffx[Cfg::IPWX], voffy[Cfg::IPWY];
+#pragma unroll
+    for (int i = 0; i < Cfg::IPWX; ++i) {
+        const int row = (i * NW + w) * Cfg::RPIX + lane / Cfg::LPRX;
+        const int sl = (lane % Cfg::LPRX) ^ wg_swz<ROWX, SZ>(row);
+        voffx[i] = (uint32_t)row * (uint32_t)(a.Cin * SZ) + sl * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::IPWY; ++i) {
+        const int row = (i * NW + w) * Cfg::RPIY + lane / Cfg::LPRY;
+        const int sl = (lane % Cfg::LPRY) ^ wg_swz<ROWY, SZ>(row);
+        voffy[i] = (uint32_t)row * (uint32_t)(a.Cdy * SZ) + sl * 16;
+    }
+    auto stage = [&](int st, int buf) {
+        const char* xs = xg + (long)st * xstep;
+        const char* ys = yg + (long)st * ystep;
+        char* lb = smem + buf * Cfg::STAGE;
+#pragma unroll
+        for (int i = 0; i < Cfg::IPWX; ++i) glds16(xs + voffx[i], lb + (i * NW + w) * 1024);
+#pragma unroll
+        for (int i = 0; i < Cfg::IPWY; ++i) glds16(ys + voffy[i], lb + Cfg::XS + (i * NW + w) * 1024);
+    };
+
+    f32x16 acc[TI][TO];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TO; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int r32 = lane & 31, hh = lane >> 5;
+    // transposed-read lane constants (f16/bf16)
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+
+    if (nsteps > 0) {
+        stage(0, 0);
+        __syncthreads();
+    }
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) stage(st + 1, buf ^ 1);
+        const char* xs = smem + buf * Cfg::STAGE;
+        const char* ys = xs + Cfg::XS;
+        if constexpr (SZ == 2) {
+            const int fx = wg_swz<ROWX, SZ>(qq), fy = wg_swz<ROWY, SZ>(qq);
+#pragma unroll
+            for (int kg = 0; kg < BKP / 16; ++kg) {
+                typename Elem<T>::frag fa[TI], fb[TO];
+                const int row0 = kg * 16 + 8 * hh + qq;
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    const int slot = (((wi * TI + i) * 4 + 2 * g1 + (pp >> 1)) ^ fx);
+                    const char* p = xs + row0 * ROWX + slot * 16 + (pp & 1) * 8;
+                    fa[i] = tr_frag<T>(p, p + 4 * ROWX);
+                }
+#pragma unroll
+                for (int j = 0; j < TO; ++j) {
+                    const int slot = (((wo * TO + j) * 4 + 2 * g1 + (pp >> 1)) ^ fy);
+                    const char* p = ys + row0 * ROWY + slot * 16 + (pp & 1) * 8;
+                    fb[j] = tr_frag<T>(p, p + 4 * ROWY);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TO; ++j) mma32(acc[i][j], fa[i], fb[j]);
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < BKP / 2; ++s2) {
+                const int row = 2 * s2 + hh;
+                float fa[TI], fb[TO];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) fa[i] = *(const float*)(xs + row * ROWX + ((wi * TI + i) * 32 + r32) * 4);
+#pragma unroll
+                for (int j = 0; j < TO; ++j) fb[j] = *(const float*)(ys + row * ROWY + ((wo * TO + j) * 32 + r32) * 4);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TO; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- accumulate into fp32 HWIO gradient
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TO; ++j) {
+            const int co = co0 + (wo * TO + j) * 32 + r32;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ci = ci0 + (wi * TI + i) * 32 + acc_row(q, hh);
+                if (ci < a.Cin && co < a.Cout)
+                    atomicAdd(a.dW + ((size_t)tap * a.Cin + ci) * a.Cout + co, acc[i][j][q] * a.scale);
+            }
+        }
+}
+
+template <typename T, int WI, int WO, int TI, int TO>
+static hipError_t wg_launch(WgradArgs a, hipStream_t s) {
+    typedef WgCfg<T, WI, WO, TI, TO> Cfg;
+    auto kern = wgrad_kernel<T, WI, WO, TI, TO>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
+    const long Mp = (long)a.N * (a.H + 2) * (a.W + 2);
+    const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
+    const int tiles = a.taps * nIT * nOT;
+    if (a.splitk <= 0) {
+        long sk = (1536 + tiles - 1) / tiles;       // aim at ~6 blocks per CU
+        const long maxsk = (ksteps + 7) / 8;         // at least 8 K steps per block
+        if (sk > maxsk) sk = maxsk;
+        if (sk < 1) sk = 1;
+        a.splitk = (int)sk;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS, s, a);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t wg_T(const WgradArgs& a, hipStream_t s) {
+    const int bi = a.Cin >= 128 ? 128 : a.Cin;       // Cin is 32, 64 or a multiple of 128
+    const int bo = a.Cdy >= 128 ? 128 : (a.Cdy >= 64 ? 64 : 32);
+    if (bi == 128 && bo == 128) return wg_launch<T, 2, 2, 2, 2>(a, s);
+    if (bi == 128 && bo == 64) return wg_launch<T, 2, 2, 2, 1>(a, s);
+    if (bi == 128 && bo == 32) return wg_launch<T, 4, 1, 1, 1>(a, s);
+    if (bi == 64 && bo == 128) return wg_launch<T, 2, 2, 1, 2>(a, s);
+    if (bi == 64 && bo == 64) return wg_launch<T, 2, 2, 1, 1>(a, s);
+    if (bi == 64 && bo == 32) return wg_launch<T, 2, 1, 1, 1>(a, s);
+    if (bi == 32 && bo == 128) return wg_launch<T, 1, 4, 1, 1>(a, s);
+    if (bi == 32 && bo == 64) return wg_launch<T, 1, 2, 1, 1>(a, s);
+    if (bi == 32 && bo == 32) return wg_launch<T, 1, 1, 1, 1>(a, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
+    if (a.Cin % 32 != 0 || (a.Cin > 128 && a.Cin % 128 != 0)) return hipErrorInvalidValue;
+    switch (dtype) {
+        case 0: return wg_T<float>(a, s);
+        case 1: return wg_T<half_t>(a, s);
+        case 2: return wg_T<bf16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace y2

@@ -1,0 +1,307 @@
+"""Host-side driver of one network context of libyolo2_hip.so.
+
+PyTorch is plumbing only: it owns device memory (flat parameter / gradient /
+BN-state buffers, one workspace blob) and the HIP stream handle.  Every
+computation is a hand-written gfx950 kernel behind the C ABI; nothing here
+falls back to torch ops.
+
+Reference counterpart: the TF1 graph + variables that
+src/yolo2_nets/darknet.py builds, and the autodiff graph of
+src/pascal/pascal_train_darknet.py:49-51.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+# (filter_size, in_chl, out_chl, maxpool_after) -- src/yolo2_nets/darknet.py:150-177
+CORE_SPEC = [
+    (3, 3, 32, 1),
+    (3, 32, 64, 1),
+    (3, 64, 128, 0), (3, 128, 64, 0), (3, 64, 128, 1),
+    (3, 128, 256, 0), (1, 256, 128, 0), (3, 128, 256, 1),
+    (3, 256, 512, 0), (1, 512, 256, 0), (3, 256, 512, 0), (1, 512, 256, 0), (3, 256, 512, 1),
+    (3, 512, 1024, 0), (1, 1024, 512, 0), (3, 512, 1024, 0), (1, 1024, 512, 0), (3, 512, 1024, 0),
+]
+
+
+def det_head_spec(output_filter):
+    """src/yolo2_nets/darknet.py:189-200."""
+    return [(3, 1024, 1024, 0)] * 3 + [(1, 1024, output_filter, 0)]
+
+
+CLS_HEAD_SPEC = [(1, 1024, 1000, 0)]   # src/yolo2_nets/darknet.py:115
+
+PARAM_KEYS = ("W", "b", "gamma", "beta")
+STATE_KEYS = ("moving_mean", "moving_var")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Network:
+    """One conv-BN-leaky(-pool) stack bound to device buffers."""
+
+    def __init__(self, spec, batch, height, width, dtype="f16", core_layers=None, tail=_lib.Y2_TAIL_NONE,
+                 tail_k=7, training=True, device="cuda:0", grad_scale=None, bessel=False):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.Y2Error("no MI355X visible: tensorflow_yolo2_amd has no CPU path")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.spec = [tuple(int(v) for v in s) for s in spec]
+        self.dtype = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        self.training = bool(training)
+        self.batch, self.height, self.width = batch, height, width
+        self.core_layers = len(spec) if core_layers is None else core_layers
+        flat = (C.c_int * (4 * len(spec)))(*[v for s in self.spec for v in s])
+        h = C.c_void_p()
+        check(self.lib.y2_ctx_create(C.byref(h), flat, len(spec), self.core_layers, tail, tail_k,
+                                     batch, height, width, self.dtype))
+        self.h = h
+        self.num_layers = len(spec)
+        self.n_params = self.lib.y2_param_count(h)
+        self.n_state = self.lib.y2_state_count(h)
+        shp = (C.c_int * 4)()
+        check(self.lib.y2_output_shape(h, shp))
+        self.out_shape = tuple(shp)
+        if tail == _lib.Y2_TAIL_AVGPOOL:
+            self.out_shape = (shp[0], shp[3]) if shp[1] == 1 and shp[2] == 1 else tuple(shp)
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device) if training else None
+        self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.device)
+        self.ws_bytes = self.lib.y2_workspace_bytes(h, int(training))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        check(self.lib.y2_bind(h, _ptr(self.params), _ptr(self.grads), _ptr(self.state), _ptr(self.workspace),
+                               self.ws_bytes, int(training), _stream()))
+        if grad_scale is None:
+            grad_scale = 1.0 if self.dtype != _lib.Y2_F16 else 1024.0
+        self.grad_scale = float(grad_scale)
+        check(self.lib.y2_set_options(h, self.grad_scale, int(bessel)))
+        self._offsets = []
+        off = (C.c_size_t * 6)()
+        for l in range(self.num_layers):
+            check(self.lib.y2_param_offsets(h, l, off))
+            self._offsets.append(tuple(off))
+        self._out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.y2_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- parameters ------------------------------------------------------
+    def _shapes(self, l):
+        k, ci, co, _ = self.spec[l]
+        return {"W": (k, k, ci, co), "b": (co,), "gamma": (co,), "beta": (co,),
+                "moving_mean": (co,), "moving_var": (co,)}
+
+    def layer_views(self, l, grads=False):
+        """dict of views into the flat buffers (reference creation order W, b, gamma, beta)."""
+        o = self._offsets[l]
+        shp = self._shapes(l)
+        src = self.grads if grads else self.params
+        out = {}
+        for i, k in enumerate(PARAM_KEYS):
+            n = int(np.prod(shp[k]))
+            out[k] = src[o[i]:o[i] + n].view(shp[k])
+        if not grads:
+            for i, k in enumerate(STATE_KEYS):
+                n = int(np.prod(shp[k]))
+                out[k] = self.state[o[4 + i]:o[4 + i] + n].view(shp[k])
+        return out
+
+    def init_params(self, seed=0):
+        """darknet.py:10-17 initial values, generated on the device."""
+        check(self.lib.y2_init_params(self.h, seed, _stream()))
+
+    def load_params(self, layers):
+        """layers: list of dicts with numpy arrays W, b, gamma, beta, moving_mean, moving_var."""
+        assert len(layers) == self.num_layers
+        for l, p in enumerate(layers):
+            v = self.layer_views(l)
+            for k in PARAM_KEYS + STATE_KEYS:
+                v[k].copy_(torch.as_tensor(np.asarray(p[k], np.float32)).to(self.device))
+        check(self.lib.y2_params_changed(self.h))
+
+    def export_params(self):
+        out = []
+        for l in range(self.num_layers):
+            out.append({k: v.detach().cpu().numpy().copy() for k, v in self.layer_views(l).items()})
+        return out
+
+    def export_grads(self):
+        return [{k: v.detach().cpu().numpy().copy() for k, v in self.layer_views(l, grads=True).items()}
+                for l in range(self.num_layers)]
+
+    def params_changed(self):
+        check(self.lib.y2_params_changed(self.h))
+
+    # ---- execution -------------------------------------------------------
+    def forward(self, images, is_training_core=True, is_training_head=True, out=None):
+        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        assert tuple(images.shape[:3]) == (self.batch, self.height, self.width), images.shape
+        out = self._out if out is None else out
+        check(self.lib.y2_forward(self.h, _ptr(images), int(bool(is_training_core)), int(bool(is_training_head)),
+                                  _ptr(out), _stream()))
+        return out
+
+    def backward(self, dout, layer_lo=0, layer_hi=None):
+        layer_hi = self.num_layers if layer_hi is None else layer_hi
+        if dout is not None:
+            assert dout.is_cuda and dout.dtype == torch.float32 and dout.is_contiguous()
+        check(self.lib.y2_backward(self.h, _ptr(dout), layer_lo, layer_hi, _stream()))
+
+    def debug_read(self, layer, what):
+        k, ci, co, _ = self.spec[layer]
+        info = (C.c_int * 8)()
+        check(self.lib.y2_layer_info(self.h, layer, info))
+        c = ci if what == 0 else co
+        t = torch.empty((self.batch, info[4], info[5], c), dtype=torch.float32, device=self.device)
+        check(self.lib.y2_debug_read(self.h, layer, what, _ptr(t), _stream()))
+        return t
+
+
+# ---------------------------------------------------------------------------
+# flat-buffer optimizers
+# ---------------------------------------------------------------------------
+class AdamOptimizer:
+    """tf.train.AdamOptimizer defaults (src/pascal/pascal_train_darknet.py:51)."""
+
+    def __init__(self, net, learning_rate=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        self.net, self.lr, self.b1, self.b2, self.eps = net, learning_rate, beta1, beta2, epsilon
+        self.m = torch.zeros_like(net.params)
+        self.v = torch.zeros_like(net.params)
+        self.t = 0
+
+    def step(self, grad_mult=1.0):
+        self.t += 1
+        n = self.net
+        check(n.lib.y2_adam_step(_ptr(n.params), _ptr(self.m), _ptr(self.v), _ptr(n.grads), n.n_params, self.t,
+                                 self.lr, self.b1, self.b2, self.eps, grad_mult, _stream()))
+        n.params_changed()
+
+
+class MomentumOptimizer:
+    """tf.train.MomentumOptimizer(0.001, 0.9) (src/imagenet/imagenet_train_darknet.py:58)."""
+
+    def __init__(self, net, learning_rate=1e-3, momentum=0.9):
+        self.net, self.lr, self.mom = net, learning_rate, momentum
+        self.accum = torch.zeros_like(net.params)
+
+    def step(self, grad_mult=1.0):
+        n = self.net
+        check(n.lib.y2_momentum_step(_ptr(n.params), _ptr(self.accum), _ptr(n.grads), n.n_params, self.lr,
+                                     self.mom, grad_mult, _stream()))
+        n.params_changed()
+
+
+# ---------------------------------------------------------------------------
+# loss / decode ops on device tensors
+# ---------------------------------------------------------------------------
+LAMBDA_COORD = 5.0   # src/config.py:44
+LAMBDA_NOOBJ = 0.5   # src/config.py:45
+
+
+def yolo_loss(net, labels, num_class, batch_size, image_size, S, B, need_grad=True,
+              lambda_coord=LAMBDA_COORD, lambda_noobj=LAMBDA_NOOBJ):
+    """get_loss (src/yolo2_nets/net_utils.py:263-372) forward (+ d loss / d net).
+    Returns (loss[5] = class, object, noobject, coord, total; ious; object_mask; dnet or None)."""
+    lib = _lib.load()
+    assert net.is_cuda and labels.is_cuda
+    net = net.contiguous().float()
+    labels = labels.contiguous().float()
+    assert net.numel() == batch_size * S * S * (num_class + 5 * B), "net shape does not match batch_size/S/B"
+    assert labels.numel() == batch_size * S * S * (5 + num_class)
+    dev = net.device
+    loss = torch.empty(5, dtype=torch.float32, device=dev)
+    ious = torch.empty((batch_size, S, S, B), dtype=torch.float32, device=dev)
+    mask = torch.empty((batch_size, S, S, B), dtype=torch.float32, device=dev)
+    dnet = torch.empty((batch_size, S, S, num_class + 5 * B), dtype=torch.float32, device=dev) if need_grad else None
+    ws = torch.empty(lib.y2_yolo_loss_workspace_bytes(batch_size, S), dtype=torch.uint8, device=dev)
+    check(lib.y2_yolo_loss(_ptr(net), _ptr(labels), num_class, batch_size, float(image_size), S, B,
+                           lambda_coord, lambda_noobj, _ptr(loss), _ptr(ious), _ptr(mask), _ptr(dnet), _ptr(ws),
+                           _stream()))
+    return loss, ious, mask, dnet
+
+
+def get_iou(boxes1, boxes2):
+    """src/yolo2_nets/net_utils.py:222-260 on [..., 4] device tensors."""
+    lib = _lib.load()
+    b1 = boxes1.contiguous().float()
+    b2 = boxes2.contiguous().float()
+    assert b1.shape == b2.shape and b1.shape[-1] == 4
+    out = torch.empty(b1.shape[:-1], dtype=torch.float32, device=b1.device)
+    check(lib.y2_get_iou(_ptr(b1), _ptr(b2), _ptr(out), out.numel(), _stream()))
+    return out
+
+
+def decode_detections(predict, S, B, num_class, im_w, im_h, object_thresh=0.5):
+    """Arithmetic of show_yolo_detection (src/yolo2_nets/net_utils.py:393-421).
+    Returns the reference's tuples (ulx, uly, w, h, cls, conf, c, r, i) in its loop order."""
+    lib = _lib.load()
+    p = predict.contiguous().float().view(-1)
+    assert p.numel() == S * S * (num_class + 5 * B)
+    det = torch.empty((S * S * B, 8), dtype=torch.int32, device=p.device)
+    conf = torch.empty(S * S * B, dtype=torch.float32, device=p.device)
+    check(lib.y2_decode_detections(_ptr(p), S, B, num_class, im_w, im_h, float(object_thresh), _ptr(det),
+                                   _ptr(conf), _stream()))
+    det = det.cpu().numpy()
+    conf = conf.cpu().numpy()
+    out = []
+    for i in range(S * S * B):
+        if det[i, 0]:
+            out.append((int(det[i, 1]), int(det[i, 2]), int(det[i, 3]), int(det[i, 4]), int(det[i, 5]),
+                        float(conf[i]), int(det[i, 6]), int(det[i, 7]), i % B))
+    return out
+
+
+def softmax_cross_entropy(logits, labels, need_grad=True):
+    """sparse_softmax_cross_entropy_with_logits + reduce_mean (imagenet_train_darknet.py:51-53)."""
+    lib = _lib.load()
+    logits = logits.contiguous().float()
+    labels = labels.contiguous().to(torch.int32)
+    n, c = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if need_grad else None
+    check(lib.y2_softmax_cross_entropy(_ptr(logits), _ptr(labels), n, c, _ptr(loss), _ptr(dl), _stream()))
+    return loss, dl
+
+
+def conv2d(x, w, bias=None, dtype="f32"):
+    """tf.nn.conv2d(x, W, [1,1,1,1], 'SAME') (+ bias) on fp32 NHWC / HWIO device tensors."""
+    lib = _lib.load()
+    dt = _lib.DTYPES[dtype]
+    n, h, wd, ci = x.shape
+    k, _, _, co = w.shape
+    x = x.contiguous().float()
+    w = w.contiguous().float()
+    y = torch.empty((n, h, wd, co), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.y2_conv2d_workspace_bytes(n, h, wd, ci, co, k, dt), dtype=torch.uint8, device=x.device)
+    check(lib.y2_conv2d(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), n, h, wd, ci, co, k, dt, _ptr(ws), _stream()))
+    return y
+
+
+def conv2d_backward(x, w, dy, dtype="f32"):
+    lib = _lib.load()
+    dt = _lib.DTYPES[dtype]
+    n, h, wd, ci = x.shape
+    k, _, _, co = w.shape
+    x, w, dy = x.contiguous().float(), w.contiguous().float(), dy.contiguous().float()
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    ws = torch.empty(lib.y2_conv2d_workspace_bytes(n, h, wd, ci, co, k, dt), dtype=torch.uint8, device=x.device)
+    check(lib.y2_conv2d_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), n, h, wd, ci, co, k, dt,
+                                 _ptr(ws), _stream()))
+    return dx, dw
