@@ -204,10 +204,32 @@ def moving_update(moving, batch, momentum=BN_MOMENTUM):
 # --------------------------------------------------------------------------
 # conv_bn_layer -- darknet.py:32-46
 # --------------------------------------------------------------------------
-def conv_bn_layer(x, p, is_training, pool, dtype=np.float32, bessel=False):
-    """Returns (out, cache, new_moving).  cache holds what backward needs."""
+def quantizer(kind):
+    """Storage-precision model of the fast modes: rounds to f16 / bf16 (round to
+    nearest even) and returns float64.  None / 'f32' -> identity."""
+    if kind in (None, "f32"):
+        return None
+    if kind == "f16":
+        return lambda a: np.asarray(a).astype(np.float16).astype(np.float64)
+    if kind == "bf16":
+        def q(a):
+            u = np.asarray(a, np.float32).view(np.uint32).astype(np.uint64)
+            u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+            return u.astype(np.uint32).view(np.float32).astype(np.float64)
+        return q
+    raise ValueError(kind)
+
+
+def conv_bn_layer(x, p, is_training, pool, dtype=np.float32, bessel=False, quant=None):
+    """Returns (out, cache, new_moving).  cache holds what backward needs.
+    quant (see quantizer) models the half-precision STORAGE points of the HIP fast
+    modes: filter, conv output, layer output (arithmetic in between stays wide)."""
     W = p["W"].astype(dtype)
+    if quant is not None:
+        W = quant(W).astype(dtype)
     h_conv = conv2d_same(x, W) + p["b"].astype(dtype)                 # darknet.py:35
+    if quant is not None:
+        h_conv = quant(h_conv).astype(dtype)
     gamma, beta = p["gamma"].astype(dtype), p["beta"].astype(dtype)
     new_moving = None
     if is_training:
@@ -226,8 +248,11 @@ def conv_bn_layer(x, p, is_training, pool, dtype=np.float32, bessel=False):
     return out, cache, new_moving
 
 
-def conv_bn_layer_backward(p, cache, dout, dtype=np.float32, need_dx=True):
+def conv_bn_layer_backward(p, cache, dout, dtype=np.float32, need_dx=True, quant=None, grad_scale=1.0):
     W = p["W"].astype(dtype)
+    if quant is not None:
+        W = quant(W).astype(dtype)
+        dout = quant(dout * grad_scale).astype(dtype) / grad_scale
     gamma = p["gamma"].astype(dtype)
     d_act = max_pool_2x2_backward(cache["act"], dout) if cache["pool"] else dout
     d_bn = leaky_backward(cache["h_bn"], d_act)
@@ -241,6 +266,8 @@ def conv_bn_layer_backward(p, cache, dout, dtype=np.float32, need_dx=True):
         dbeta = d_bn.sum(axis=(0, 1, 2))
         d_conv = d_bn * gamma * inv
     db = d_conv.sum(axis=(0, 1, 2))
+    if quant is not None:
+        d_conv = quant(d_conv * grad_scale).astype(dtype) / grad_scale
     dx, dW = conv2d_same_backward(cache["x"], W, d_conv)
     grads = dict(W=dW, b=db, gamma=dgamma, beta=dbeta)
     return (dx if need_dx else None), grads
@@ -249,21 +276,29 @@ def conv_bn_layer_backward(p, cache, dout, dtype=np.float32, need_dx=True):
 # --------------------------------------------------------------------------
 # networks
 # --------------------------------------------------------------------------
-def run_stack(x, params, spec, is_training, dtype=np.float32, bessel=False):
+def run_stack(x, params, spec, is_training, dtype=np.float32, bessel=False, quant=None):
+    """is_training: bool, or a per-layer list of bools.  The LAST layer's output is
+    never quantised (the HIP path emits it in fp32)."""
     caches, movings = [], []
     x = x.astype(dtype)
-    for p, (_k, _ci, _co, pool) in zip(params, spec):
-        x, cache, mv = conv_bn_layer(x, p, is_training, pool, dtype, bessel)
+    if quant is not None:
+        x = quant(x).astype(dtype)
+    n = len(params)
+    for i, (p, (_k, _ci, _co, pool)) in enumerate(zip(params, spec)):
+        tr = is_training[i] if isinstance(is_training, (list, tuple)) else is_training
+        x, cache, mv = conv_bn_layer(x, p, tr, pool, dtype, bessel, quant)
+        if quant is not None and i + 1 < n:
+            x = quant(x).astype(dtype)
         caches.append(cache)
         movings.append(mv)
     return x, caches, movings
 
 
-def run_stack_backward(params, caches, dout, dtype=np.float32, need_input_grad=False):
+def run_stack_backward(params, caches, dout, dtype=np.float32, need_input_grad=False, quant=None, grad_scale=1.0):
     grads = [None] * len(params)
     for i in range(len(params) - 1, -1, -1):
         need_dx = need_input_grad or i > 0
-        dout, grads[i] = conv_bn_layer_backward(params[i], caches[i], dout, dtype, need_dx)
+        dout, grads[i] = conv_bn_layer_backward(params[i], caches[i], dout, dtype, need_dx, quant, grad_scale)
     return dout, grads
 
 

@@ -552,8 +552,7 @@ struct OpPlan {
 static OpPlan op_plan(int N, int H, int W, int Cin, int Cout, int k, int dtype) {
     OpPlan p{};
     const size_t sz = dtype_size(dtype);
-    p.Cin_p = round_up(Cin, 32);
-    if (p.Cin_p > 128) p.Cin_p = round_up(Cin, 128);
+    p.Cin_p = Cin <= 32 ? 32 : (Cin <= 64 ? 64 : round_up(Cin, 128));
     p.ldy = round_up(Cout, 32);
     p.Cdy = p.ldy;
     p.Cout_pad = round_up(Cout, conv_block_couts(Cout));

@@ -20,6 +20,11 @@ def relerr(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def l2err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
 TOL = {"f32": 1e-5, "f16": 4e-3, "bf16": 3e-2}
 
 
@@ -150,15 +155,22 @@ def test_stack_backward(first3, dtype):
     net = E.Network(spec, shape[0], shape[1], shape[2], dtype=dtype, training=True)
     net.load_params(params)
     out = net.forward(dev(x), True, True)
-    ref, caches, _ = R.run_stack(x, params, spec, True, np.float64)
+    # f32 mode is checked against the exact reference semantics.  The half modes are
+    # the exact gradient of a function that differs from the f32 one at max-pool /
+    # leaky decisions (activations are STORED in half precision), so they are checked
+    # against the oracle with the same storage points quantised (oracle quantizer()).
+    q = R.quantizer(dtype)
+    ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q)
+    assert l2err(out.cpu().numpy(), ref) < {"f32": 1e-5, "f16": 1e-3, "bf16": 8e-3}[dtype]
     dout = rng.standard_normal(ref.shape).astype(np.float32)
     net.backward(dev(dout))
-    _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64)
+    _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,
+                                     grad_scale=net.grad_scale)
     grads = net.export_grads()
-    tol = {"f32": 2e-4, "f16": 3e-2, "bf16": 2e-1}[dtype]
+    tol = {"f32": 2e-4, "f16": 1e-2, "bf16": 6e-2}[dtype]
     for l in range(len(spec)):
         for k in ("W", "gamma", "beta"):
-            e = relerr(grads[l][k], rgrads[l][k])
+            e = l2err(grads[l][k], rgrads[l][k])
             assert e < tol, (l, k, e)
         # conv bias gradient is mathematically zero under batch-stat BN: absolute check
         scale = np.abs(rgrads[l]["gamma"]).max() + np.abs(rgrads[l]["beta"]).max()
