@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the Darknet-19 YOLO detector TRAIN STEP
+(darknet19_core + darknet19_detection + get_loss + backward + Adam) at 416x416,
+batch 64 per GPU, synthetic inputs resident in HBM (BASELINE.json configs[3]; the
+metric is quoted on fwd+bwd at 416x416, which fits one GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the MFMA
+implicit-GEMM convolution: forward + dgrad launches): algorithmic FLOPs of those
+launches / their HIP-event time measured on the launch stream inside the timed region.
+`cpu_baseline` is the oracle's PyTorch-CPU restatement of the same train step on a
+bounded sample (rank 0, N=1 only) -- "port", NOT the TF1 reference, which cannot run here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"f16": 2500.0, "bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md, dense
+
+
+def conv_flops(spec, batch, size):
+    """(forward FLOPs of the implicit-GEMM layers, of conv1, list per layer)"""
+    h = size
+    per = []
+    for (k, ci, co, pool) in spec:
+        per.append(2.0 * batch * h * h * k * k * ci * co)
+        if pool:
+            h = (h + 1) // 2
+    return per
+
+
+def cpu_baseline(args, spec_core, spec_head):
+    """oracle (torch-CPU restatement) timed on the host cores: bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    from oracle import torch_ref as T, nn_ref as R
+    from tensorflow_yolo2_amd import synthetic
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bs = args.cpu_batch
+    size, S = args.image_size, args.image_size // 32
+    spec = [(k, ci, co, bool(p)) for (k, ci, co, p) in spec_core + spec_head]
+    params = T.to_torch_params(R.init_params(spec, seed=0), torch.float32, requires_grad=True)
+    step = T.detector_train_step_fn(spec[:len(spec_core)], spec[len(spec_core):], params, S, 2, 20, size)
+    x = torch.as_tensor(synthetic.images(bs, size, 1234))
+    lab = torch.as_tensor(synthetic.det_labels(bs, size, S, 4321))
+    step(x, lab)                                   # warm-up
+    times = []
+    t_end = time.time() + args.cpu_seconds
+    while len(times) < 5 and (time.time() < t_end or not times):
+        t0 = time.time()
+        step(x, lab)
+        times.append(time.time() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": bs / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle/torch_ref.py (PyTorch-CPU fp32 restatement, not TF1): detector fwd+loss+bwd, "
+                      "%dx%d, batch %d, median of %d steps" % (size, size, bs, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--image-size", type=int, default=416)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
+    ap.add_argument("--kernel-events", default="timed", choices=["timed", "separate", "off"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--forward-only", action="store_true", help="configs[1]: core forward only (inference BN)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from tensorflow_yolo2_amd.trainer import DetectorTrainer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    device = "cuda:%d" % local_rank
+    torch.cuda.set_device(device)
+
+    size, bs = args.image_size, args.batch
+    S = size // 32
+    spec_core, spec_head = list(E.CORE_SPEC), E.det_head_spec(30)
+    images = torch.as_tensor(synthetic.images(bs, size, 1234 + rank)).to(device)
+    labels = torch.as_tensor(synthetic.det_labels(bs, size, S, 4321 + rank)).to(device)
+
+    if args.forward_only:
+        net = E.Network(spec_core, bs, size, size, dtype=args.dtype, training=False, device=device)
+        net.init_params(0)
+        run = lambda: net.forward(images, False, False)
+        spec = spec_core
+        flop_mult = 1.0
+    else:
+        tr = DetectorTrainer(bs, size, dtype=args.dtype, device=device, seed=0)
+        net = tr.net
+        run = lambda: tr.step(images, labels)
+        spec = spec_core + spec_head
+        flop_mult = 3.0
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run()
+    sync_all()
+    if args.kernel_events == "timed":
+        net.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = net.profile_collect() if args.kernel_events == "timed" else None
+    net.profile_enable(False)
+    if args.kernel_events == "separate":
+        net.profile_enable(True)
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        prof = net.profile_collect()
+        net.profile_enable(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * bs * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        per = conv_flops(spec, bs, size)
+        fwd_igemm = sum(per[1:])
+        # forward igemm launches: layers 1..L-1; dgrad launches: layers 1..L-1 (layer 0 needs no dgrad)
+        igemm_flops = fwd_igemm * (1.0 if args.forward_only else 2.0)
+        roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                "frac": None, "traffic": None, "kernel": "conv_igemm_kernel (forward + dgrad launches)"}
+        kernels = None
+        if prof is not None:
+            t_igemm = (prof["conv_fwd"][0] + prof["dgrad"][0]) / args.steps * 1e-3
+            if t_igemm > 0:
+                roof["achieved"] = igemm_flops / t_igemm / 1e12
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                roof["avg_launch_ms"] = (prof["conv_fwd"][0] + prof["dgrad"][0]) / max(
+                    prof["conv_fwd"][1] + prof["dgrad"][1], 1)
+            kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
+                       for k, v in prof.items()}
+            if not args.forward_only and prof["wgrad"][0] > 0:
+                kernels["wgrad"]["tflops"] = fwd_igemm / (prof["wgrad"][0] / args.steps * 1e-3) / 1e12
+        total_flops = sum(per) * flop_mult
+        out = {
+            "metric": "images/sec fwd+bwd Darknet-19 416x416" if not args.forward_only
+                      else "images/sec forward Darknet-19 core 416x416",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("YOLO detector train step: darknet19_core + darknet19_detection(30) + get_loss "
+                                    "+ backward + Adam" if not args.forward_only else "darknet19_core forward"),
+                       "image_size": size, "batch_per_gpu": bs, "global_batch": bs * world, "S": S, "B": 2,
+                       "parallelism": "dp%d" % world, "grad_allreduce": "rccl sum, 3 overlapped slices"
+                       if world > 1 else "none"},
+            "whole_step_tflops": total_flops / (ms_per_step * 1e-3) / 1e12 * 1.0,
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline and not args.forward_only:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, spec_core, spec_head)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,13 @@ int y2_backward(y2_ctx* ctx, const float* dout, int layer_lo, int layer_hi, void
 /* copy a layer's saved activation (post BN+leaky+pool input of `layer`, or conv output) for tests */
 int y2_debug_read(y2_ctx* ctx, int layer, int what, float* dst, void* stream);
 
+/* Optional measurement aid: bracket every kernel launch of y2_forward / y2_backward with
+ * HIP events on the launch stream (the reference only has utils/timer.py wall clocks).
+ * Categories: 0 conv fwd (implicit GEMM), 1 conv1 fwd, 2 dgrad, 3 wgrad, 4 conv1 wgrad,
+ * 5 BN fwd passes, 6 BN bwd passes, 7 pack/convert.  collect() waits for the events. */
+int y2_profile_enable(y2_ctx* ctx, int on);
+int y2_profile_collect(y2_ctx* ctx, double* ms_by_category, int* launches_by_category, int ncat);
+
 /* ---- get_loss / get_iou / show_yolo_detection (src/yolo2_nets/net_utils.py:222-439) */
 size_t y2_yolo_loss_workspace_bytes(int batch, int S);
 /* loss[5] = class, object, noobject, coord, total; dnet may be NULL */

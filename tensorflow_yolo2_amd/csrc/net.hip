@@ -89,10 +89,35 @@ struct y2_ctx {
     size_t part_rows, part_ld;
     size_t total_infer = 0, total_train = 0;
     int dA_cur = 0;
+    // optional per-launch HIP-event bracketing (bench.py roofline leg)
+    bool prof = false;
+    struct ProfRec { int cat; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    size_t prof_used = 0;
     size_t sz() const { return dtype_size(dtype); }
     PadGeom in_geom(int l) const { return PadGeom{N, L[l].H, L[l].W, L[l].cin_s}; }
     PadGeom dy_geom(int l) const { return PadGeom{N, L[l].H, L[l].W, L[l].ldy}; }
 };
+
+enum { CAT_CONV_FWD = 0, CAT_CONV1_FWD, CAT_DGRAD, CAT_WGRAD, CAT_CONV1_WGRAD, CAT_BN_FWD, CAT_BN_BWD, CAT_MISC,
+       CAT_COUNT };
+
+struct ProfScope {
+    y2_ctx* c; hipStream_t s; int idx = -1;
+    ProfScope(y2_ctx* c_, hipStream_t s_, int cat) : c(c_), s(s_) {
+        if (!c->prof) return;
+        if (c->prof_used == c->prof_recs.size()) {
+            y2_ctx::ProfRec r; r.cat = cat;
+            if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+            c->prof_recs.push_back(r);
+        }
+        idx = (int)c->prof_used++;
+        c->prof_recs[idx].cat = cat;
+        hipEventRecord(c->prof_recs[idx].a, s);
+    }
+    ~ProfScope() { if (idx >= 0) hipEventRecord(c->prof_recs[idx].b, s); }
+};
+#define PROF(cat) ProfScope _prof_scope(c, s, cat)
 
 static void plan(y2_ctx* c) {
     const size_t sz = c->sz();
@@ -250,7 +275,31 @@ int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers
     return Y2_OK;
 }
 
-void y2_ctx_destroy(y2_ctx* ctx) { delete ctx; }
+void y2_ctx_destroy(y2_ctx* ctx) {
+    if (!ctx) return;
+    for (auto& r : ctx->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    delete ctx;
+}
+
+int y2_profile_enable(y2_ctx* c, int on) {
+    c->prof = on != 0;
+    c->prof_used = 0;
+    return Y2_OK;
+}
+int y2_profile_collect(y2_ctx* c, double* ms, int* count, int ncat) {
+    if (ncat < CAT_COUNT) return fail(Y2_ERR_ARG, "need room for %d categories", (int)CAT_COUNT);
+    for (int i = 0; i < ncat; ++i) { ms[i] = 0.0; count[i] = 0; }
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        auto& r = c->prof_recs[i];
+        HIPCHK(hipEventSynchronize(r.b));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.cat] += t;
+        count[r.cat] += 1;
+    }
+    c->prof_used = 0;
+    return Y2_OK;
+}
 int y2_num_layers(const y2_ctx* c) { return (int)c->L.size(); }
 int y2_layer_info(const y2_ctx* c, int l, int info[8]) {
     if (l < 0 || l >= (int)c->L.size()) return fail(Y2_ERR_ARG, "layer out of range");
@@ -314,6 +363,7 @@ int y2_params_changed(y2_ctx* c) {
 }
 
 static int pack_all_weights(y2_ctx* c, hipStream_t s) {
+    PROF(CAT_MISC);
     for (size_t l = 0; l < c->L.size(); ++l) {
         const Layer& y = c->L[l];
         if (y.first3) {
@@ -350,7 +400,7 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
         float *scale = stat, *shift = stat + y.ldy, *mean = stat + 2 * y.ldy, *invstd = stat + 3 * y.ldy;
         int P = 0;
         if (y.first3) {
-            HIPCHK(launch_pack_input(c->dtype, images, xin, c->N, y.H, y.W, s));
+            { PROF(CAT_MISC); HIPCHK(launch_pack_input(c->dtype, images, xin, c->N, y.H, y.W, s)); }
             Conv1Args a{};
             a.x4 = xin; a.w = c->ws + y.wf; a.y = c->ws + y.y; a.bias = c->params + y.pb;
             a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2;
@@ -358,7 +408,7 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
             int nb = (y.M + 127) / 128;
             a.nblocks = nb > 2048 ? 2048 : nb;
             P = a.nblocks;
-            HIPCHK(launch_conv1_fwd(c->dtype, a, s));
+            { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
         } else {
             if (l == 0) HIPCHK(launch_pack_act(c->dtype, images, xin, c->N, y.H, y.W, y.cin, y.cin_s, s));
             ConvArgs a{};
@@ -367,8 +417,9 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
             a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.cin_s; a.M = y.M; a.Cout = y.cout; a.ldy = y.ldy;
             a.taps = y.k * y.k;
             P = (y.M + conv_block_pixels(y.cout) - 1) / conv_block_pixels(y.cout);
-            HIPCHK(launch_conv_igemm(c->dtype, a, s));
+            { PROF(CAT_CONV_FWD); HIPCHK(launch_conv_igemm(c->dtype, a, s)); }
         }
+        PROF(CAT_BN_FWD);
         if (training) {
             BnFinalizeArgs f{};
             f.part_cnt = part_cnt; f.part_mean = part_mean; f.part_m2 = part_m2;
@@ -421,6 +472,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             src = dh;
         }
         c->dA_cur = 0;
+        PROF(CAT_MISC);
         HIPCHK(launch_convert_grad(c->dtype, src, dA[0], y.M, y.cout, y.ldy, c->grad_scale, s));
         // weight/bias gradients are accumulated with atomics: clear the whole flat buffer once per step
         HIPCHK(hipMemsetAsync(c->grads, 0, c->nparams * sizeof(float), s));
@@ -440,27 +492,30 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         b.N = c->N; b.H = y.H; b.W = y.W; b.C = y.cout; b.ldy = y.ldy;
         b.ldd = y.ldy;
         b.pool = y.pool; b.training = c->fwd_training[l]; b.inv_grad_scale = inv_gs;
-        HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
-        HIPCHK(launch_bn_bwd_finalize(b, s));
-        HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
+        {
+            PROF(CAT_BN_BWD);
+            HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
+            HIPCHK(launch_bn_bwd_finalize(b, s));
+            HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
+        }
         char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
         if (y.first3) {
             Conv1WgradArgs g{};
             g.x4 = xin; g.dy = dyp; g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M; g.scale = inv_gs;
-            HIPCHK(launch_conv1_wgrad(c->dtype, g, s));
+            { PROF(CAT_CONV1_WGRAD); HIPCHK(launch_conv1_wgrad(c->dtype, g, s)); }
         } else {
             WgradArgs g{};
             g.x = xin; g.dy = dyp; g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M;
             g.Cin = y.cin_s; g.Cdy = y.ldy; g.Cout = y.cout; g.taps = y.k * y.k; g.splitk = 0; g.scale = inv_gs;
-            HIPCHK(launch_wgrad(c->dtype, g, s));
+            { PROF(CAT_WGRAD); HIPCHK(launch_wgrad(c->dtype, g, s)); }
             if (l > 0) {
                 ConvArgs a{};
                 a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
                 a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.ldy; a.M = y.M; a.Cout = y.cin; a.ldy = y.cin;
                 a.taps = y.k * y.k;
-                HIPCHK(launch_conv_igemm(c->dtype, a, s));
+                { PROF(CAT_DGRAD); HIPCHK(launch_conv_igemm(c->dtype, a, s)); }
                 c->dA_cur ^= 1;
             }
         }

@@ -163,6 +163,18 @@ class Network:
             assert dout.is_cuda and dout.dtype == torch.float32 and dout.is_contiguous()
         check(self.lib.y2_backward(self.h, _ptr(dout), layer_lo, layer_hi, _stream()))
 
+    PROFILE_CATEGORIES = ("conv_fwd", "conv1_fwd", "dgrad", "wgrad", "conv1_wgrad", "bn_fwd", "bn_bwd", "misc")
+
+    def profile_enable(self, on=True):
+        check(self.lib.y2_profile_enable(self.h, int(on)))
+
+    def profile_collect(self):
+        n = len(self.PROFILE_CATEGORIES)
+        ms = (C.c_double * n)()
+        cnt = (C.c_int * n)()
+        check(self.lib.y2_profile_collect(self.h, ms, cnt, n))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(self.PROFILE_CATEGORIES)}
+
     def debug_read(self, layer, what):
         k, ci, co, _ = self.spec[layer]
         info = (C.c_int * 8)()

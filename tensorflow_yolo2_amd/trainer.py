@@ -1,0 +1,111 @@
+"""Train-step drivers: the counterpart of the `sess.run([loss, train_op, ...])` loop of
+src/pascal/pascal_train_darknet.py:96-102 and src/imagenet/imagenet_train_darknet.py:106-135.
+
+Data parallelism (not in the reference): one process per GPU,
+identically seeded replicas, batch sharded by rank, BN statistics per replica, ONE
+flat fp32 gradient buffer all-reduced (SUM) over RCCL/xGMI, then scaled by 1/world
+inside the optimizer kernel -- slim's clone semantics (model_deploy.py:222-225,
+436-446: clone loss / num_clones, add_n over clones).  The all-reduce is issued in
+layer slices on a side stream as soon as backward has finished them (head first:
+its three 37.7 MB filters are 59 % of the payload), overlapping the remaining
+dgrad/wgrad kernels.
+"""
+import torch
+
+from . import _lib, engine
+from .engine import (CORE_SPEC, CLS_HEAD_SPEC, det_head_spec, Network, AdamOptimizer, MomentumOptimizer,
+                     yolo_loss, softmax_cross_entropy)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+class GradReducer:
+    """Sliced, overlapped all-reduce of a Network's flat gradient buffer."""
+
+    def __init__(self, net, slices=None):
+        self.net = net
+        n = net.num_layers
+        if slices is None:
+            # backward order: head / 13x13 block / rest
+            cuts = sorted({0, min(13, n), min(18, n), n})
+            slices = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)][::-1]
+        self.slices = slices
+        self.comm_stream = torch.cuda.Stream(device=net.device) if net.device.type == "cuda" else None
+        self._pending = []
+
+    def _range(self, lo, hi):
+        start = self.net._offsets[lo][0]
+        end = self.net.n_params if hi == self.net.num_layers else self.net._offsets[hi][0]
+        return start, end
+
+    def backward_and_reduce(self, dout):
+        dist = _dist()
+        net = self.net
+        if dist is None:
+            net.backward(dout)
+            return 1
+        for (lo, hi) in self.slices:
+            net.backward(dout if hi == net.num_layers else None, lo, hi)
+            s, e = self._range(lo, hi)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                dist.all_reduce(net.grads[s:e], op=dist.ReduceOp.SUM)
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        return dist.get_world_size()
+
+
+class DetectorTrainer:
+    """darknet19_core + darknet19_detection + get_loss + AdamOptimizer().minimize
+    (src/pascal/pascal_train_darknet.py:39-51) as one object."""
+
+    def __init__(self, batch, image_size=224, S=None, B=2, num_class=20, dtype="f16", device="cuda:0",
+                 grad_scale=None, seed=0, core_spec=None, head_spec=None):
+        core_spec = list(core_spec or CORE_SPEC)
+        head_spec = list(head_spec or det_head_spec(5 * B + num_class))
+        self.net = Network(core_spec + head_spec, batch, image_size, image_size, dtype=dtype,
+                           core_layers=len(core_spec), training=True, device=device, grad_scale=grad_scale)
+        self.batch, self.image_size, self.B, self.num_class = batch, image_size, B, num_class
+        self.S = self.net.out_shape[1] if S is None else S
+        assert self.net.out_shape[1] == self.S == self.net.out_shape[2], (self.net.out_shape, self.S)
+        self.net.init_params(seed)
+        self.opt = AdamOptimizer(self.net)
+        self.reducer = GradReducer(self.net)
+        self.last = None
+
+    def forward_loss(self, images, labels, is_training=True, need_grad=True):
+        grid_net = self.net.forward(images, is_training, True)           # head BN always batch stats (darknet.py:184)
+        return grid_net, yolo_loss(grid_net, labels, self.num_class, self.batch, self.image_size, self.S, self.B,
+                                   need_grad=need_grad)
+
+    def step(self, images, labels):
+        grid_net, (loss, ious, mask, dnet) = self.forward_loss(images, labels, True, True)
+        world = self.reducer.backward_and_reduce(dnet)
+        self.opt.step(grad_mult=1.0 / world)
+        self.last = (loss, ious, mask)
+        return loss, ious, mask
+
+
+class ClassifierTrainer:
+    """darknet19 + sparse softmax CE + MomentumOptimizer(0.001, 0.9)
+    (src/imagenet/imagenet_train_darknet.py:46-58)."""
+
+    def __init__(self, batch, image_size=224, dtype="f16", device="cuda:0", grad_scale=None, seed=0, spec=None):
+        spec = list(spec or (CORE_SPEC + CLS_HEAD_SPEC))
+        self.net = Network(spec, batch, image_size, image_size, dtype=dtype, core_layers=len(spec),
+                           tail=_lib.Y2_TAIL_AVGPOOL, tail_k=image_size // 32, training=True, device=device,
+                           grad_scale=grad_scale)
+        self.net.init_params(seed)
+        self.opt = MomentumOptimizer(self.net, 1e-3, 0.9)
+        self.reducer = GradReducer(self.net)
+
+    def step(self, images, labels):
+        logits = self.net.forward(images, True, True)
+        loss, dlogits = softmax_cross_entropy(logits, labels)
+        world = self.reducer.backward_and_reduce(dlogits)
+        self.opt.step(grad_mult=1.0 / world)
+        return loss, logits
