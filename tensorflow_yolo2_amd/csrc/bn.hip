@@ -14,41 +14,73 @@ namespace y2 {
 // ---------------------------------------------------------------------------
 // merge per-block (count, mean, M2) partials -> batch mean / biased variance
 // ---------------------------------------------------------------------------
+// block = 8 channels x 128 slices of the partial list; loads are unrolled so the
+// (latency-bound) walk over P partials keeps 4 independent loads in flight per thread
+constexpr int kFinCh = 8, kFinSl = 128;
+
+Y2_DEV double fin_block_sum(double v, double (*red)[kFinCh], int sl, int cl) {
+    __syncthreads();
+    red[sl][cl] = v;
+    __syncthreads();
+    for (int s = kFinSl / 2; s > 0; s >>= 1) {
+        if (sl < s) red[sl][cl] += red[sl + s][cl];
+        __syncthreads();
+    }
+    return red[0][cl];
+}
+
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinalizeArgs a) {
-    __shared__ double red[32][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double red[kFinSl][kFinCh];
+    const int cl = threadIdx.x % kFinCh, sl = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
     const bool cv = c < a.C;
+    const int cc = cv ? c : 0;
     double n = 0.0, sm = 0.0;
-    if (cv)
-        for (int p = sl; p < a.P; p += 32) {
-            const double k = a.part_cnt[p];
-            n += k;
-            sm += k * (double)a.part_mean[(size_t)p * a.ldp + c];
+    {
+        double n4[4] = {0, 0, 0, 0}, s4[4] = {0, 0, 0, 0};
+        int p = sl;
+        for (; p + 3 * kFinSl < a.P; p += 4 * kFinSl) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double k = a.part_cnt[p + u * kFinSl];
+                n4[u] += k;
+                s4[u] += k * (double)a.part_mean[(size_t)(p + u * kFinSl) * a.ldp + cc];
+            }
         }
-    red[sl][cl] = n;
-    __syncthreads();
-    double ntot = 0.0;
-    for (int i = 0; i < 32; ++i) ntot += red[i][cl];
-    __syncthreads();
-    red[sl][cl] = sm;
-    __syncthreads();
-    double stot = 0.0;
-    for (int i = 0; i < 32; ++i) stot += red[i][cl];
-    __syncthreads();
+        for (; p < a.P; p += kFinSl) {
+            const double k = a.part_cnt[p];
+            n4[0] += k;
+            s4[0] += k * (double)a.part_mean[(size_t)p * a.ldp + cc];
+        }
+        n = (n4[0] + n4[1]) + (n4[2] + n4[3]);
+        sm = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    const double ntot = fin_block_sum(n, red, sl, cl);
+    const double stot = fin_block_sum(sm, red, sl, cl);
     const double mean = ntot > 0 ? stot / ntot : 0.0;
     double m2 = 0.0;
-    if (cv)
-        for (int p = sl; p < a.P; p += 32) {
-            const double k = a.part_cnt[p];
-            const double d = (double)a.part_mean[(size_t)p * a.ldp + c] - mean;
-            m2 += (double)a.part_m2[(size_t)p * a.ldp + c] + k * d * d;
+    {
+        double m4[4] = {0, 0, 0, 0};
+        int p = sl;
+        for (; p + 3 * kFinSl < a.P; p += 4 * kFinSl) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t q = (size_t)(p + u * kFinSl) * a.ldp + cc;
+                const double k = a.part_cnt[p + u * kFinSl];
+                const double d = (double)a.part_mean[q] - mean;
+                m4[u] += (double)a.part_m2[q] + k * d * d;
+            }
         }
-    red[sl][cl] = m2;
-    __syncthreads();
+        for (; p < a.P; p += kFinSl) {
+            const size_t q = (size_t)p * a.ldp + cc;
+            const double k = a.part_cnt[p];
+            const double d = (double)a.part_mean[q] - mean;
+            m4[0] += (double)a.part_m2[q] + k * d * d;
+        }
+        m2 = (m4[0] + m4[1]) + (m4[2] + m4[3]);
+    }
+    const double mt = fin_block_sum(m2, red, sl, cl);
     if (sl == 0 && cv) {
-        double mt = 0.0;
-        for (int i = 0; i < 32; ++i) mt += red[i][cl];
         const float var = (float)(ntot > 0 ? mt / ntot : 0.0);
         const float meanf = (float)mean;
         const float inv = 1.0f / sqrtf(var + a.eps);
@@ -68,7 +100,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinalizeArgs a) {
 }
 
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.C + 31) / 32), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 
@@ -339,41 +371,42 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
             for (int e = 0; e < EPC; ++e) {
                 float t = 0.f;
                 for (int r = 0; r < g.rows; ++r) t += red[(r * g.CT + ch) * EPC + e];
-                if (c0 + e < a.C) {
-                    if (APPLY) {
-                        if (a.dbias) atomicAdd(a.dbias + c0 + e, t * a.inv_grad_scale);
-                    } else {
-                        a.psum[((size_t)blockIdx.x * 2 + k) * a.ldy + c0 + e] = t;
-                    }
-                }
+                // APPLY: slot 0 holds the block's sum(dy) (conv-bias gradient partial)
+                if (c0 + e < a.C) a.psum[((size_t)blockIdx.x * 2 + k) * a.ldy + c0 + e] = t;
             }
         }
     }
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs a) {
-    __shared__ double red[32][33];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+// mode 0: after the reduce pass -> dbeta, dgamma, coef.  mode 1: after the apply pass -> dbias.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs a, int mode, int P) {
+    __shared__ double red[kFinSl][kFinCh];
+    const int cl = threadIdx.x % kFinCh, sl = threadIdx.x / kFinCh;
+    const int c = blockIdx.x * kFinCh + cl;
     const bool cv = c < a.C;
-    double t[2];
-    for (int k = 0; k < 2; ++k) {
-        double v = 0.0;
-        if (cv)
-            for (int p = sl; p < a.P; p += 32) v += (double)a.psum[((size_t)p * 2 + k) * a.ldy + c];
-        __syncthreads();
-        red[sl][cl] = v;
-        __syncthreads();
-        double tt = 0.0;
-        for (int i = 0; i < 32; ++i) tt += red[i][cl];
-        t[k] = tt;
+    const int cc = cv ? c : 0;
+    double t[2] = {0.0, 0.0};
+    const int nk = mode == 0 ? 2 : 1;
+    for (int k = 0; k < nk; ++k) {
+        double v4[4] = {0, 0, 0, 0};
+        int p = sl;
+        for (; p + 3 * kFinSl < P; p += 4 * kFinSl) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] += (double)a.psum[((size_t)(p + u * kFinSl) * 2 + k) * a.ldy + cc];
+        }
+        for (; p < P; p += kFinSl) v4[0] += (double)a.psum[((size_t)p * 2 + k) * a.ldy + cc];
+        t[k] = fin_block_sum((v4[0] + v4[1]) + (v4[2] + v4[3]), red, sl, cl);
     }
     if (sl == 0 && cv) {
-        const double m = (double)a.N * a.H * a.W;
-        a.dbeta[c] = (float)(t[0] * a.inv_grad_scale);
-        a.dgamma[c] = (float)(t[1] * a.inv_grad_scale);
-        a.coef[c] = a.training ? (float)(t[0] / m) : 0.f;
-        a.coef[a.ldy + c] = a.training ? (float)(t[1] / m) : 0.f;
+        if (mode == 0) {
+            const double m = (double)a.N * a.H * a.W;
+            a.dbeta[c] = (float)(t[0] * a.inv_grad_scale);
+            a.dgamma[c] = (float)(t[1] * a.inv_grad_scale);
+            a.coef[c] = a.training ? (float)(t[0] / m) : 0.f;
+            a.coef[a.ldy + c] = a.training ? (float)(t[1] / m) : 0.f;
+        } else {
+            a.dbias[c] = (float)(t[0] * a.inv_grad_scale);
+        }
     }
 }
 
@@ -403,16 +436,21 @@ hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + 31) / 32), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, 0, a.P);
     return hipGetLastError();
 }
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s) {
+    hipError_t e = hipErrorInvalidValue;
+    int P = 0;
     switch (dtype) {
-        case 0: return bn_bwd_T<float, true>(a, s);
-        case 1: return bn_bwd_T<half_t, true>(a, s);
-        case 2: return bn_bwd_T<bf16_t, true>(a, s);
+        case 0: P = bwd_blocks<float>(a); e = bn_bwd_T<float, true>(a, s); break;
+        case 1: P = bwd_blocks<half_t>(a); e = bn_bwd_T<half_t, true>(a, s); break;
+        case 2: P = bwd_blocks<bf16_t>(a); e = bn_bwd_T<bf16_t, true>(a, s); break;
     }
-    return hipErrorInvalidValue;
+    if (e != hipSuccess) return e;
+    if (a.dbias)   // conv-bias gradient = sum(dy): block partials -> one tiny reduction (no contended atomics)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, 1, P);
+    return hipGetLastError();
 }
 
 }  // namespace y2

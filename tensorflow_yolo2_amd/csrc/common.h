@@ -101,6 +101,19 @@ Y2_DEV float leaky01(float z) { return fmaxf(0.1f * z, z); }
 // TF maximum(alpha*z, z): gradient to alpha*z where alpha*z >= z, i.e. z <= 0
 Y2_DEV float leaky01_slope(float z) { return (0.1f * z >= z) ? 0.1f : 1.0f; }
 
+// two ds_read_b64_tr_b16 (hardware-transposed LDS reads, 16-bit elements) -> one 8-element
+// MFMA fragment: p0 addresses k = 0..3 of this lane's half, p1 the next four
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T>
+Y2_DEV typename Elem<T>::frag tr_frag(const char* p0, const char* p1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+    s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename Elem<T>::frag, both);
+}
+
 // fast unsigned division by a runtime constant via 32-bit magic (valid for n < 2^31)
 struct FastDiv {
     uint32_t d, m, s;  // q = (hi32(n*m) + n) >> s  (round-up method)

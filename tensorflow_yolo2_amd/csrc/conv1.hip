@@ -160,58 +160,4 @@ hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------
-// conv1 weight gradient: dW[kh][kw][c][co] = sum_p x4[p+(kh,kw)][c] * dy[p][co]
-// Tiny output (27 x 32), giant reduction (M pixels).  Thread = (co, tap-group);
-// the x value is a broadcast load, dy is coalesced over co.
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
-    const int co = threadIdx.x & 31, tg = threadIdx.x >> 5;  // 8 tap groups
-    // group tg handles flattened (tap, c) indices tg, tg+8, tg+16, tg+24 (< 27)
-    int toff[4], valid[4];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int f = tg + 8 * k;
-        valid[k] = f < 27;
-        const int tap = f / 3, c = f % 3;
-        const int kh = tap / 3, kw = tap % 3;
-        toff[k] = valid[k] ? ((kh * (a.W + 2) + kw) * 4 + c) : 0;
-    }
-    const size_t per_blk = ((size_t)a.M + gridDim.x - 1) / gridDim.x;
-    size_t p0 = (size_t)blockIdx.x * per_blk, p1 = p0 + per_blk;
-    if (p1 > (size_t)a.M) p1 = a.M;
-    const T* x4 = (const T*)a.x4;
-    const T* dy = (const T*)a.dy;
-    const int hw = a.H * a.W;
-    for (size_t p = p0; p < p1; ++p) {
-        const int n = (int)(p / hw), rem = (int)(p - (size_t)n * hw);
-        const int h = rem / a.W, ww = rem - h * a.W;
-        const size_t pix = (size_t)(n * (a.H + 2) + h) * (a.W + 2) + ww;  // top-left tap in x4
-        const size_t pixc = pix + (a.W + 2) + 1;                          // centre in dy
-        const float g = Elem<T>::to_f32(dy[pixc * 32 + co]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (valid[k]) acc[k] += Elem<T>::to_f32(x4[pix * 4 + toff[k]]) * g;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (valid[k]) atomicAdd(a.dW + (tg + 8 * k) * 32 + co, acc[k] * a.scale);
-}
-
-hipError_t launch_conv1_wgrad(int dtype, const Conv1WgradArgs& a, hipStream_t s) {
-    int nb = (a.M + 511) / 512;
-    if (nb > 4096) nb = 4096;
-    if (nb < 1) nb = 1;
-    dim3 g(nb), b(256);
-    switch (dtype) {
-        case 0: hipLaunchKernelGGL(conv1_wgrad_kernel<float>, g, b, 0, s, a); break;
-        case 1: hipLaunchKernelGGL(conv1_wgrad_kernel<half_t>, g, b, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(conv1_wgrad_kernel<bf16_t>, g, b, 0, s, a); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
 }  // namespace y2

@@ -1,0 +1,132 @@
+// First-layer weight gradient: dW[kh][kw][c][co] = sum_p x4[p (+) (kh,kw)][c] * dy[p][co]
+// (TF Conv2DBackpropFilter of the 3 -> 32 layer, darknet.py:150).
+// Output is tiny (27 x 32) and the reduction is over all N*H*W pixels, so the kernel is a
+// pure HBM stream of dy (64 B/pixel at f16) + x4 (8 B/pixel).  MI355X design:
+//   * persistent blocks walk whole image rows; per row the dy row and the three x4 rows
+//     are staged with global_load_lds (dy padded to 16 pixels with reads of its zero border)
+//   * D[(kh,kw,c)][co] on 32x32 MFMA with the PIXEL as k: both operands are read
+//     k-strided out of the row images with ds_read_b64_tr_b16; the 16 elements
+//     (kw*4+c) of one filter row are contiguous in x4, so the transposed read takes
+//     overlapping 32-byte windows of the x4 row image directly (no im2col)
+//   * accumulators live in registers across all rows of the block; one LDS reduction
+//     over the 4 waves and 864 float atomics per block at the end.
+#include "common.h"
+#include "kernels.h"
+
+namespace y2 {
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
+    constexpr int SZ = sizeof(T);
+    constexpr int DYP = 32 * SZ;   // bytes per dy pixel
+    constexpr int XP = 4 * SZ;     // bytes per x4 pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wp = (a.W + 15) & ~15;                  // pixels per row, padded to the MFMA k step
+    const int dy_bytes = Wp * DYP;
+    const int x_bytes = ((Wp + 4) * XP + 15) & ~15;   // one x4 row image (window of the last pixel included)
+    char* dy_l = smem;
+    char* x_l = smem + dy_bytes;
+    const int dy_chunks = dy_bytes / 16, x_chunks = x_bytes / 16;
+    const int rows = a.N * a.H;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+
+    f32x16 acc1, acc2;   // acc1: filter rows kh = 0 (MFMA rows 0..15) and 1 (16..31); acc2: kh = 2 (rows 0..15)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1[q] = acc2[q] = 0.f;
+
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int n = row / a.H, h = row - n * a.H;
+        const char* dyrow = (const char*)a.dy + ((size_t)(n * (a.H + 2) + h + 1) * (a.W + 2) + 1) * DYP;
+        const char* dyzero = dyrow - DYP;   // left border pixel: 32 zeros
+        const char* xrow = (const char*)a.x4 + ((size_t)(n * (a.H + 2) + h) * (a.W + 2)) * XP;
+        const size_t xpitch = (size_t)(a.W + 2) * XP;
+        __syncthreads();   // previous row fully consumed
+        for (int i0 = w * 64; i0 < dy_chunks; i0 += 256) {
+            const int i = i0 + lane;
+            if (i < dy_chunks) {
+                const int pix = (i * 16) / DYP;
+                const char* src = pix < a.W ? dyrow + (size_t)i * 16 : dyzero + (i * 16) % DYP;
+                glds16(src, dy_l + i0 * 16);
+            }
+        }
+        for (int kh = 0; kh < 3; ++kh)
+            for (int i0 = w * 64; i0 < x_chunks; i0 += 256) {
+                const int i = i0 + lane;
+                if (i < x_chunks) glds16(xrow + kh * xpitch + (size_t)i * 16, x_l + kh * x_bytes + i0 * 16);
+            }
+        __syncthreads();   // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
+        for (int s = w; s * 16 < a.W; s += 4) {
+            const int w0 = s * 16;
+            if constexpr (SZ == 2) {
+                const int pix = w0 + 8 * hh + qq;
+                const char* pb = dy_l + pix * DYP + (16 * g1 + 4 * pp) * 2;
+                typename Elem<T>::frag fb = tr_frag<T>(pb, pb + 4 * DYP);
+                const char* pa1 = x_l + g1 * x_bytes + (pix + pp) * XP;
+                typename Elem<T>::frag fa1 = tr_frag<T>(pa1, pa1 + 4 * XP);
+                const char* pa2 = x_l + 2 * x_bytes + (pix + pp) * XP;
+                typename Elem<T>::frag fa2 = tr_frag<T>(pa2, pa2 + 4 * XP);
+                mma32(acc1, fa1, fb);
+                mma32(acc2, fa2, fb);
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const int pix = w0 + 2 * k2 + hh;
+                    const float b = *(const float*)(dy_l + pix * DYP + r32 * 4);
+                    const float a1 = *(const float*)(x_l + (r32 >> 4) * x_bytes + pix * XP + (r32 & 15) * 4);
+                    const float a2 = *(const float*)(x_l + 2 * x_bytes + pix * XP + (r32 & 15) * 4);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b, acc2, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- reduce the 4 waves through LDS, then one atomic per (tap, c, co)
+    __syncthreads();
+    float* red = (float*)smem;   // [4 waves][48 rows][32 co]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = acc_row(q, hh);
+        red[(w * 48 + r) * 32 + r32] = acc1[q];
+        if (r < 16) red[(w * 48 + 32 + r) * 32 + r32] = acc2[q];
+    }
+    __syncthreads();
+    for (int i = tid; i < 48 * 32; i += 256) {
+        const int r = i >> 5, co = i & 31;
+        const int kh = r >> 4, e = r & 15, kw = e >> 2, c = e & 3;
+        if (kw < 3 && c < 3) {
+            const float v = red[i] + red[48 * 32 + i] + red[2 * 48 * 32 + i] + red[3 * 48 * 32 + i];
+            atomicAdd(a.dW + ((kh * 3 + kw) * 3 + c) * 32 + co, v * a.scale);
+        }
+    }
+}
+
+template <typename T>
+static hipError_t c1wg_T(const Conv1WgradArgs& a, hipStream_t s) {
+    constexpr int SZ = sizeof(T);
+    const int Wp = (a.W + 15) & ~15;
+    size_t lds = (size_t)Wp * 32 * SZ + 3 * (size_t)((((Wp + 4) * 4 * SZ) + 15) & ~15);
+    const size_t red = 4 * 48 * 32 * sizeof(float);
+    if (lds < red) lds = red;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto kern = conv1_wgrad_kernel<T>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int rows = a.N * a.H;
+    int nb = rows < 512 ? rows : 512;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv1_wgrad(int dtype, const Conv1WgradArgs& a, hipStream_t s) {
+    switch (dtype) {
+        case 0: return c1wg_T<float>(a, s);
+        case 1: return c1wg_T<half_t>(a, s);
+        case 2: return c1wg_T<bf16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace y2

@@ -45,17 +45,6 @@ Y2_DEV int wg_swz(int row) {
     return 0;
 }
 
-typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-template <typename T>
-Y2_DEV typename Elem<T>::frag tr_frag(const char* p0, const char* p1) {
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
-    s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(typename Elem<T>::frag, both);
-}
-
 template <typename T, int WI, int WO, int TI, int TO>
 __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
     typedef WgCfg<T, WI, WO, TI, TO> Cfg;
