@@ -1,0 +1,50 @@
+// Development-only entry points (not part of include/yolo2_hip.h): time one convolution
+// shape with a chosen kernel variant, on buffers allocated here.
+#include <stdio.h>
+#pragma clang diagnostic ignored "-Wunused-value"
+#include <vector>
+#include "kernels.h"
+
+namespace y2 {
+hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc);
+}
+using namespace y2;
+
+extern "C" int y2dev_bench_conv(int N, int H, int W, int Cin, int Cout, int k, int variant, int iters, float* ms_out) {
+    const size_t sz = 2;
+    const size_t xpix = (size_t)N * (H + 1) * (W + 1) + 4 * (W + 3) + 256;
+    const int taps = k * k;
+    const int cout_pad = (Cout + 255) / 256 * 256;
+    void *x = nullptr, *w = nullptr, *y = nullptr;
+    float* bias = nullptr;
+    if (hipMalloc(&x, xpix * Cin * sz) != hipSuccess) return -1;
+    if (hipMalloc(&w, (size_t)cout_pad * taps * Cin * sz) != hipSuccess) return -1;
+    if (hipMalloc(&y, (size_t)N * H * W * Cout * sz + 4096) != hipSuccess) return -1;
+    if (hipMalloc(&bias, Cout * 4) != hipSuccess) return -1;
+    // pseudo-random f16 contents (finite, sign-varying)
+    std::vector<unsigned short> hx(xpix * Cin), hw((size_t)cout_pad * taps * Cin);
+    unsigned int r = 12345;
+    for (auto& v : hx) { r = r * 1664525u + 1013904223u; v = (unsigned short)(((r >> 16) & 0x83FF) | 0x3800); }
+    for (auto& v : hw) { r = r * 1664525u + 1013904223u; v = (unsigned short)(((r >> 16) & 0x83FF) | 0x2C00); }
+    hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(bias, 0, Cout * 4);
+    ConvArgs a{};
+    a.x = (char*)x + (size_t)(W + 3) * Cin * sz; a.w = w; a.y = y; a.bias = bias;
+    a.N = N; a.H = H; a.W = W; a.C = Cin; a.M = N * H * W; a.Cout = Cout; a.ldy = Cout; a.taps = taps;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int bp, bc;
+    for (int i = 0; i < 3; ++i)
+        if (launch_conv_igemm_variant(variant, a, 0, &bp, &bc) != hipSuccess) return -2;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) launch_conv_igemm_variant(variant, a, 0, &bp, &bc);
+    hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) return -3;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+    hipFree(x); hipFree(w); hipFree(y); hipFree(bias);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
             Chunk<T> o;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(r[e]);
-            const size_t off = (((size_t)(n * (Ho + 2) + ho + 1) * (Wo + 2) + wo + 1) * a.C + c0) * sizeof(T);
+            const size_t off = (bpix(n, ho, wo, Ho, Wo) * a.C + c0) * sizeof(T);
             st_chunk<T>((char*)a.out + off, o);
         }
     }
@@ -326,8 +326,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                         }
                     }
                     if (APPLY) {
-                        const size_t off =
-                            (((size_t)(n * (a.H + 2) + hi + 1) * (a.W + 2) + wi + 1) * a.ldy + c0) * sizeof(T);
+                        const size_t off = (bpix(n, hi, wi, a.H, a.W) * a.ldy + c0) * sizeof(T);
                         st_chunk<T>((char*)a.dyp + off, o);
                     }
                 }
@@ -350,8 +349,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                     }
                 }
                 if (APPLY) {
-                    const size_t off =
-                        (((size_t)(n * (a.H + 2) + ho + 1) * (a.W + 2) + wo + 1) * a.ldy + c0) * sizeof(T);
+                    const size_t off = (bpix(n, ho, wo, a.H, a.W) * a.ldy + c0) * sizeof(T);
                     st_chunk<T>((char*)a.dyp + off, o);
                 }
             }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
 
     const int ntiles = (a.M + 31) / 32;
     const int nwaves = gridDim.x * 4;
-    const int rowpitch = (a.W + 2) * 4 * SZ;
+    const int rowpitch = (a.W + 1) * 4 * SZ;
     int my_cnt = 0;
     for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += nwaves) {
         const int p = tile * 32 + r32;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
             const int hw = a.H * a.W;
             const int n = p / hw, rem = p - n * hw;
             const int h = rem / a.W, ww = rem - h * a.W;
-            base = (uint32_t)((n * (a.H + 2) + h) * (a.W + 2) + ww) * (uint32_t)(4 * SZ);
+            base = (uint32_t)(bpix(n, h, ww, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(4 * SZ);
         }
         f32x16 acc;
 #pragma unroll

@@ -39,10 +39,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(Conv1WgradArgs a) {
 
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         const int n = row / a.H, h = row - n * a.H;
-        const char* dyrow = (const char*)a.dy + ((size_t)(n * (a.H + 2) + h + 1) * (a.W + 2) + 1) * DYP;
+        const char* dyrow = (const char*)a.dy + bpix(n, h, 0, a.H, a.W) * DYP;
         const char* dyzero = dyrow - DYP;   // left border pixel: 32 zeros
-        const char* xrow = (const char*)a.x4 + ((size_t)(n * (a.H + 2) + h) * (a.W + 2)) * XP;
-        const size_t xpitch = (size_t)(a.W + 2) * XP;
+        const char* xrow = (const char*)a.x4 + (bpix(n, h, 0, a.H, a.W) - (size_t)(a.W + 2)) * XP;
+        const size_t xpitch = (size_t)(a.W + 1) * XP;
         __syncthreads();   // previous row fully consumed
         for (int i0 = w * 64; i0 < dy_chunks; i0 += 256) {
             const int i = i0 + lane;

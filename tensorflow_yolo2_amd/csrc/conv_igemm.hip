@@ -23,10 +23,21 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef Y2_CONV_STAGES
+#define Y2_CONV_STAGES 3
+#endif
+
 namespace y2 {
 
-template <typename T, int WP, int WC, int TP, int TC, int BKB>
+template <int N>
+Y2_DEV void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NS = LDS stages of the global_load_lds pipeline (NS-1 K-steps in flight)
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS_>
 struct ConvCfg {
+    static constexpr int NS = NS_;
     static constexpr int NW = WP * WC;
     static constexpr int NT = NW * 64;
     static constexpr int BP = WP * TP * 32;  // pixels per block
@@ -45,15 +56,18 @@ struct ConvCfg {
     static constexpr int EROW = TC * 32 * SZ + 16;
     static constexpr int EPW = TP * 32 * EROW;
     static constexpr int ESTAT = NW * TC * 32 * 2 * 4;
-    static constexpr int LDS_MAIN = 2 * STAGE;
+    static constexpr int IPW_MIN = NI / NW;
+    static constexpr int LDS_MAIN = NS * STAGE;
     static constexpr int LDS_EPI = NW * EPW + ESTAT;
     static constexpr int LDS = LDS_MAIN > LDS_EPI ? LDS_MAIN : LDS_EPI;
     static_assert(NI_P % NW == 0, "pixel rows must split evenly over waves");
 };
 
-template <typename T, int WP, int WC, int TP, int TC, int BKB>
+// ABL: timing-only ablation bits (dev): 1 skip pixel-tile loads, 2 skip filter-tile loads,
+// 4 skip MFMAs, 8 skip LDS fragment reads.  0 in every product launch.
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0>
 __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
-    typedef ConvCfg<T, WP, WC, TP, TC, BKB> Cfg;
+    typedef ConvCfg<T, WP, WC, TP, TC, BKB, NS> Cfg;
     typedef typename Elem<T>::frag frag_t;
     constexpr int NW = Cfg::NW, BP = Cfg::BP, BC = Cfg::BC, SZ = Cfg::SZ;
     constexpr int LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB, IPW = Cfg::IPW, KG = Cfg::KG;
@@ -84,7 +98,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
                 const int hw = a.H * a.W;
                 const int n = p / hw, rem = p - n * hw;
                 const int h = rem / a.W, ww = rem - h * a.W;
-                base = (uint32_t)((n * (a.H + 2) + h) * (a.W + 2) + ww) * (uint32_t)(a.C * SZ);
+                // top-left tap of the 3x3 window (bordered layout, common.h)
+                base = (uint32_t)(bpix(n, h, ww, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(a.C * SZ);
             }
             voff[i] = base + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
         } else {
@@ -94,7 +109,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     }
     const int cpt = (a.C * SZ) / BKB;  // k-chunks per tap
     const int nK = a.taps * cpt;
-    const int rowpitch = (a.W + 2) * a.C * SZ;
+    const int rowpitch = (a.W + 1) * a.C * SZ;
 
     auto stage = [&](int kk, int buf) {
         const int t = kk / cpt, c = kk - t * cpt;
@@ -112,9 +127,9 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
         for (int i = 0; i < IPW; ++i) {
             const int ii = i * NW + w;
             if (i * NW < Cfg::NI_P) {
-                glds16(xs + voff[i], lbase + ii * 1024);
+                if (!(ABL & 1)) glds16(xs + voff[i], lbase + ii * 1024);
             } else if ((i + 1) * NW <= Cfg::NI || ii < Cfg::NI) {
-                glds16(ws + voff[i], lbase + ii * 1024);
+                if (!(ABL & 2)) glds16(ws + voff[i], lbase + ii * 1024);
             }
         }
     };
@@ -135,26 +150,56 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    stage(0, 0);
-    __syncthreads();  // hipcc drains vmcnt(0) before the barrier
+    // ---- software pipeline: NS-1 K-steps of LDS-DMA stay in flight ACROSS the barrier.
+    // Raw s_barrier + counted vmcnt (a __syncthreads() would drain vmcnt(0) every step).
+    //   iteration kk:  wait until stage kk has landed (this wave's part)  -> barrier (everyone's
+    //   part landed AND everyone finished reading stage kk-1) -> refill the buffer stage kk-1
+    //   used with stage kk+NS-1 -> MFMAs on stage kk.
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nK) stage(s0, s0);
+    int cbuf = 0, ibuf = NS - 1;
     for (int kk = 0; kk < nK; ++kk) {
-        const int buf = kk & 1;
-        if (kk + 1 < nK) stage(kk + 1, buf ^ 1);
-        const char* lb = smem + buf * Cfg::STAGE;
+        if (kk + NS - 2 < nK) wait_vmcnt<(NS - 2) * Cfg::IPW_MIN>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kk + NS - 1 < nK) stage(kk + NS - 1, ibuf);
+        const char* lb = smem + cbuf * Cfg::STAGE;
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             frag_t fc[TC], fp[TP];
+            if (ABL & 8) {
 #pragma unroll
-            for (int i = 0; i < TC; ++i) fc[i] = *(const frag_t*)(lb + cbase + i * 32 * BKB + foff[g]);
+                for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int j = 0; j < TP; ++j) fp[j] = *(const frag_t*)(lb + pbase + j * 32 * BKB + foff[g]);
+                    for (int e = 0; e < Elem<T>::kPerFrag; ++e) fc[i][e] = (T)(float)(kk + e);
 #pragma unroll
-            for (int i = 0; i < TC; ++i)
+                for (int j = 0; j < TP; ++j)
 #pragma unroll
-                for (int j = 0; j < TP; ++j) mma32(acc[i][j], fc[i], fp[j]);
+                    for (int e = 0; e < Elem<T>::kPerFrag; ++e) fp[j][e] = (T)(float)(kk - e);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) fc[i] = *(const frag_t*)(lb + cbase + i * 32 * BKB + foff[g]);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) fp[j] = *(const frag_t*)(lb + pbase + j * 32 * BKB + foff[g]);
+            }
+            if (ABL & 4) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) asm volatile("" ::"v"(fc[i]));
+#pragma unroll
+                for (int j = 0; j < TP; ++j) asm volatile("" ::"v"(fp[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) mma32(acc[i][j], fc[i], fp[j]);
+            }
         }
-        __syncthreads();
+        cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
+        ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
     }
+    __syncthreads();
 
     // ---------------------------------------------------------------- epilogue
     constexpr int EROW = Cfg::EROW;
@@ -272,10 +317,11 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     }
 }
 
-template <typename T, int WP, int WC, int TP, int TC, int BKB>
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
-    typedef ConvCfg<T, WP, WC, TP, TC, BKB> Cfg;
-    auto kern = conv_igemm_kernel<T, WP, WC, TP, TC, BKB>;
+    typedef ConvCfg<T, WP, WC, TP, TC, BKB, NS> Cfg;
+    static_assert(Cfg::LDS <= 160 * 1024, "LDS budget");
+    auto kern = conv_igemm_kernel<T, WP, WC, TP, TC, BKB, NS, ABL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -294,12 +340,13 @@ static hipError_t launch_T(const ConvArgs& a, hipStream_t s) {
     const int kb = a.C * (int)sizeof(T);  // bytes per tap per pixel
     const bool k128 = (kb % 128) == 0;
     if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
+    constexpr int NSA = Y2_CONV_STAGES;
     if (a.Cout > 64) {
-        return k128 ? launch_cfg<T, 2, 2, 2, 2, 128>(a, s) : launch_cfg<T, 2, 2, 2, 2, 64>(a, s);
+        return k128 ? launch_cfg<T, 2, 2, 2, 2, 128, NSA>(a, s) : launch_cfg<T, 2, 2, 2, 2, 64, NSA>(a, s);
     } else if (a.Cout > 32) {
-        return k128 ? launch_cfg<T, 4, 1, 2, 2, 128>(a, s) : launch_cfg<T, 4, 1, 2, 2, 64>(a, s);
+        return k128 ? launch_cfg<T, 4, 1, 2, 2, 128, 3>(a, s) : launch_cfg<T, 4, 1, 2, 2, 64, 3>(a, s);
     } else {
-        return k128 ? launch_cfg<T, 4, 1, 2, 1, 128>(a, s) : launch_cfg<T, 4, 1, 2, 1, 64>(a, s);
+        return k128 ? launch_cfg<T, 4, 1, 2, 1, 128, 3>(a, s) : launch_cfg<T, 4, 1, 2, 1, 64, 3>(a, s);
     }
 }
 
@@ -315,4 +362,33 @@ hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+}  // namespace y2
+
+// ---------------------------------------------------------------------------
+// development aid: explicit tile / pipeline variants (f16 only) for A/B timing
+// ---------------------------------------------------------------------------
+namespace y2 {
+hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc) {
+    typedef half_t T;
+    switch (variant) {
+        case 0: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2>(a, s);
+        case 1: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 3>(a, s);
+        case 2: *bp = 256; *bc = 128; return launch_cfg<T, 4, 2, 2, 2, 128, 3>(a, s);
+        case 3: *bp = 256; *bc = 128; return launch_cfg<T, 4, 2, 2, 2, 128, 2>(a, s);
+        case 4: *bp = 128; *bc = 128; return launch_cfg<T, 2, 4, 2, 1, 128, 2>(a, s);
+        case 5: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 4>(a, s);
+        case 6: *bp = 128; *bc = 256; return launch_cfg<T, 2, 4, 2, 2, 128, 3>(a, s);
+        case 7: *bp = 128; *bc = 128; return launch_cfg<T, 2, 4, 2, 1, 128, 3>(a, s);
+        case 8: *bp = 256; *bc = 256; return launch_cfg<T, 4, 2, 2, 4, 128, 2>(a, s);
+        // ablations of variant 0
+        case 10: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 1>(a, s);
+        case 11: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 2>(a, s);
+        case 12: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 3>(a, s);
+        case 13: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 4>(a, s);
+        case 14: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 8>(a, s);
+        case 15: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 11>(a, s);
+        case 16: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 12>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
 }  // namespace y2

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/yolo2_hip.h"
+#include "common.h"
 #include "kernels.h"
 
 using namespace y2;
@@ -47,8 +48,8 @@ constexpr float kBnMomentum = 0.99f;
 struct PadGeom {
     int N, H, W, C;
     size_t front_px() const { return (size_t)W + 3; }
-    size_t body_px() const { return (size_t)N * (H + 2) * (W + 2); }
-    size_t back_px() const { return (size_t)W + 3 + 256; }
+    size_t body_px() const { return bbody_pixels(N, H, W); }
+    size_t back_px() const { return (size_t)2 * W + 6 + 256; }
     size_t bytes(size_t sz) const { return align_up((front_px() + body_px() + back_px()) * C * sz + 64, 256); }
     size_t base_off(size_t sz) const { return front_px() * C * sz; }
 };

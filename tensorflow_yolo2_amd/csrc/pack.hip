@@ -15,7 +15,7 @@ __global__ void pack_input_kernel(const float* __restrict__ img, T* __restrict__
         const int h = (int)((p / W) % H);
         const int n = (int)(p / ((size_t)W * H));
         const float* s = img + p * 3;
-        T* d = x4 + (((size_t)(n * (H + 2) + h + 1) * (W + 2)) + w + 1) * 4;
+        T* d = x4 + bpix(n, h, w, H, W) * 4;
         d[0] = Elem<T>::from_f32(s[0]);
         d[1] = Elem<T>::from_f32(s[1]);
         d[2] = Elem<T>::from_f32(s[2]);
@@ -51,7 +51,7 @@ __global__ void act_pack_kernel(const float* in, T* xp, float* out, int N, int H
         const int w = (int)(p % W);
         const int h = (int)((p / W) % H);
         const int n = (int)(p / ((size_t)W * H));
-        const size_t po = (((size_t)(n * (H + 2) + h + 1) * (W + 2)) + w + 1) * Cs + c;
+        const size_t po = bpix(n, h, w, H, W) * Cs + c;
         if (PACK) xp[po] = Elem<T>::from_f32(c < C ? in[p * C + c] : 0.f);
         else out[i] = Elem<T>::to_f32(xp[po]);
     }

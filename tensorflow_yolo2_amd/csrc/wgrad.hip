@@ -63,7 +63,7 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
     const int split = b / a.taps;
     const int ci0 = it * BI, co0 = ot * BO;
 
-    const long Mp = (long)a.N * (a.H + 2) * (a.W + 2);
+    const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
     const long ksteps = (Mp + BKP - 1) / BKP;
     const long spb = (ksteps + a.splitk - 1) / a.splitk;
     const long s_begin = (long)split * spb;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
     int toff;  // tap shift in pixels relative to the centre
     if (a.taps == 9) {
         const int kh = tap / 3, kw = tap - kh * 3;
-        toff = (kh - 1) * (a.W + 2) + (kw - 1);
+        toff = (kh - 1) * (a.W + 1) + (kw - 1);
     } else {
         toff = 0;
     }
@@ -194,7 +194,7 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s) {
         attr_set = true;
     }
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
-    const long Mp = (long)a.N * (a.H + 2) * (a.W + 2);
+    const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
     const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
     const int tiles = a.taps * nIT * nOT;
     if (a.splitk <= 0) {
