@@ -7,12 +7,18 @@
 
 namespace y2 {
 hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc);
+hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s);
+static hipError_t run_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc) {
+    if (variant >= 20 && a.taps == 9) return launch_conv_halo_variant(variant, a, s);
+    if (variant >= 20) variant = 0;
+    return launch_conv_igemm_variant(variant, a, s, bp, bc);
+}
 }
 using namespace y2;
 
 extern "C" int y2dev_bench_conv(int N, int H, int W, int Cin, int Cout, int k, int variant, int iters, float* ms_out) {
     const size_t sz = 2;
-    const size_t xpix = (size_t)N * (H + 1) * (W + 1) + 4 * (W + 3) + 256;
+    const size_t xpix = (size_t)N * (H + 1) * (W + 1) + 4 * (W + 3) + 2048;
     const int taps = k * k;
     const int cout_pad = (Cout + 255) / 256 * 256;
     void *x = nullptr, *w = nullptr, *y = nullptr;
@@ -36,9 +42,9 @@ extern "C" int y2dev_bench_conv(int N, int H, int W, int Cin, int Cout, int k, i
     hipEventCreate(&e0); hipEventCreate(&e1);
     int bp, bc;
     for (int i = 0; i < 3; ++i)
-        if (launch_conv_igemm_variant(variant, a, 0, &bp, &bc) != hipSuccess) return -2;
+        if (run_variant(variant, a, 0, &bp, &bc) != hipSuccess) return -2;
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) launch_conv_igemm_variant(variant, a, 0, &bp, &bc);
+    for (int i = 0; i < iters; ++i) run_variant(variant, a, 0, &bp, &bc);
     hipEventRecord(e1, 0);
     if (hipEventSynchronize(e1) != hipSuccess) return -3;
     float ms = 0.f;

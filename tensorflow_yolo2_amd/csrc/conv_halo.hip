@@ -1,0 +1,317 @@
+// 3x3 stride-1 SAME convolution as an im2col-free implicit GEMM with an LDS-resident
+// HALO tile (gfx950).  Replaces tf.nn.conv2d(..., 'SAME') + bias for filter_size 3
+// (reference src/yolo2_nets/darknet.py:20-21,32-36) and its dgrad.
+//
+// Why: in the per-tap implicit GEMM every one of the 9 taps re-stages the (shifted)
+// pixel tile -- measured on MI355X those strided 128-byte row gathers, not the MFMAs,
+// set the kernel time.  Here the block stages ONE contiguous range of the bordered
+// pixel space per K-chunk: all interior pixels of the tile plus one row/column of halo
+// (the shared-border layout of common.h makes that range contiguous), and the nine
+// taps are nine row-shifted views of that single LDS image:
+//     LDS row of (pixel p, tap kh,kw) = arow_tl(p) + kh*pitch + kw.
+// Pixel-side global->LDS traffic drops by ~6x at 13x13 (9 taps x 128 rows -> 184 rows),
+// and the L2 sees long contiguous reads instead of per-tap gathers.  Only the filter
+// tile streams per (tap, chunk) step, through an NSB-deep global_load_lds ring with a
+// counted vmcnt and raw s_barrier (loads stay in flight across the barrier).
+#include "common.h"
+#include "conv_epilogue.h"
+#include "kernels.h"
+
+namespace y2 {
+
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NSB, bool ADB>
+struct HaloCfg {
+    static constexpr int NW = WP * WC, NT = NW * 64;
+    static constexpr int BP = WP * TP * 32, BC = WC * TC * 32;
+    static constexpr int SZ = sizeof(T);
+    static constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB;
+    static constexpr int NI_C = BC / RPI;
+    static constexpr int IPWB = (NI_C + NW - 1) / NW;
+    static constexpr int IPW_MIN = NI_C / NW;
+    static constexpr int BSTAGE = BC * BKB;
+    static constexpr int KG = BKB / 32;
+    static constexpr int NA = ADB ? 2 : 1;
+};
+
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NSB, bool ADB, int ABL = 0>
+__global__ __launch_bounds__(WP* WC * 64) void conv_halo_kernel(ConvArgs a, int arows) {
+    typedef HaloCfg<T, WP, WC, TP, TC, BKB, NSB, ADB> Cfg;
+    typedef typename Elem<T>::frag frag_t;
+    constexpr int NW = Cfg::NW, BP = Cfg::BP, BC = Cfg::BC, SZ = Cfg::SZ;
+    constexpr int LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB, KG = Cfg::KG, IPWB = Cfg::IPWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w / WC, wc = w % WC;
+    const int nCT = (a.Cout + BC - 1) / BC;
+    const int ct = blockIdx.x % nCT, pt = blockIdx.x / nCT;
+    const int m0 = pt * BP, n0 = ct * BC;
+    const int pitch = a.W + 1, hw = a.H * a.W;
+    const int Ktot = 9 * a.C;
+    const char* __restrict__ xg = (const char*)a.x;
+    const char* __restrict__ wg = (const char*)a.w;
+
+    auto bpos = [&](int p) -> long {  // bordered position of interior pixel p (linear n,h,w index)
+        const int n = p / hw, rem = p - n * hw;
+        const int h = rem / a.W, ww = rem - h * a.W;
+        return (long)bpix(n, h, ww, a.H, a.W);
+    };
+    // the A image covers bordered positions [lo, lo + nrows): top-left tap of the first pixel
+    // ... bottom-right tap of the last pixel
+    const int p_last = (m0 + BP - 1 < a.M) ? m0 + BP - 1 : a.M - 1;
+    const long lo = bpos(m0) - pitch - 1;
+    const int nrows = (int)(bpos(p_last) + pitch + 1 - lo) + 1;
+    const int npieces = (nrows + RPI - 1) / RPI;
+    const int abytes = arows * BKB;
+    char* const bbase = smem + Cfg::NA * abytes;
+
+    const int lrow = lane / LPR, lslot = lane % LPR;
+    const int rowbytes = a.C * SZ;
+    auto issueA = [&](int c, int ab) {
+        const char* xs = xg + lo * (long)rowbytes + (long)c * BKB;
+        char* dst = smem + ab * abytes;
+        for (int i = w; i < npieces; i += NW) {
+            const int row = i * RPI + lrow;
+            const uint32_t off = (uint32_t)row * (uint32_t)rowbytes + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+            if (!(ABL & 1)) glds16(xs + off, dst + i * 1024);
+        }
+    };
+    uint32_t voffB[IPWB];
+#pragma unroll
+    for (int i = 0; i < IPWB; ++i) {
+        const int r = (i * NW + w) * RPI + lrow;
+        voffB[i] = (uint32_t)(n0 + r) * (uint32_t)(Ktot * SZ) + (uint32_t)((lslot ^ ((r / RPB) % LPR)) * 16);
+    }
+    auto issueB = [&](int c, int t, int buf) {
+        const char* ws = wg + (size_t)(t * rowbytes + c * BKB);
+        char* dst = bbase + buf * Cfg::BSTAGE;
+#pragma unroll
+        for (int i = 0; i < IPWB; ++i) {
+            const int ii = i * NW + w;
+            if (!(ABL & 2) && ((i + 1) * NW <= Cfg::NI_C || ii < Cfg::NI_C)) glds16(ws + voffB[i], dst + ii * 1024);
+        }
+    };
+
+    // fragment addressing
+    const int r32 = lane & 31, hh = lane >> 5;
+    int arow_tl[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        int p = m0 + (wp * TP + j) * 32 + r32;
+        if (p > a.M - 1) p = a.M - 1;
+        arow_tl[j] = (int)(bpos(p) - pitch - 1 - lo);
+    }
+    int foffB[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) foffB[g] = r32 * BKB + (((2 * g + hh) ^ ((r32 / RPB) % LPR)) * 16);
+    const int cbase = (wc * TC) * 32 * BKB;
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int nchunks = rowbytes / BKB;
+    const int steps = nchunks * 9;
+    // prologue: A(0) first (oldest), then NSB-1 filter stages
+    issueA(0, 0);
+    {
+        int c0 = 0, t0 = 0;
+#pragma unroll
+        for (int s0 = 0; s0 < NSB - 1; ++s0) {
+            if (s0 < steps) issueB(c0, t0, s0);
+            if (++t0 == 9) { t0 = 0; ++c0; }
+        }
+    }
+    int c = 0, t = 0, kh = 0, kw = 0;          // current step
+    int ci = 0, ti = NSB - 1;                  // step being issued (NSB-1 ahead)
+    while (ti >= 9) { ti -= 9; ++ci; }
+    int bbuf = 0, ibuf = NSB - 1;
+    for (int s = 0; s < steps; ++s) {
+        if (s + NSB - 2 < steps) wait_vmcnt<(NSB - 2) * Cfg::IPW_MIN>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NSB - 1 < steps) issueB(ci, ti, ibuf);
+        if (t == 0) {
+            if (ADB) {
+                if (c + 1 < nchunks) issueA(c + 1, (c + 1) & 1);
+            } else if (c > 0) {
+                issueA(c, 0);          // single image: everyone is past the barrier, the old one is dead
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+        const char* ab = smem + (ADB ? (c & 1) : 0) * abytes;
+        const char* bb = bbase + bbuf * Cfg::BSTAGE;
+        const int shift = kh * pitch + kw;
+        int aoff[TP], asw[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int row = arow_tl[j] + shift;
+            aoff[j] = row * BKB;
+            asw[j] = (row / RPB) % LPR;
+        }
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            frag_t fc[TC], fp[TP];
+            if (ABL & 8) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int e = 0; e < Elem<T>::kPerFrag; ++e) fc[i][e] = (T)(float)(s + e);
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int e = 0; e < Elem<T>::kPerFrag; ++e) fp[j][e] = (T)(float)(s - e + aoff[j]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) fc[i] = *(const frag_t*)(bb + cbase + i * 32 * BKB + foffB[g]);
+#pragma unroll
+                for (int j = 0; j < TP; ++j) fp[j] = *(const frag_t*)(ab + aoff[j] + (((2 * g + hh) ^ asw[j]) * 16));
+            }
+            if (ABL & 4) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) asm volatile("" ::"v"(fc[i]));
+#pragma unroll
+                for (int j = 0; j < TP; ++j) asm volatile("" ::"v"(fp[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) mma32(acc[i][j], fc[i], fp[j]);
+            }
+        }
+        // advance
+        if (++kw == 3) { kw = 0; ++kh; }
+        if (++t == 9) { t = 0; kh = 0; ++c; }
+        if (++ti == 9) { ti = 0; ++ci; }
+        bbuf = (bbuf + 1 == NSB) ? 0 : bbuf + 1;
+        ibuf = (ibuf + 1 == NSB) ? 0 : ibuf + 1;
+    }
+    __syncthreads();
+    if (ABL & 16) {   // skip the epilogue (keep the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) t += acc[i][j][0] + acc[i][j][7];
+        if (t == 123.456f) ((float*)a.y)[0] = t;
+        return;
+    }
+    conv_epilogue<T, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
+}
+
+// worst-case rows of the A image over all tiles of the launch
+static int halo_rows(int H, int W, int BP, int RPI) {
+    const int pitch = W + 1;
+    const int rows_cross = (BP - 1) / W + 1;
+    const int img_cross = (BP - 1) / (H * W) + 1;
+    const int span = (BP - 1) + rows_cross + img_cross * pitch;
+    const int nrows = span + 2 * (pitch + 1) + 1;
+    return (nrows + RPI - 1) / RPI * RPI;
+}
+
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NSB, bool ADB, int ABL = 0>
+static hipError_t halo_launch(const ConvArgs& a, hipStream_t s) {
+    typedef HaloCfg<T, WP, WC, TP, TC, BKB, NSB, ADB> Cfg;
+    typedef EpiCfg<T, WP, WC, TP, TC> Epi;
+    const int arows = halo_rows(a.H, a.W, Cfg::BP, Cfg::RPI);
+    size_t lds = (size_t)Cfg::NA * arows * BKB + (size_t)NSB * Cfg::BSTAGE;
+    if (lds < (size_t)Epi::LDS) lds = Epi::LDS;
+    if (lds > 160 * 1024) return hipErrorOutOfMemory;
+    auto kern = conv_halo_kernel<T, WP, WC, TP, TC, BKB, NSB, ADB, ABL>;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = lds;
+    }
+    const int nPT = (a.M + Cfg::BP - 1) / Cfg::BP;
+    const int nCT = (a.Cout + Cfg::BC - 1) / Cfg::BC;
+    hipLaunchKernelGGL(kern, dim3(nPT * nCT), dim3(Cfg::NT), lds, s, a, arows);
+    return hipGetLastError();
+}
+
+// double-buffer the A image when there is more than one K-chunk and LDS allows it
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NSB, int ABL = 0>
+static hipError_t halo_pick(const ConvArgs& a, hipStream_t s) {
+    typedef HaloCfg<T, WP, WC, TP, TC, BKB, NSB, true> Cfg;
+    const int nchunks = a.C * (int)sizeof(T) / BKB;
+    const size_t arows = halo_rows(a.H, a.W, Cfg::BP, Cfg::RPI);
+    const size_t lds2 = 2 * arows * BKB + (size_t)NSB * Cfg::BSTAGE;
+    if (nchunks > 1 && lds2 <= 150 * 1024) return halo_launch<T, WP, WC, TP, TC, BKB, NSB, true, ABL>(a, s);
+    return halo_launch<T, WP, WC, TP, TC, BKB, NSB, false, ABL>(a, s);
+}
+
+template <typename T>
+static hipError_t halo_T(const ConvArgs& a, hipStream_t s) {
+    const int kb = a.C * (int)sizeof(T);
+    const bool k128 = (kb % 128) == 0;
+    if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
+    if (a.Cout > 64) {
+        // 64-byte K chunks: image + ring fit 3 blocks per CU (measured best at 13x13 / 26x26)
+        return halo_pick<T, 2, 2, 2, 2, 64, 2>(a, s);
+    } else if (a.Cout > 32) {
+        return k128 ? halo_pick<T, 4, 1, 2, 2, 128, 3>(a, s) : halo_pick<T, 4, 1, 2, 2, 64, 3>(a, s);
+    } else {
+        return k128 ? halo_pick<T, 4, 1, 2, 1, 128, 3>(a, s) : halo_pick<T, 4, 1, 2, 1, 64, 3>(a, s);
+    }
+}
+
+hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (a.taps != 9) return hipErrorInvalidValue;
+    switch (dtype) {
+        case 0: return halo_T<float>(a, s);
+        case 1: return halo_T<half_t>(a, s);
+        case 2: return halo_T<bf16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// Kernel policy (measured on MI355X, scripts/bench_conv.py): the halo image wins where the
+// image rows are short (13x13, 26x26: the nine taps share ~85 % of their rows); on the large
+// feature maps the image would take a whole CU's LDS, and the per-tap kernel with 8 waves wins.
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
+    if (a.taps == 9 && a.W <= 26) return launch_conv_halo(dtype, a, s);
+    return launch_conv_igemm(dtype, a, s);
+}
+
+// development variants (f16) for scripts/bench_conv.py
+hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s) {
+    typedef half_t T;
+    switch (variant) {
+        case 20: return halo_pick<T, 2, 2, 2, 2, 128, 3>(a, s);
+        case 21: return halo_pick<T, 2, 2, 2, 2, 128, 2>(a, s);
+        case 22: return halo_pick<T, 2, 4, 2, 1, 128, 3>(a, s);
+        case 23: return halo_pick<T, 2, 4, 2, 1, 128, 2>(a, s);
+        case 24: return halo_pick<T, 4, 2, 2, 2, 128, 3>(a, s);
+        case 25: return halo_pick<T, 2, 4, 2, 2, 128, 3>(a, s);
+        case 26: return halo_pick<T, 2, 4, 2, 2, 128, 2>(a, s);
+        case 27: return halo_pick<T, 2, 2, 2, 2, 128, 4>(a, s);
+        case 28: return halo_pick<T, 2, 2, 2, 2, 64, 3>(a, s);
+        case 29: return halo_pick<T, 2, 2, 2, 2, 64, 2>(a, s);
+        case 40: return halo_pick<T, 2, 2, 2, 2, 64, 4>(a, s);
+        case 41: return halo_pick<T, 2, 4, 2, 1, 64, 3>(a, s);
+        case 42: return halo_pick<T, 4, 1, 1, 4, 128, 2>(a, s);   // wave = 32 px x 128 co
+        case 43: return halo_pick<T, 1, 4, 4, 1, 128, 2>(a, s);   // wave = 128 px x 32 co
+        // ablations of variant 24 (256x128, 8 waves, NSB 3)
+        case 30: return halo_pick<T, 4, 2, 2, 2, 128, 3, 3>(a, s);    // no loads
+        case 31: return halo_pick<T, 4, 2, 2, 2, 128, 3, 4>(a, s);    // no MFMA
+        case 32: return halo_pick<T, 4, 2, 2, 2, 128, 3, 8>(a, s);    // no LDS reads
+        case 33: return halo_pick<T, 4, 2, 2, 2, 128, 3, 16>(a, s);   // no epilogue
+        case 34: return halo_pick<T, 4, 2, 2, 2, 128, 3, 11>(a, s);   // MFMA only
+        case 35: return halo_pick<T, 4, 2, 2, 2, 128, 3, 27>(a, s);   // MFMA only, no epilogue
+        case 36: return halo_pick<T, 4, 2, 2, 2, 128, 3, 12>(a, s);   // loads only
+        case 37: return halo_pick<T, 4, 2, 2, 2, 128, 3, 1>(a, s);    // no A loads
+        case 38: return halo_pick<T, 4, 2, 2, 2, 128, 3, 2>(a, s);    // no B loads
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace y2

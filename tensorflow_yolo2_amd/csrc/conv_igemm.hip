@@ -21,6 +21,7 @@
 // on the per-lane SOURCE address and on the ds_read (LDS image stays linear,
 // cdna guide rule 21), conflict-free for ds_read_b128.
 #include "common.h"
+#include "conv_epilogue.h"
 #include "kernels.h"
 
 #ifndef Y2_CONV_STAGES
@@ -28,11 +29,6 @@
 #endif
 
 namespace y2 {
-
-template <int N>
-Y2_DEV void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // NS = LDS stages of the global_load_lds pipeline (NS-1 K-steps in flight)
 template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS_>
@@ -201,120 +197,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     }
     __syncthreads();
 
-    // ---------------------------------------------------------------- epilogue
-    constexpr int EROW = Cfg::EROW;
-    char* ew = smem + w * Cfg::EPW;
-    const int cw0 = n0 + wc * TC * 32;  // first cout of this wave
-#pragma unroll
-    for (int i = 0; i < TC; ++i) {
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const int cl = i * 32 + 8 * q4 + 4 * hh;  // local cout of register 4*q4
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) b4[j] = (cw0 + cl + j < a.Cout) ? a.bias[cw0 + cl + j] : 0.f;
-            }
-#pragma unroll
-            for (int j2 = 0; j2 < TP; ++j2) {
-                T o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = Elem<T>::from_f32(acc[i][j2][4 * q4 + j] + b4[j]);
-                char* dst = ew + (j2 * 32 + r32) * EROW + cl * SZ;
-                if (SZ == 2) *(u32x2*)dst = *(const u32x2*)o;
-                else *(u32x4*)dst = *(const u32x4*)o;
-            }
-        }
-    }
-    __syncthreads();
-
-    constexpr int EPC = 16 / SZ;                 // elements per chunk
-    constexpr int CPR = TC * 32 / EPC;           // chunks per pixel row
-    constexpr int RPIe = 64 / CPR;               // pixel rows per read instruction
-    constexpr int NIT = TP * 32 / RPIe;
-    const int ch = lane % CPR, prow0 = lane / CPR;
-    const int mw0 = m0 + wp * TP * 32;           // first pixel of this wave
-    const int cch = cw0 + ch * EPC;              // first cout of this lane's chunk
-    float vals[NIT][EPC];
-    float s[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int prow = it * RPIe + prow0;
-        Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
-        const bool pv = (mw0 + prow) < a.M;
-        if (pv && cch < a.ldy) st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            vals[it][e] = pv ? Elem<T>::to_f32(c.v[e]) : 0.f;
-            s[e] += vals[it][e];
-        }
-    }
-    if (a.part_mean) {
-        int cntw = a.M - mw0;
-        cntw = cntw < 0 ? 0 : (cntw > TP * 32 ? TP * 32 : cntw);
-        const float inv = cntw > 0 ? 1.0f / (float)cntw : 0.f;
-        float mean[EPC], m2[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-#pragma unroll
-            for (int msk = CPR; msk < 64; msk <<= 1) s[e] = wave_sum_xor(s[e], msk);
-            mean[e] = s[e] * inv;
-            m2[e] = 0.f;
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const bool pv = (mw0 + it * RPIe + prow0) < a.M;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float d = pv ? vals[it][e] - mean[e] : 0.f;
-                m2[e] += d * d;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPC; ++e)
-#pragma unroll
-            for (int msk = CPR; msk < 64; msk <<= 1) m2[e] = wave_sum_xor(m2[e], msk);
-        // combine the WP waves that share these channels (Chan's parallel update)
-        float* st = (float*)(smem + NW * Cfg::EPW);
-        if (prow0 == 0) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                st[(w * TC * 32 + ch * EPC + e) * 2 + 0] = mean[e];
-                st[(w * TC * 32 + ch * EPC + e) * 2 + 1] = m2[e];
-            }
-        }
-        __syncthreads();
-        if (wp == 0 && prow0 == 0) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                float n_acc = 0.f, mean_acc = 0.f, m2_acc = 0.f;
-                for (int k = 0; k < WP; ++k) {
-                    int cntk = a.M - (m0 + k * TP * 32);
-                    cntk = cntk < 0 ? 0 : (cntk > TP * 32 ? TP * 32 : cntk);
-                    if (cntk == 0) continue;
-                    const int wk = k * WC + wc;
-                    const float mk = st[(wk * TC * 32 + ch * EPC + e) * 2 + 0];
-                    const float vk = st[(wk * TC * 32 + ch * EPC + e) * 2 + 1];
-                    const float nn = n_acc + (float)cntk;
-                    const float dlt = mk - mean_acc;
-                    mean_acc += dlt * ((float)cntk / nn);
-                    m2_acc += vk + dlt * dlt * (n_acc * (float)cntk / nn);
-                    n_acc = nn;
-                }
-                const int co = cch + e;
-                if (co < a.ldy) {
-                    a.part_mean[(size_t)pt * a.ldy + co] = mean_acc;
-                    a.part_m2[(size_t)pt * a.ldy + co] = m2_acc;
-                }
-            }
-        }
-        if (tid == 0 && ct == 0) {
-            int cb = a.M - m0;
-            a.part_cnt[pt] = (float)(cb > BP ? BP : cb);
-        }
-    }
+    conv_epilogue<T, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
 }
 
 template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0>
@@ -340,13 +223,14 @@ static hipError_t launch_T(const ConvArgs& a, hipStream_t s) {
     const int kb = a.C * (int)sizeof(T);  // bytes per tap per pixel
     const bool k128 = (kb % 128) == 0;
     if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
-    constexpr int NSA = Y2_CONV_STAGES;
+    // 2 LDS stages and two blocks per CU beat deeper rings here (global->LDS fill rate, not
+    // latency, bounds this kernel); 8 waves of 64x32 beat 4 waves of 64x64 by ~5-8 %
     if (a.Cout > 64) {
-        return k128 ? launch_cfg<T, 2, 2, 2, 2, 128, NSA>(a, s) : launch_cfg<T, 2, 2, 2, 2, 64, NSA>(a, s);
+        return k128 ? launch_cfg<T, 2, 4, 2, 1, 128, 2>(a, s) : launch_cfg<T, 2, 4, 2, 1, 64, 2>(a, s);
     } else if (a.Cout > 32) {
-        return k128 ? launch_cfg<T, 4, 1, 2, 2, 128, 3>(a, s) : launch_cfg<T, 4, 1, 2, 2, 64, 3>(a, s);
+        return k128 ? launch_cfg<T, 4, 1, 2, 2, 128, 2>(a, s) : launch_cfg<T, 4, 1, 2, 2, 64, 2>(a, s);
     } else {
-        return k128 ? launch_cfg<T, 4, 1, 2, 1, 128, 3>(a, s) : launch_cfg<T, 4, 1, 2, 1, 64, 3>(a, s);
+        return k128 ? launch_cfg<T, 4, 1, 2, 1, 128, 2>(a, s) : launch_cfg<T, 4, 1, 2, 1, 64, 2>(a, s);
     }
 }
 

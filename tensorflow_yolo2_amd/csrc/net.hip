@@ -418,7 +418,7 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
             a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.cin_s; a.M = y.M; a.Cout = y.cout; a.ldy = y.ldy;
             a.taps = y.k * y.k;
             P = (y.M + conv_block_pixels(y.cout) - 1) / conv_block_pixels(y.cout);
-            { PROF(CAT_CONV_FWD); HIPCHK(launch_conv_igemm(c->dtype, a, s)); }
+            { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s)); }
         }
         PROF(CAT_BN_FWD);
         if (training) {
@@ -516,7 +516,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
                 a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.ldy; a.M = y.M; a.Cout = y.cin; a.ldy = y.cin;
                 a.taps = y.k * y.k;
-                { PROF(CAT_DGRAD); HIPCHK(launch_conv_igemm(c->dtype, a, s)); }
+                { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s)); }
                 c->dA_cur ^= 1;
             }
         }
@@ -645,7 +645,7 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
     ConvArgs a{};
     a.x = xp; a.w = ws + p.wf; a.y = ws + p.y; a.bias = bias;
     a.N = N; a.H = H; a.W = W; a.C = p.Cin_p; a.M = N * H * W; a.Cout = Cout; a.ldy = p.ldy; a.taps = k * k;
-    HIPCHK(launch_conv_igemm(dtype, a, s));
+    HIPCHK(launch_conv(dtype, a, s));
     HIPCHK(launch_cast_to_f32(dtype, ws + p.y, y, (size_t)N * H * W, Cout, p.ldy, s));
     return Y2_OK;
 }
@@ -669,7 +669,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
         ConvArgs a{};
         a.x = dyp; a.w = ws + p.wd; a.y = ws + p.dx;
         a.N = N; a.H = H; a.W = W; a.C = p.Cdy; a.M = N * H * W; a.Cout = p.Cin_p; a.ldy = p.Cin_p; a.taps = k * k;
-        HIPCHK(launch_conv_igemm(dtype, a, s));
+        HIPCHK(launch_conv(dtype, a, s));
         HIPCHK(launch_cast_to_f32(dtype, ws + p.dx, dx, (size_t)N * H * W, Cin, p.Cin_p, s));
     }
     if (dw) {
