@@ -8,6 +8,7 @@
 namespace y2 {
 hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc);
 hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s);
+hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s);
 static hipError_t run_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc) {
     if (variant >= 20 && a.taps == 9) return launch_conv_halo_variant(variant, a, s);
     if (variant >= 20) variant = 0;
@@ -15,6 +16,43 @@ static hipError_t run_variant(int variant, const ConvArgs& a, hipStream_t s, int
 }
 }
 using namespace y2;
+
+extern "C" int y2dev_bench_wgrad(int N, int H, int W, int Cin, int Cout, int k, int variant, int splitk, int iters,
+                                 float* ms_out) {
+    const size_t sz = 2;
+    const size_t pix = (size_t)N * (H + 1) * (W + 1) + 4 * (W + 3) + 2048;
+    void *x = nullptr, *dy = nullptr;
+    float* dw = nullptr;
+    if (hipMalloc(&x, pix * Cin * sz) != hipSuccess) return -1;
+    if (hipMalloc(&dy, pix * Cout * sz) != hipSuccess) return -1;
+    if (hipMalloc(&dw, (size_t)k * k * Cin * Cout * 4) != hipSuccess) return -1;
+    std::vector<unsigned short> hx(pix * Cin), hy(pix * Cout);
+    unsigned int r = 777;
+    for (auto& v : hx) { r = r * 1664525u + 1013904223u; v = (unsigned short)(((r >> 16) & 0x83FF) | 0x3800); }
+    for (auto& v : hy) { r = r * 1664525u + 1013904223u; v = (unsigned short)(((r >> 16) & 0x83FF) | 0x2C00); }
+    hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dy, hy.data(), hy.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(dw, 0, (size_t)k * k * Cin * Cout * 4);
+    WgradArgs g{};
+    g.x = (char*)x + (size_t)(W + 3) * Cin * sz; g.dy = (char*)dy + (size_t)(W + 3) * Cout * sz; g.dW = dw;
+    g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = Cin; g.Cdy = Cout; g.Cout = Cout; g.taps = k * k;
+    g.splitk = splitk; g.scale = 1.f;
+    auto run = [&]() { return variant >= 2 ? launch_wgrad9_variant(variant, g, 0) : (variant == 1 ? launch_wgrad9(1, g, 0) : launch_wgrad(1, g, 0)); };
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i)
+        if (run() != hipSuccess) return -2;
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) run();
+    hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) return -3;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_out = ms / iters;
+    hipFree(x); hipFree(dy); hipFree(dw);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return 0;
+}
 
 extern "C" int y2dev_bench_conv(int N, int H, int W, int Cin, int Cout, int k, int variant, int iters, float* ms_out) {
     const size_t sz = 2;

@@ -150,5 +150,17 @@ template <int N>
 Y2_DEV void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// run-time count (wave-uniform): the immediate must be a literal, so dispatch over 0..31
+// (larger counts wait for 31: conservative)
+Y2_DEV void wait_vmcnt_dyn(int n) {
+    switch (n) {
+#define Y2_W(k) case k: wait_vmcnt<k>(); break;
+        Y2_W(0) Y2_W(1) Y2_W(2) Y2_W(3) Y2_W(4) Y2_W(5) Y2_W(6) Y2_W(7) Y2_W(8) Y2_W(9) Y2_W(10) Y2_W(11)
+        Y2_W(12) Y2_W(13) Y2_W(14) Y2_W(15) Y2_W(16) Y2_W(17) Y2_W(18) Y2_W(19) Y2_W(20) Y2_W(21) Y2_W(22)
+        Y2_W(23) Y2_W(24) Y2_W(25) Y2_W(26) Y2_W(27) Y2_W(28) Y2_W(29) Y2_W(30)
+#undef Y2_W
+        default: wait_vmcnt<31>(); break;
+    }
+}
 
 }  // namespace y2

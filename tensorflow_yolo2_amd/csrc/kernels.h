@@ -62,7 +62,9 @@ struct WgradArgs {
     int splitk;
     float scale;
 };
-hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
+hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);       // one tap per block
+hipError_t launch_wgrad9(int dtype, const WgradArgs& a, hipStream_t s);      // 3x3: nine taps per block
+hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a, hipStream_t s);
 
 // ---- packing
 hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H, int W, hipStream_t s);

@@ -114,9 +114,9 @@ struct ProfScope {
         }
         idx = (int)c->prof_used++;
         c->prof_recs[idx].cat = cat;
-        hipEventRecord(c->prof_recs[idx].a, s);
+        (void)hipEventRecord(c->prof_recs[idx].a, s);
     }
-    ~ProfScope() { if (idx >= 0) hipEventRecord(c->prof_recs[idx].b, s); }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_recs[idx].b, s); }
 };
 #define PROF(cat) ProfScope _prof_scope(c, s, cat)
 
@@ -278,7 +278,7 @@ int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers
 
 void y2_ctx_destroy(y2_ctx* ctx) {
     if (!ctx) return;
-    for (auto& r : ctx->prof_recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     delete ctx;
 }
 
@@ -510,7 +510,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             g.x = xin; g.dy = dyp; g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M;
             g.Cin = y.cin_s; g.Cdy = y.ldy; g.Cout = y.cout; g.taps = y.k * y.k; g.splitk = 0; g.scale = inv_gs;
-            { PROF(CAT_WGRAD); HIPCHK(launch_wgrad(c->dtype, g, s)); }
+            { PROF(CAT_WGRAD); HIPCHK(launch_wgrad_auto(c->dtype, g, s)); }
             if (l > 0) {
                 ConvArgs a{};
                 a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
@@ -677,7 +677,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
         g.x = xp; g.dy = dyp; g.dW = (float*)(ws + p.dw);
         g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = p.Cin_p; g.Cdy = p.Cdy; g.Cout = Cout;
         g.taps = k * k; g.splitk = 0; g.scale = 1.f;
-        HIPCHK(launch_wgrad(dtype, g, s));
+        HIPCHK(launch_wgrad_auto(dtype, g, s));
         for (int t = 0; t < k * k; ++t)
             HIPCHK(hipMemcpyAsync(dw + (size_t)t * Cin * Cout, (float*)(ws + p.dw) + (size_t)t * p.Cin_p * Cout,
                                   (size_t)Cin * Cout * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -1,0 +1,297 @@
+// Weight gradient of a 3x3 convolution with ALL NINE TAPS in one block
+// (TF Conv2DBackpropFilter, reference darknet.py:20-21):
+//     dW[t][ci][co] = sum_p X[p (+) t][ci] * dY[p][co],   t = (kh, kw)
+// The per-tap kernel (wgrad.hip) re-stages X and dY for every tap and is bound by the
+// global->LDS fill rate (65 FLOP per staged byte).  Here a block owns a (BI x BO) slice
+// of ci x co for all nine taps: per K step it stages ONE dY tile [64 px][BO] and ONE
+// X window [64 + 2*pitch + 2 px][BI] of the bordered pixel space; the nine taps read
+// row-shifted views of that window.  ~235 FLOP per staged byte at 13x13, 36 MFMAs per
+// wave between barriers, and the dY fragment is shared by the nine MFMAs of a k-group.
+// K runs linearly over the bordered pixel space (dY border = 0); fragments come out of
+// the [pixel][channel] images through ds_read_b64_tr_b16.
+#include "common.h"
+#include "conv_epilogue.h"
+#include "kernels.h"
+
+namespace y2 {
+
+template <typename T, int WI, int WO>
+struct Wg9Cfg {
+    static constexpr int NW = WI * WO, NT = NW * 64;
+    static constexpr int SZ = sizeof(T);
+    static constexpr int BI = 32 * WI, BO = 32 * WO;
+    static constexpr int BKP = (SZ == 2) ? 64 : 32;
+    static constexpr int ROWX = BI * SZ, ROWY = BO * SZ;
+    static constexpr int LPRX = ROWX / 16, LPRY = ROWY / 16;
+    static constexpr int RPIX = 64 / LPRX, RPIY = 64 / LPRY;
+    static constexpr int NIY = BKP / RPIY;
+    static constexpr int IPWY = (NIY + NW - 1) / NW;
+    static constexpr int YS = BKP * ROWY;
+};
+
+// bank swizzle of the [pixel][channel] images for the transposed 4x16 reads (see wgrad.hip)
+template <int ROWB, int SZ>
+Y2_DEV int wg9_swz(int row) {
+    if (SZ != 2) return 0;
+    if (ROWB >= 256) return (row & 3) << 2;
+    if (ROWB == 128) return ((row & 3) >> 1) << 2;
+    return 0;
+}
+
+// NS LDS stages; NS-1 K steps of LDS-DMA stay in flight across the raw barrier (counted vmcnt):
+// with one wave per SIMD (as many waves as the dW tiling yields) this is what hides HBM latency.
+template <typename T, int WI, int WO, int NS>
+__global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wrows) {
+    typedef Wg9Cfg<T, WI, WO> Cfg;
+    constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
+    constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = w / WO, wo = w % WO;
+    const int pitch = a.W + 1;
+
+    const int nIT = (a.Cin + BI - 1) / BI, nOT = (a.Cout + BO - 1) / BO;
+    int b = blockIdx.x;
+    const int ot = b % nOT; b /= nOT;
+    const int it = b % nIT;
+    const int split = b / nIT;
+    const int ci0 = it * BI, co0 = ot * BO;
+
+    const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
+    const long ksteps = (Mp + BKP - 1) / BKP;
+    const long spb = (ksteps + a.splitk - 1) / a.splitk;
+    const long s_begin = (long)split * spb;
+    long s_end = s_begin + spb;
+    if (s_end > ksteps) s_end = ksteps;
+    const int nsteps = (int)(s_end > s_begin ? s_end - s_begin : 0);
+
+    const int xs_bytes = wrows * ROWX;              // one X window
+    const int stage_bytes = xs_bytes + Cfg::YS;
+    const int xpieces = wrows / Cfg::RPIX;
+    const long kb = s_begin * BKP;
+    // window of step s starts at bordered position kb + s*BKP - pitch - 1 (top-left tap)
+    const char* xg = (const char*)a.x + ((kb - pitch - 1) * a.Cin + ci0) * SZ;
+    const char* yg = (const char*)a.dy + (kb * a.Cdy + co0) * SZ;
+    const long xstep = (long)BKP * a.Cin * SZ, ystep = (long)BKP * a.Cdy * SZ;
+
+    const int lrx = lane / Cfg::LPRX, lsx = lane % Cfg::LPRX;
+    uint32_t voffy[Cfg::IPWY];
+#pragma unroll
+    for (int i = 0; i < Cfg::IPWY; ++i) {
+        const int row = (i * NW + w) * Cfg::RPIY + lane / Cfg::LPRY;
+        const int sl = (lane % Cfg::LPRY) ^ wg9_swz<ROWY, SZ>(row);
+        voffy[i] = (uint32_t)row * (uint32_t)(a.Cdy * SZ) + sl * 16;
+    }
+    auto stage = [&](int st, int buf) {
+        const char* xs = xg + (long)st * xstep;
+        const char* ys = yg + (long)st * ystep;
+        char* lb = smem + buf * stage_bytes;
+        for (int i = w; i < xpieces; i += NW) {
+            const int row = i * Cfg::RPIX + lrx;
+            const uint32_t off = (uint32_t)row * (uint32_t)(a.Cin * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
+            glds16(xs + off, lb + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::IPWY; ++i) {
+            const int ii = i * NW + w;
+            if ((i + 1) * NW <= Cfg::NIY || ii < Cfg::NIY) glds16(ys + voffy[i], lb + xs_bytes + ii * 1024);
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+    int shift[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) shift[t] = (t / 3) * pitch + (t % 3);
+
+    // loads per wave per stage (the launcher makes the X window a multiple of RPIX*NW rows)
+    const int lps = xpieces / NW + Cfg::NIY / NW;
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nsteps) stage(s0, s0);
+    int cbuf = 0, ibuf = NS - 1;
+    for (int st = 0; st < nsteps; ++st) {
+        if (st + NS - 2 < nsteps) wait_vmcnt_dyn((NS - 2) * lps);
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + NS - 1 < nsteps) stage(st + NS - 1, ibuf);
+        const int buf = cbuf;
+        cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
+        ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
+        const char* xs = smem + buf * stage_bytes;
+        const char* ys = xs + xs_bytes;
+        if constexpr (SZ == 2) {
+            // dY fragment address (no tap shift): rows kg*16 + 8*hh + qq (+4)
+            const int fy = wg9_swz<ROWY, SZ>(qq);
+            const char* pyb = ys + (8 * hh + qq) * ROWY + (((wo * 4 + 2 * g1 + (pp >> 1)) ^ fy) * 16) + (pp & 1) * 8;
+            // X fragment per tap: row = 8*hh + qq + shift[t]; the swizzle follows the LDS row
+            const char* pxb[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int row = 8 * hh + qq + shift[t];
+                const int fx = wg9_swz<ROWX, SZ>(row);
+                pxb[t] = xs + row * ROWX + (((wi * 4 + 2 * g1 + (pp >> 1)) ^ fx) * 16) + (pp & 1) * 8;
+            }
+            // Software pipeline over the k-groups: the fragments of group kg+1 are requested
+            // while the nine MFMAs of group kg issue (one wave per SIMD: nothing else hides the
+            // ~100-cycle LDS latency; the compiler's own schedule keeps only one fragment ahead).
+            typedef typename Elem<T>::frag frag_t;
+            frag_t fa0[9], fa1[9], fb0, fb1;
+            auto load_group = [&](int kg, frag_t (&fa)[9], frag_t& fb) {
+                const char* py = pyb + kg * 16 * ROWY;
+                fb = tr_frag<T>(py, py + 4 * ROWY);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const char* px = pxb[t] + kg * 16 * ROWX;
+                    fa[t] = tr_frag<T>(px, px + 4 * ROWX);
+                }
+            };
+            load_group(0, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kg = 0; kg < BKP / 16; kg += 2) {
+                load_group(kg + 1, fa1, fb1);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) mma32(acc[t], fa0[t], fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kg + 2 < BKP / 16) load_group(kg + 2, fa0, fb0);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) mma32(acc[t], fa1[t], fb1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll 4
+            for (int s2 = 0; s2 < BKP / 2; ++s2) {
+                const int row = 2 * s2 + hh;
+                const float fb = *(const float*)(ys + row * ROWY + (wo * 32 + r32) * 4);
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float fa = *(const float*)(xs + (row + shift[t]) * ROWX + (wi * 32 + r32) * 4);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int co = co0 + wo * 32 + r32;
+    if (co < a.Cout) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ci = ci0 + wi * 32 + acc_row(q, hh);
+                if (ci < a.Cin) {
+                    float* dst = a.dW + ((size_t)t * a.Cin + ci) * a.Cout + co;
+                    if (a.splitk == 1) *dst = acc[t][q] * a.scale;
+                    else atomicAdd(dst, acc[t][q] * a.scale);
+                }
+            }
+    }
+}
+
+template <typename T, int WI, int WO, int NS>
+static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s) {
+    typedef Wg9Cfg<T, WI, WO> Cfg;
+    static_assert(Cfg::NIY % Cfg::NW == 0, "dY pieces must split evenly over waves");
+    const int pitch = a.W + 1;
+    int wrows = Cfg::BKP + 2 * pitch + 2;
+    const int gran = Cfg::RPIX * Cfg::NW;           // every wave issues the same number of pieces
+    wrows = (wrows + gran - 1) / gran * gran;
+    size_t lds = NS * ((size_t)wrows * Cfg::ROWX + Cfg::YS);
+    if (lds > 160 * 1024) return hipErrorOutOfMemory;
+    auto kern = wgrad9_kernel<T, WI, WO, NS>;
+    const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
+    const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
+    const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
+    const int tiles = nIT * nOT;
+    if (a.splitk <= 0) {
+        // short image rows (big dW, K = a few thousand steps): one block per CU measured best;
+        // long rows (tiny dW, K = 10^5 steps): ~3 blocks per CU to cover the HBM stream
+        long sk = a.W <= 26 ? (256 + tiles / 2) / tiles : (768 + tiles - 1) / tiles;
+        const long maxsk = (ksteps + 7) / 8;
+        if (sk > maxsk) sk = maxsk;
+        if (sk < 1) sk = 1;
+        a.splitk = (int)sk;
+    }
+    // With no more blocks than CUs, ask for > half of a CU's LDS: the dispatcher then cannot
+    // co-locate two blocks on one CU while another CU idles (measured: it does otherwise).
+    if (tiles * a.splitk <= 256 && lds < 84 * 1024) lds = 84 * 1024;
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), lds, s, a, wrows);
+    return hipGetLastError();
+}
+// deepest ring that fits (4 stages where the window is small)
+template <typename T, int WI, int WO>
+static hipError_t wg9_launch(const WgradArgs& a, hipStream_t s, int ns = 0) {
+    typedef Wg9Cfg<T, WI, WO> Cfg;
+    const int gran = Cfg::RPIX * Cfg::NW;
+    const int wrows = (Cfg::BKP + 2 * (a.W + 1) + 2 + gran - 1) / gran * gran;
+    const size_t stage = (size_t)wrows * Cfg::ROWX + Cfg::YS;
+    (void)stage;
+    if (ns == 0) ns = 2;   // deeper rings measured slower on every Darknet-19 shape (bench_wgrad.py)
+    if (ns >= 4) return wg9_launch_ns<T, WI, WO, 4>(a, s);
+    if (ns == 3) return wg9_launch_ns<T, WI, WO, 3>(a, s);
+    return wg9_launch_ns<T, WI, WO, 2>(a, s);
+}
+
+template <typename T>
+static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
+    const bool i64 = a.Cin >= 64, o64 = a.Cdy >= 64;
+    if (i64 && o64) return wg9_launch<T, 2, 2>(a, s);
+    if (i64) return wg9_launch<T, 2, 1>(a, s);
+    if (o64) return wg9_launch<T, 1, 2>(a, s);
+    return wg9_launch<T, 1, 1>(a, s);
+}
+
+// 3x3 only; the window grows with the image row, so this form is for short rows
+hipError_t launch_wgrad9(int dtype, const WgradArgs& a, hipStream_t s) {
+    if (a.taps != 9 || a.Cin % 32 != 0) return hipErrorInvalidValue;
+    switch (dtype) {
+        case 0: return wg9_T<float>(a, s);
+        case 1: return wg9_T<half_t>(a, s);
+        case 2: return wg9_T<bf16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace y2
+
+namespace y2 {
+// policy: all-taps kernel where the image rows are short (window ~1.5-2x the K step),
+// per-tap kernel on the large feature maps and for 1x1 filters
+// development variants (f16): explicit block shapes
+hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s) {
+    switch (variant) {
+        case 2: return wg9_launch<half_t, 2, 1>(a, s);
+        case 3: return wg9_launch<half_t, 1, 2>(a, s);
+        case 4: return wg9_launch<half_t, 1, 1>(a, s);
+        case 5: return wg9_launch<half_t, 2, 2>(a, s);
+        case 6: return wg9_launch<half_t, 2, 2>(a, s, 2);
+        case 7: return wg9_launch<half_t, 2, 2>(a, s, 3);
+        case 8: return wg9_launch<half_t, 2, 2>(a, s, 4);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a, hipStream_t s) {
+    // measured per shape (scripts/bench_wgrad.py): nine-tap blocks win everywhere except 52x52
+    if (a.taps == 9 && (a.W <= 26 || a.W >= 100)) {
+        hipError_t e = launch_wgrad9(dtype, a, s);
+        if (e != hipErrorOutOfMemory) return e;   // window too large for LDS: fall through
+        (void)hipGetLastError();
+    }
+    return launch_wgrad(dtype, a, s);
+}
+}  // namespace y2
