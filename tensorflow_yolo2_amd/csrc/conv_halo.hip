@@ -250,12 +250,25 @@ static hipError_t halo_pick(const ConvArgs& a, hipStream_t s) {
 }
 
 template <typename T>
-static hipError_t halo_T(const ConvArgs& a, hipStream_t s) {
+static hipError_t halo_T(const ConvArgs& a, hipStream_t s, int* bp) {
     const int kb = a.C * (int)sizeof(T);
     const bool k128 = (kb % 128) == 0;
     if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
+    *bp = a.Cout > 64 ? 128 : 256;
     if (a.Cout > 64) {
-        // 64-byte K chunks: image + ring fit 3 blocks per CU (measured best at 13x13 / 26x26)
+        // measured on the Darknet-19 shapes (scripts/bench_conv.py): big pixel tiles (the filter
+        // ring is re-streamed once per pixel tile) with 8 waves; fall back when LDS runs out
+        hipError_t e = hipErrorOutOfMemory;
+        if (a.W <= 13 && a.M >= 384 * 8) {
+            *bp = 384;
+            e = k128 ? halo_pick<T, 4, 2, 3, 2, 128, 2>(a, s) : halo_pick<T, 4, 2, 3, 2, 64, 2>(a, s);
+        } else if (a.M >= 256 * 8) {
+            *bp = 256;
+            e = halo_pick<T, 4, 2, 2, 2, 64, 2>(a, s);
+        }
+        if (e != hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();
+        *bp = 128;
         return halo_pick<T, 2, 2, 2, 2, 64, 2>(a, s);
     } else if (a.Cout > 32) {
         return k128 ? halo_pick<T, 4, 1, 2, 2, 128, 3>(a, s) : halo_pick<T, 4, 1, 2, 2, 64, 3>(a, s);
@@ -264,12 +277,12 @@ static hipError_t halo_T(const ConvArgs& a, hipStream_t s) {
     }
 }
 
-hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s) {
+hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* bp) {
     if (a.taps != 9) return hipErrorInvalidValue;
     switch (dtype) {
-        case 0: return halo_T<float>(a, s);
-        case 1: return halo_T<half_t>(a, s);
-        case 2: return halo_T<bf16_t>(a, s);
+        case 0: return halo_T<float>(a, s, bp);
+        case 1: return halo_T<half_t>(a, s, bp);
+        case 2: return halo_T<bf16_t>(a, s, bp);
     }
     return hipErrorInvalidValue;
 }
@@ -277,9 +290,14 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s) {
 // Kernel policy (measured on MI355X, scripts/bench_conv.py): the halo image wins where the
 // image rows are short (13x13, 26x26: the nine taps share ~85 % of their rows); on the large
 // feature maps the image would take a whole CU's LDS, and the per-tap kernel with 8 waves wins.
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s) {
-    if (a.taps == 9 && a.W <= 26) return launch_conv_halo(dtype, a, s);
-    return launch_conv_igemm(dtype, a, s);
+// *block_pixels receives the pixel-tile size used (= rows per BN partial record)
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels) {
+    int bp = conv_block_pixels(a.Cout);
+    hipError_t e;
+    if (a.taps == 9 && a.W <= 52) e = launch_conv_halo(dtype, a, s, &bp);
+    else e = launch_conv_igemm(dtype, a, s);
+    if (block_pixels) *block_pixels = bp;
+    return e;
 }
 
 // development variants (f16) for scripts/bench_conv.py
@@ -300,6 +318,25 @@ hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t 
         case 41: return halo_pick<T, 2, 4, 2, 1, 64, 3>(a, s);
         case 42: return halo_pick<T, 4, 1, 1, 4, 128, 2>(a, s);   // wave = 32 px x 128 co
         case 43: return halo_pick<T, 1, 4, 4, 1, 128, 2>(a, s);   // wave = 128 px x 32 co
+        // ablations of variant 29 (128x128, 64-byte chunks, NSB 2: the product choice)
+        case 50: return halo_pick<T, 2, 2, 2, 2, 64, 2, 3>(a, s);    // no loads
+        case 51: return halo_pick<T, 2, 2, 2, 2, 64, 2, 4>(a, s);    // no MFMA
+        case 52: return halo_pick<T, 2, 2, 2, 2, 64, 2, 8>(a, s);    // no LDS reads
+        case 53: return halo_pick<T, 2, 2, 2, 2, 64, 2, 11>(a, s);   // MFMA only
+        case 54: return halo_pick<T, 2, 2, 2, 2, 64, 2, 12>(a, s);   // loads only
+        case 55: return halo_pick<T, 2, 2, 2, 2, 64, 2, 16>(a, s);   // no epilogue
+        case 56: return halo_pick<T, 2, 2, 2, 2, 64, 2, 2>(a, s);    // no B loads
+        case 57: return halo_pick<T, 2, 2, 3, 2, 64, 2>(a, s);       // 192 x 128 tile
+        case 58: return halo_pick<T, 2, 2, 4, 2, 64, 2>(a, s);       // 256 x 128 tile, 4 waves
+        case 59: return halo_pick<T, 2, 2, 2, 4, 64, 2>(a, s);       // 128 x 256 tile, 4 waves
+        case 60: return halo_pick<T, 4, 2, 3, 2, 64, 3>(a, s);       // 384 x 128, 8 waves
+        case 61: return halo_pick<T, 4, 2, 3, 2, 64, 2>(a, s);
+        case 62: return halo_pick<T, 4, 2, 2, 2, 64, 3>(a, s);       // 256 x 128, 8 waves
+        case 63: return halo_pick<T, 4, 2, 2, 2, 64, 2>(a, s);
+        case 64: return halo_pick<T, 4, 2, 4, 2, 64, 2>(a, s);       // 512 x 128, 8 waves
+        case 65: return halo_pick<T, 4, 2, 3, 2, 128, 2>(a, s);      // 384 x 128, 128-byte chunks
+        case 66: return halo_pick<T, 2, 4, 3, 1, 64, 2>(a, s);       // 192 x 128, 8 waves of 96x32
+        case 67: return halo_pick<T, 4, 2, 1, 2, 64, 2>(a, s);       // 128 x 128, 8 waves of 32x64
         // ablations of variant 24 (256x128, 8 waves, NSB 3)
         case 30: return halo_pick<T, 4, 2, 2, 2, 128, 3, 3>(a, s);    // no loads
         case 31: return halo_pick<T, 4, 2, 2, 2, 128, 3, 4>(a, s);    // no MFMA

@@ -24,8 +24,8 @@ struct ConvArgs {
     int taps;           // 9 (3x3) or 1 (1x1)
 };
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
-hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s);    // 3x3: LDS halo image, 9 shifted views
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s);         // picks one of the two per shape
+hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels = nullptr);  // policy
 int conv_block_pixels(int Cout);
 int conv_block_couts(int Cout);
 

@@ -417,8 +417,9 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
             if (training) { a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2; }
             a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.cin_s; a.M = y.M; a.Cout = y.cout; a.ldy = y.ldy;
             a.taps = y.k * y.k;
-            P = (y.M + conv_block_pixels(y.cout) - 1) / conv_block_pixels(y.cout);
-            { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s)); }
+            int bp = 0;
+            { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s, &bp)); }
+            P = (y.M + bp - 1) / bp;
         }
         PROF(CAT_BN_FWD);
         if (training) {
