@@ -1,0 +1,45 @@
+"""Counterpart of src/pascal/pascal_detect_darknet.py: single-image detection.
+    python -m tensorflow_yolo2_amd.pascal.pascal_detect_darknet IMAGE [--size 224]
+Same sequence as the reference (:23-63): read + bilinear resize + x/255*2-1 on BGR pixels, core
+with is_training=False, head with its default is_training=True, reshape to [-1,S,S,30], decode."""
+import argparse
+import sys
+
+import numpy as np
+import torch
+
+from .. import config as cfg
+from ..img_dataset import pascal_voc
+from ..yolo2_nets import darknet, net_utils
+
+
+class _Imdb:
+    classes = pascal_voc.CLASSES
+    num_class = len(pascal_voc.CLASSES)
+    name = 'voc_2007'
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("image")
+    ap.add_argument("--size", type=int, default=cfg.IMAGE_SIZE)
+    ap.add_argument("--dtype", default="f16")
+    args = ap.parse_args(argv)
+    from PIL import Image
+    imdb = _Imdb()
+    S, B = args.size // 32, cfg.B
+    rgb = np.array(Image.open(args.image).convert("RGB"), dtype=np.uint8)
+    bgr = rgb[:, :, ::-1]                                   # cv2.imread gives BGR; the reference never swaps
+    image = pascal_voc.image_read(bgr, args.size).reshape((1, args.size, args.size, 3))
+    darknet.set_default_dtype(args.dtype)
+    input_data = torch.as_tensor(np.ascontiguousarray(image)).cuda()
+    core_net = darknet.darknet19_core(input_data, is_training=False)
+    final_conv_layer = darknet.darknet19_detection(core_net, 5 * B + imdb.num_class)
+    grid_net = final_conv_layer.reshape([-1, S, S, 5 * B + imdb.num_class])
+    predicts = grid_net.eval()                              # random weights unless a checkpoint was loaded
+    cfg.S = S
+    return net_utils.show_yolo_detection(args.image, predicts, imdb)
+
+
+if __name__ == "__main__":
+    sys.exit(0 if main() is not None else 1)

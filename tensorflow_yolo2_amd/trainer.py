@@ -22,6 +22,26 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
+def layer_slices(num_layers):
+    """Backward-order layer slices for the overlapped all-reduce: head / 13x13 block / rest."""
+    cuts = sorted({0, min(13, num_layers), min(18, num_layers), num_layers})
+    return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)][::-1]
+
+
+def slice_range(w_offsets, n_params, num_layers, lo, hi):
+    """[start, end) of layers [lo, hi) in the flat buffer (w_offsets[l] = offset of layer l's filter)."""
+    start = w_offsets[lo]
+    end = n_params if hi == num_layers else w_offsets[hi]
+    return start, end
+
+
+def reduce_flat(flat, ranges, dist):
+    """SUM all-reduce of the given [start, end) ranges of a flat tensor (any device/backend)."""
+    for (s, e) in ranges:
+        dist.all_reduce(flat[s:e], op=dist.ReduceOp.SUM)
+    return flat
+
+
 class GradReducer:
     """Sliced, overlapped all-reduce of a Network's flat gradient buffer."""
 
@@ -29,17 +49,13 @@ class GradReducer:
         self.net = net
         n = net.num_layers
         if slices is None:
-            # backward order: head / 13x13 block / rest
-            cuts = sorted({0, min(13, n), min(18, n), n})
-            slices = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)][::-1]
+            slices = layer_slices(n)
         self.slices = slices
         self.comm_stream = torch.cuda.Stream(device=net.device) if net.device.type == "cuda" else None
         self._pending = []
 
     def _range(self, lo, hi):
-        start = self.net._offsets[lo][0]
-        end = self.net.n_params if hi == self.net.num_layers else self.net._offsets[hi][0]
-        return start, end
+        return slice_range([o[0] for o in self.net._offsets], self.net.n_params, self.net.num_layers, lo, hi)
 
     def backward_and_reduce(self, dout):
         dist = _dist()
@@ -54,7 +70,7 @@ class GradReducer:
             ready.record()
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
-                dist.all_reduce(net.grads[s:e], op=dist.ReduceOp.SUM)
+                reduce_flat(net.grads, [(s, e)], dist)
         torch.cuda.current_stream().wait_stream(self.comm_stream)
         return dist.get_world_size()
 

@@ -1,0 +1,255 @@
+"""GPU tests (-m gpu): golden vectors, the full Darknet-19 networks, the reference-named
+Python interface, and size-independent properties at BASELINE.json's full size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_ref as R, loss_ref as L
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def l2err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# ---------------------------------------------------------------- golden vectors
+def test_golden_tiny_stack(golden_dir):
+    from tensorflow_yolo2_amd import engine as E
+    g = np.load(os.path.join(golden_dir, "tiny_stack.npz"))
+    spec = [tuple(int(v) for v in s) for s in g["spec"]]
+    params = []
+    for l, (k, ci, co, _p) in enumerate(spec):
+        p = R.init_layer(np.random.default_rng(0), k, ci, co)
+        for key in ("W", "b", "gamma", "beta"):
+            p[key] = g["p%d_%s" % (l, key)]
+        params.append(p)
+    x = g["x"]
+    net = E.Network(spec, x.shape[0], x.shape[1], x.shape[2], dtype="f32", training=True)
+    net.load_params(params)
+    out = net.forward(dev(x), True, True)
+    assert relerr(out.cpu().numpy(), g["out"]) < 1e-3          # north_star: 1e-3 relative (observed ~1e-6)
+    net.backward(dev(g["dout"]))
+    grads, state = net.export_grads(), net.export_params()
+    for l in range(len(spec)):
+        for k in ("W", "gamma", "beta"):
+            assert relerr(grads[l][k], g["g%d_%s" % (l, k)]) < 1e-3, (l, k)
+        assert relerr(state[l]["moving_mean"], g["mm%d" % l]) < 1e-4
+        assert relerr(state[l]["moving_var"], g["mv%d" % l]) < 1e-4
+
+
+@pytest.mark.parametrize("S,size", [(7, 224), (13, 416)])
+def test_golden_loss_and_decode(golden_dir, S, size):
+    from tensorflow_yolo2_amd import engine as E
+    g = np.load(os.path.join(golden_dir, "loss_S%d.npz" % S))
+    n = g["net"].shape[0]
+    loss, ious, mask, dnet = E.yolo_loss(dev(g["net"]), dev(g["labels"]), 20, n, size, S, 2)
+    np.testing.assert_array_equal(mask.cpu().numpy(), g["mask"])      # index work: bit-exact
+    np.testing.assert_array_equal(ious.cpu().numpy(), g["ious"])
+    assert abs(loss[4].item() - g["total"]) < 1e-5 * abs(g["total"])
+    np.testing.assert_allclose(loss[:4].cpu().numpy(), g["parts"], rtol=1e-5)
+    assert relerr(dnet.cpu().numpy(), g["dnet"]) < 1e-5
+    dets = E.decode_detections(dev(g["net"][0]), S, 2, 20, 353, 500)
+    np.testing.assert_array_equal(np.array([d[:5] + d[6:] for d in dets], np.int32).reshape(-1, 8), g["dets"])
+    np.testing.assert_array_equal(np.array([d[5] for d in dets], np.float32), g["dets_conf"])
+
+
+# ---------------------------------------------------------------- full networks
+def _torch_ref_detector(params, x, labels, S, size):
+    from oracle import torch_ref as T
+    spec = R.CORE_SPEC + R.det_head_spec(30)
+    tp = T.to_torch_params(params, torch.float64, requires_grad=True)
+    net, _ = T.run_stack(torch.tensor(x, dtype=torch.float64), tp, spec, True)
+    n = x.shape[0]
+    loss, ious, mask, _ = T.get_loss(net.reshape(n, S, S, 30), torch.tensor(labels, dtype=torch.float64), 20, n,
+                                     size, S, 2, L.yolo_grid_offset(S, 2))
+    loss.backward()
+    return net.detach().numpy(), loss.item(), ious.detach().numpy(), mask.numpy(), tp
+
+
+def test_full_detector_f32_vs_oracle_224():
+    """darknet19_core + darknet19_detection(30) + get_loss + backward at the reference's own shape
+    (224x224, S=7), random weights, against the float64 CPU oracle: 1e-3 relative."""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    n, size, S = 2, 224, 7
+    spec = E.CORE_SPEC + E.det_head_spec(30)
+    params = R.init_params(spec, seed=0)
+    x = synthetic.images(n, size, 1234)
+    labels = synthetic.det_labels(n, size, S, 4321)
+    ref_net, ref_loss, ref_ious, ref_mask, tp = _torch_ref_detector(params, x, labels, S, size)
+    net = E.Network(spec, n, size, size, dtype="f32", core_layers=18, training=True)
+    net.load_params(params)
+    grid = net.forward(dev(x), True, True)
+    assert grid.shape == (n, S, S, 30)
+    assert relerr(grid.cpu().numpy(), ref_net) < 1e-3
+    loss, ious, mask, dnet = E.yolo_loss(grid, dev(labels), 20, n, size, S, 2)
+    assert abs(loss[4].item() - ref_loss) < 1e-3 * abs(ref_loss)
+    np.testing.assert_array_equal(mask.cpu().numpy(), ref_mask)
+    assert relerr(ious.cpu().numpy(), ref_ious) < 1e-3
+    net.backward(dnet)
+    grads = net.export_grads()
+    # gradients: fp32 round-off is amplified through 22 batch-norms over tiny batches (98 pixels at the
+    # end with N = 2); observed 2e-3 at the first layer, < 1e-3 from the middle of the net on
+    for l in (0, 1, 7, 17, 18, 21):
+        for k in ("W", "gamma", "beta"):
+            e = l2err(grads[l][k], tp[l][k].grad.numpy())
+            assert e < 5e-3, (l, k, e)
+
+
+def test_full_detector_inference_mode_core():
+    """pascal_detect_darknet.py:41-42: core with moving statistics, head with batch statistics."""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from oracle import torch_ref as T
+    n, size = 1, 224
+    spec = E.CORE_SPEC + E.det_head_spec(30)
+    rng = np.random.default_rng(3)
+    params = R.init_params(spec, seed=1)
+    for p in params:
+        p["moving_mean"] = rng.uniform(-0.5, 0.5, p["b"].shape).astype(np.float32)
+        p["moving_var"] = rng.uniform(5.0, 50.0, p["b"].shape).astype(np.float32)
+    x = synthetic.images(n, size, 5)
+    tp = T.to_torch_params(params, torch.float64)
+    h, _ = T.run_stack(torch.tensor(x, dtype=torch.float64), tp[:18], R.CORE_SPEC, False)
+    ref, _ = T.run_stack(h, tp[18:], R.det_head_spec(30), True)
+    net = E.Network(spec, n, size, size, dtype="f32", core_layers=18, training=False)
+    net.load_params(params)
+    out = net.forward(dev(x), False, True).cpu().numpy()
+    assert relerr(out, ref.numpy()) < 1e-3
+
+
+def test_full_classifier_vs_oracle():
+    """darknet19() + softmax CE + backward + Momentum (imagenet_train_darknet.py:46-58), 64x64 crops."""
+    from tensorflow_yolo2_amd import engine as E, synthetic, _lib
+    n, size = 4, 64
+    spec = E.CORE_SPEC + E.CLS_HEAD_SPEC
+    params = R.init_params(spec, seed=2)
+    x = synthetic.images(n, size, 11)
+    labels = synthetic.cls_labels(n, 12)
+    logits_ref, ctx, _ = R.darknet19(x, params, True, np.float64, spec=R.CORE_SPEC + R.CLS_HEAD_SPEC, pool_k=2)
+    loss_ref, dl = R.sparse_softmax_cross_entropy_mean(logits_ref, labels)
+    _, rg = R.darknet19_backward(params, ctx, dl, np.float64)
+    net = E.Network(spec, n, size, size, dtype="f32", tail=_lib.Y2_TAIL_AVGPOOL, tail_k=2, training=True)
+    net.load_params(params)
+    logits = net.forward(dev(x), True, True)
+    assert logits.shape == (n, 1000)
+    assert relerr(logits.cpu().numpy(), logits_ref) < 1e-3
+    loss, dlog = E.softmax_cross_entropy(logits, torch.as_tensor(labels).cuda())
+    assert abs(loss.item() - loss_ref) < 1e-3 * loss_ref
+    net.backward(dlog)
+    g = net.export_grads()
+    for l in (0, 9, 18):
+        assert l2err(g[l]["W"], rg[l]["W"]) < 2e-3, l
+
+
+def test_reference_named_interface_train_and_detect():
+    """darknet19_core / darknet19_detection / get_loss / AdamOptimizer().minimize used exactly like
+    src/pascal/pascal_train_darknet.py:39-51 and pascal_detect_darknet.py:41-43."""
+    from tensorflow_yolo2_amd import config as cfg, synthetic
+    from tensorflow_yolo2_amd.yolo2_nets import darknet, net_utils
+    from tensorflow_yolo2_amd.trainer import DetectorTrainer
+    darknet.reset_default_graph()
+    darknet.set_default_dtype("f32")
+    n, size, S, B = 2, 64, 2, 2
+    x = dev(synthetic.images(n, size, 1))
+    labels = synthetic.det_labels(n, size, S, 2)
+    core_net = darknet.darknet19_core(x, is_training=True)
+    final = darknet.darknet19_detection(core_net, 30)
+    grid_net = final.reshape([-1, S, S, 30])
+    with pytest.raises(ValueError):
+        darknet.darknet19_core(x, is_training=True)             # same scope without reuse
+    opt = net_utils.AdamOptimizer()
+    loss, ious, mask = net_utils.get_loss(grid_net, labels, 20, n, size, S, B, cfg.yolo_grid_offset(S, B))
+    first = float(loss)
+    opt.minimize(loss)()
+    # the same step through the trainer object (same seed-0 initial values) gives the same loss
+    tr = DetectorTrainer(n, size, dtype="f32", seed=0)
+    l2, _, _ = tr.step(x, dev(labels))
+    assert abs(float(l2[4]) - first) < 1e-5 * abs(first)
+    loss2, _, _ = net_utils.get_loss(grid_net, labels, 20, n, size, S, B, cfg.yolo_grid_offset(S, B))
+    assert np.isfinite(float(loss2)) and float(loss2) != first
+    with pytest.raises(ValueError):
+        net_utils.get_loss(grid_net, labels, 20, n, size, S, B, np.zeros((S, S, B)))
+    # detect-time graph shares the variables by scope name
+    core_d = darknet.darknet19_core(x, is_training=False, reuse=True)
+    det = darknet.darknet19_detection(core_d, 30, reuse=True).reshape([-1, S, S, 30])
+    pred = det.eval()
+    assert pred.shape == (n, S, S, 30) and torch.isfinite(pred).all()
+    dets = net_utils.decode_yolo_detection(pred[0], 353, 500, 20, S, B, object_thresh=-1e9)
+    assert len(dets) == S * S * B
+    darknet.reset_default_graph()
+    darknet.set_default_dtype("f16")
+
+
+# ---------------------------------------------------------------- full BASELINE size
+def test_full_size_416_properties():
+    """416x416, S=13 (BASELINE.json configs[3] geometry, batch 16 here to bound the f32 leg):
+       * f32 directional derivative of the loss matches <grad, v>  (independent of any oracle)
+       * conv-bias gradients vanish under batch-statistic BN
+       * f16 step agrees with the f32 step: loss within 2e-2, gradient cosine > 0.85."""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    n, size, S = 16, 416, 13
+    spec = E.CORE_SPEC + E.det_head_spec(30)
+    x = dev(synthetic.images(n, size, 1234))
+    labels = dev(synthetic.det_labels(n, size, S, 4321))
+    net = E.Network(spec, n, size, size, dtype="f32", core_layers=18, training=True)
+    net.init_params(0)
+    p0 = net.params.clone()
+    s0 = net.state.clone()
+
+    def loss_at(params):
+        net.params.copy_(params); net.state.copy_(s0); net.params_changed()
+        grid = net.forward(x, True, True)
+        l, _, _, d = E.yolo_loss(grid, labels, 20, n, size, S, 2)
+        return l[4].item(), d
+
+    base, dnet = loss_at(p0)
+    net.backward(dnet)
+    g32 = net.grads.clone()
+    gb = net.export_grads()
+    scale = max(np.abs(gb[l]["gamma"]).max() for l in range(22))
+    assert max(np.abs(gb[l]["b"]).max() for l in range(22)) < 1e-3 * scale + 1e-6
+    # step along the gradient itself, small enough to stay in the linear regime
+    v = g32 * (2e-3 * base / float((g32 * g32).sum()))     # predicted change: 0.2 % of the loss
+    lp, _ = loss_at(p0 + v)
+    lm, _ = loss_at(p0 - v)
+    num = (lp - lm) / 2
+    ana = float((g32 * v).sum())
+    assert ana > 0 and abs(num - ana) < 0.1 * abs(ana), (num, ana, base)
+    del net
+    h = E.Network(spec, n, size, size, dtype="f16", core_layers=18, training=True)
+    h.params.copy_(p0); h.state.copy_(s0); h.params_changed()
+    grid = h.forward(x, True, True)
+    l16, _, _, d16 = E.yolo_loss(grid, labels, 20, n, size, S, 2)
+    assert abs(l16[4].item() - base) < 2e-2 * abs(base)
+    h.backward(d16)
+    cos = float((h.grads * g32).sum() / (h.grads.norm() * g32.norm()))
+    # At random initialisation the 22-layer net amplifies the 5e-4 storage rounding of f16 to ~4 % at the
+    # grid output (scripts/diag_f16_dnet.py), which moves near-tied IoUs / responsible-box choices in the
+    # loss; the f16 gradient is the exact gradient of that slightly different function (checked against
+    # the quantised oracle in test_gpu_ops.py::test_stack_backward).  Observed cosine: 0.89-0.96 per layer.
+    assert cos > 0.85, cos
+
+
+def test_full_size_train_steps_bs64_f16():
+    """BASELINE.json configs[3] at full size on one GPU: the loss stays finite and falls."""
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.trainer import DetectorTrainer
+    tr = DetectorTrainer(64, 416, dtype="f16", seed=0)
+    x = dev(synthetic.images(64, 416, 1234))
+    lab = dev(synthetic.det_labels(64, 416, 13, 4321))
+    losses = [float(tr.step(x, lab)[0][4]) for _ in range(6)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    assert torch.isfinite(tr.net.params).all()
