@@ -37,13 +37,25 @@ def conv_flops(spec, batch, size):
     return per
 
 
+def usable_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, spec_core, spec_head):
     """oracle (torch-CPU restatement) timed on the host cores: bounded sample of the same workload."""
     import numpy as np
     import torch
     from oracle import torch_ref as T, nn_ref as R
     from tensorflow_yolo2_amd import synthetic
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     bs = args.cpu_batch
     size, S = args.image_size, args.image_size // 32
@@ -171,6 +183,19 @@ def main():
                        for k, v in prof.items()}
             if not args.forward_only and prof["wgrad"][0] > 0:
                 kernels["wgrad"]["tflops"] = fwd_igemm / (prof["wgrad"][0] / args.steps * 1e-3) / 1e12
+        # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (separate
+        # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction), bytes per launch
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")))
+            sel = [v for k, v in tj.items() if "conv_halo_kernel" in k or "conv_igemm_kernel" in k]
+            nl = sum(v["launches"] for v in sel)
+            if nl and not args.forward_only and bs == 64 and size == 416 and args.dtype == "f16":
+                roof["traffic"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in sel) / nl
+                roof["traffic_source"] = "profiles/r01_c_pmc_hbm_traffic.json (same command, earlier run)"
+        except (OSError, ValueError, KeyError):
+            pass
+        if roof.get("avg_launch_ms"):
+            roof["flops_per_launch"] = igemm_flops / max((prof["conv_fwd"][1] + prof["dgrad"][1]) / args.steps, 1)
         total_flops = sum(per) * flop_mult
         out = {
             "metric": "images/sec fwd+bwd Darknet-19 416x416" if not args.forward_only
