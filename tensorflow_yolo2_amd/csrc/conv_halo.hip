@@ -39,6 +39,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_halo_kernel(ConvArgs a, int 
     typedef typename Elem<T>::frag frag_t;
     constexpr int NW = Cfg::NW, BP = Cfg::BP, BC = Cfg::BC, SZ = Cfg::SZ;
     constexpr int LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB, KG = Cfg::KG, IPWB = Cfg::IPWB;
+    constexpr bool PRIO = (ABL & 32) != 0;   // dev: s_setprio(1) around the MFMA clusters
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -157,9 +158,10 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_halo_kernel(ConvArgs a, int 
             aoff[j] = row * BKB;
             asw[j] = (row / RPB) % LPR;
         }
-#pragma unroll
-        for (int g = 0; g < KG; ++g) {
-            frag_t fc[TC], fp[TP];
+        // Fragment double-buffering across the k-groups: the LDS reads of group g+1 are in flight
+        // while the TC*TP MFMAs of group g issue (the compiler's own schedule keeps the reads
+        // just-in-time, which exposes the LDS latency once per group).
+        auto load_frags = [&](int g, frag_t (&fc)[TC], frag_t (&fp)[TP]) {
             if (ABL & 8) {
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
@@ -175,17 +177,33 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_halo_kernel(ConvArgs a, int 
 #pragma unroll
                 for (int j = 0; j < TP; ++j) fp[j] = *(const frag_t*)(ab + aoff[j] + (((2 * g + hh) ^ asw[j]) * 16));
             }
+        };
+        auto mma_group = [&](frag_t (&fc)[TC], frag_t (&fp)[TP]) {
             if (ABL & 4) {
 #pragma unroll
                 for (int i = 0; i < TC; ++i) asm volatile("" ::"v"(fc[i]));
 #pragma unroll
                 for (int j = 0; j < TP; ++j) asm volatile("" ::"v"(fp[j]));
             } else {
+                if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
                     for (int j = 0; j < TP; ++j) mma32(acc[i][j], fc[i], fp[j]);
+                if (PRIO) __builtin_amdgcn_s_setprio(0);
             }
+        };
+        frag_t fc0[TC], fp0[TP], fc1[TC], fp1[TP];
+        load_frags(0, fc0, fp0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < KG; g += 2) {
+            load_frags(g + 1, fc1, fp1);
+            mma_group(fc0, fp0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < KG) load_frags(g + 2, fc0, fp0);
+            mma_group(fc1, fp1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // advance
         if (++kw == 3) { kw = 0; ++kh; }
@@ -335,6 +353,14 @@ hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t 
         case 63: return halo_pick<T, 4, 2, 2, 2, 64, 2>(a, s);
         case 64: return halo_pick<T, 4, 2, 4, 2, 64, 2>(a, s);       // 512 x 128, 8 waves
         case 65: return halo_pick<T, 4, 2, 3, 2, 128, 2>(a, s);      // 384 x 128, 128-byte chunks
+        case 76: return halo_pick<T, 4, 2, 3, 2, 128, 2, 32>(a, s);  // v65 + setprio
+        case 77: return halo_pick<T, 4, 2, 2, 2, 64, 2, 32>(a, s);   // v63 + setprio
+        case 70: return halo_pick<T, 4, 2, 3, 2, 128, 2, 3>(a, s);   // v65 without loads
+        case 71: return halo_pick<T, 4, 2, 3, 2, 128, 2, 4>(a, s);   // v65 without MFMA
+        case 72: return halo_pick<T, 4, 2, 3, 2, 128, 2, 2>(a, s);   // v65 without filter loads
+        case 73: return halo_pick<T, 4, 2, 3, 2, 128, 2, 1>(a, s);   // v65 without image loads
+        case 74: return halo_pick<T, 4, 2, 3, 2, 128, 2, 16>(a, s);  // v65 without epilogue
+        case 75: return halo_pick<T, 4, 2, 3, 2, 128, 2, 8>(a, s);   // v65 without LDS reads
         case 66: return halo_pick<T, 2, 4, 3, 1, 64, 2>(a, s);       // 192 x 128, 8 waves of 96x32
         case 67: return halo_pick<T, 4, 2, 1, 2, 64, 2>(a, s);       // 128 x 128, 8 waves of 32x64
         // ablations of variant 24 (256x128, 8 waves, NSB 3)
