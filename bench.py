@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: core forward only (inference BN)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU functional test)")
+    ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="functional test of the N>1 path on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -104,8 +106,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.all_ranks_on_gpu0:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     device = "cuda:%d" % local_rank
     torch.cuda.set_device(device)
