@@ -15,9 +15,12 @@
 
 namespace y2 {
 
-template <typename T, int WI, int WO>
+// TG = tap groups: with TG = 2 two waves share one (ci, co) tile, taps 0-4 and 5-8 -- twice the
+// waves per SIMD at the same accumulator footprint per wave (LDS reads and latency bubbles of
+// one wave hide behind the other's MFMAs) and no cross-wave reduction.
+template <typename T, int WI, int WO, int TG = 1>
 struct Wg9Cfg {
-    static constexpr int NW = WI * WO, NT = NW * 64;
+    static constexpr int NW = WI * WO * TG, NT = NW * 64;
     static constexpr int SZ = sizeof(T);
     static constexpr int BI = 32 * WI, BO = 32 * WO;
     static constexpr int BKP = (SZ == 2) ? 64 : 32;
@@ -40,15 +43,15 @@ Y2_DEV int wg9_swz(int row) {
 
 // NS LDS stages; NS-1 K steps of LDS-DMA stay in flight across the raw barrier (counted vmcnt):
 // with one wave per SIMD (as many waves as the dW tiling yields) this is what hides HBM latency.
-template <typename T, int WI, int WO, int NS>
-__global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wrows) {
-    typedef Wg9Cfg<T, WI, WO> Cfg;
+template <typename T, int WI, int WO, int NS, int TG, int T0, int NTAP>
+Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
+    typedef Wg9Cfg<T, WI, WO, TG> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = w / WO, wo = w % WO;
+    const int wq = w % (WI * WO);
+    const int wi = wq / WO, wo = wq % WO;
     const int pitch = a.W + 1;
 
     const int nIT = (a.Cin + BI - 1) / BI, nOT = (a.Cout + BO - 1) / BO;
@@ -99,17 +102,17 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wr
         }
     };
 
-    f32x16 acc[9];
+    f32x16 acc[NTAP];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NTAP; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
     const int r32 = lane & 31, hh = lane >> 5;
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
-    int shift[9];
+    int shift[NTAP];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) shift[t] = (t / 3) * pitch + (t % 3);
+    for (int t = 0; t < NTAP; ++t) shift[t] = ((T0 + t) / 3) * pitch + ((T0 + t) % 3);
 
     // loads per wave per stage (the launcher makes the X window a multiple of RPIX*NW rows)
     const int lps = xpieces / NW + Cfg::NIY / NW;
@@ -133,9 +136,9 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wr
             const int fy = wg9_swz<ROWY, SZ>(qq);
             const char* pyb = ys + (8 * hh + qq) * ROWY + (((wo * 4 + 2 * g1 + (pp >> 1)) ^ fy) * 16) + (pp & 1) * 8;
             // X fragment per tap: row = 8*hh + qq + shift[t]; the swizzle follows the LDS row
-            const char* pxb[9];
+            const char* pxb[NTAP];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            for (int t = 0; t < NTAP; ++t) {
                 const int row = 8 * hh + qq + shift[t];
                 const int fx = wg9_swz<ROWX, SZ>(row);
                 pxb[t] = xs + row * ROWX + (((wi * 4 + 2 * g1 + (pp >> 1)) ^ fx) * 16) + (pp & 1) * 8;
@@ -144,12 +147,12 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wr
             // while the nine MFMAs of group kg issue (one wave per SIMD: nothing else hides the
             // ~100-cycle LDS latency; the compiler's own schedule keeps only one fragment ahead).
             typedef typename Elem<T>::frag frag_t;
-            frag_t fa0[9], fa1[9], fb0, fb1;
-            auto load_group = [&](int kg, frag_t (&fa)[9], frag_t& fb) {
+            frag_t fa0[NTAP], fa1[NTAP], fb0, fb1;
+            auto load_group = [&](int kg, frag_t (&fa)[NTAP], frag_t& fb) {
                 const char* py = pyb + kg * 16 * ROWY;
                 fb = tr_frag<T>(py, py + 4 * ROWY);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int t = 0; t < NTAP; ++t) {
                     const char* px = pxb[t] + kg * 16 * ROWX;
                     fa[t] = tr_frag<T>(px, px + 4 * ROWX);
                 }
@@ -160,11 +163,11 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wr
             for (int kg = 0; kg < BKP / 16; kg += 2) {
                 load_group(kg + 1, fa1, fb1);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) mma32(acc[t], fa0[t], fb0);
+                for (int t = 0; t < NTAP; ++t) mma32(acc[t], fa0[t], fb0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kg + 2 < BKP / 16) load_group(kg + 2, fa0, fb0);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) mma32(acc[t], fa1[t], fb1);
+                for (int t = 0; t < NTAP; ++t) mma32(acc[t], fa1[t], fb1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wr
                 const int row = 2 * s2 + hh;
                 const float fb = *(const float*)(ys + row * ROWY + (wo * 32 + r32) * 4);
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
+                for (int t = 0; t < NTAP; ++t) {
                     const float fa = *(const float*)(xs + (row + shift[t]) * ROWX + (wi * 32 + r32) * 4);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[t], 0, 0, 0);
                 }
@@ -183,12 +186,12 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wr
     const int co = co0 + wo * 32 + r32;
     if (co < a.Cout) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NTAP; ++t)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int ci = ci0 + wi * 32 + acc_row(q, hh);
                 if (ci < a.Cin) {
-                    float* dst = a.dW + ((size_t)t * a.Cin + ci) * a.Cout + co;
+                    float* dst = a.dW + ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
                     if (a.splitk == 1) *dst = acc[t][q] * a.scale;
                     else atomicAdd(dst, acc[t][q] * a.scale);
                 }
@@ -196,9 +199,21 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad9_kernel(WgradArgs a, int wr
     }
 }
 
-template <typename T, int WI, int WO, int NS>
+template <typename T, int WI, int WO, int NS, int TG>
+__global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9_kernel(WgradArgs a, int wrows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (TG == 1) {
+        wg9_body<T, WI, WO, NS, 1, 0, 9>(a, wrows, smem);
+    } else {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (w < WI * WO) wg9_body<T, WI, WO, NS, 2, 0, 5>(a, wrows, smem);   // same barrier count in both arms
+        else wg9_body<T, WI, WO, NS, 2, 5, 4>(a, wrows, smem);
+    }
+}
+
+template <typename T, int WI, int WO, int NS, int TG = 1>
 static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s) {
-    typedef Wg9Cfg<T, WI, WO> Cfg;
+    typedef Wg9Cfg<T, WI, WO, TG> Cfg;
     static_assert(Cfg::NIY % Cfg::NW == 0, "dY pieces must split evenly over waves");
     const int pitch = a.W + 1;
     int wrows = Cfg::BKP + 2 * pitch + 2;
@@ -206,15 +221,15 @@ static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s) {
     wrows = (wrows + gran - 1) / gran * gran;
     size_t lds = NS * ((size_t)wrows * Cfg::ROWX + Cfg::YS);
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    auto kern = wgrad9_kernel<T, WI, WO, NS>;
+    auto kern = wgrad9_kernel<T, WI, WO, NS, TG>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
     const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
     const int tiles = nIT * nOT;
     if (a.splitk <= 0) {
-        // short image rows (big dW, K = a few thousand steps): one block per CU measured best;
+        // short image rows (big dW, K = a few thousand steps): two blocks per CU measured best;
         // long rows (tiny dW, K = 10^5 steps): ~3 blocks per CU to cover the HBM stream
-        long sk = a.W <= 26 ? (256 + tiles / 2) / tiles : (768 + tiles - 1) / tiles;
+        long sk = a.W <= 26 ? (512 + tiles / 2) / tiles : (768 + tiles - 1) / tiles;
         const long maxsk = (ksteps + 7) / 8;
         if (sk > maxsk) sk = maxsk;
         if (sk < 1) sk = 1;
@@ -248,11 +263,11 @@ static hipError_t wg9_launch(const WgradArgs& a, hipStream_t s, int ns = 0) {
 
 template <typename T>
 static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
-    const bool i64 = a.Cin >= 64, o64 = a.Cdy >= 64;
-    if (i64 && o64) return wg9_launch<T, 2, 2>(a, s);
-    if (i64) return wg9_launch<T, 2, 1>(a, s);
-    if (o64) return wg9_launch<T, 1, 2>(a, s);
-    return wg9_launch<T, 1, 1>(a, s);
+    // measured (scripts/bench_wgrad.py): narrow co tiles with the taps split over two waves --
+    // many small blocks, two waves per SIMD -- beat 64x64 tiles on every Darknet-19 shape
+    if (a.Cin >= 64) return wg9_launch_ns<T, 2, 1, 2, 2>(a, s);     // 64 ci x 32 co, 4 waves
+    if (a.Cdy >= 64) return wg9_launch_ns<T, 1, 2, 2, 2>(a, s);     // 32 ci x 64 co, 4 waves
+    return wg9_launch_ns<T, 1, 1, 2, 2>(a, s);
 }
 
 // 3x3 only; the window grows with the image row, so this form is for short rows
@@ -281,13 +296,20 @@ hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s)
         case 6: return wg9_launch<half_t, 2, 2>(a, s, 2);
         case 7: return wg9_launch<half_t, 2, 2>(a, s, 3);
         case 8: return wg9_launch<half_t, 2, 2>(a, s, 4);
+        case 9: return wg9_launch_ns<half_t, 2, 2, 2, 2>(a, s);      // two tap groups, 8 waves
+        case 10: return wg9_launch_ns<half_t, 2, 2, 3, 2>(a, s);
+        case 11: return wg9_launch_ns<half_t, 2, 1, 2, 2>(a, s);     // 64 x 32 tiles, 4 waves
+        case 12: return wg9_launch_ns<half_t, 1, 1, 2, 2>(a, s);     // 32 x 32 tiles, 2 waves
+        case 13: return wg9_launch_ns<half_t, 1, 2, 2, 2>(a, s);     // 32 x 64 tiles, 4 waves
+        case 14: return wg9_launch_ns<half_t, 2, 1, 3, 2>(a, s);     // 64 x 32, 3 stages
+        case 16: return wg9_launch_ns<half_t, 2, 1, 2, 1>(a, s);     // 64 x 32 tiles, 2 waves (no tap split)
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a, hipStream_t s) {
-    // measured per shape (scripts/bench_wgrad.py): nine-tap blocks win everywhere except 52x52
-    if (a.taps == 9 && (a.W <= 26 || a.W >= 100)) {
+    // measured per shape (scripts/bench_wgrad.py): nine-tap blocks win on every 3x3 layer
+    if (a.taps == 9) {
         hipError_t e = launch_wgrad9(dtype, a, s);
         if (e != hipErrorOutOfMemory) return e;   // window too large for LDS: fall through
         (void)hipGetLastError();
