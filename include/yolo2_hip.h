@@ -88,7 +88,8 @@ int y2_debug_read(y2_ctx* ctx, int layer, int what, float* dst, void* stream);
 /* Optional measurement aid: bracket every kernel launch of y2_forward / y2_backward with
  * HIP events on the launch stream (the reference only has utils/timer.py wall clocks).
  * Categories: 0 conv fwd (implicit GEMM), 1 conv1 fwd, 2 dgrad, 3 wgrad, 4 conv1 wgrad,
- * 5 BN fwd passes, 6 BN bwd passes, 7 pack/convert.  collect() waits for the events. */
+ * 5 BN fwd passes, 6 BN bwd passes, 7 pack/convert.  on = 1: every launch; on = 2: only the
+ * dominant kernel (categories 0 and 2).  collect() waits for the events. */
 int y2_profile_enable(y2_ctx* ctx, int on);
 int y2_profile_collect(y2_ctx* ctx, double* ms_by_category, int* launches_by_category, int ncat);
 

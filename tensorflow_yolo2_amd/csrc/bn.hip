@@ -18,15 +18,20 @@ namespace y2 {
 // (latency-bound) walk over P partials keeps 4 independent loads in flight per thread
 constexpr int kFinCh = 8, kFinSl = 128;
 
+// sum over the 128 slices of one channel: 3 in-wave shuffle steps (a wave holds 8 channels x 8
+// slices), then 16 per-wave partials through LDS -- two barriers instead of a 7-level tree
 Y2_DEV double fin_block_sum(double v, double (*red)[kFinCh], int sl, int cl) {
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();   // previous use of `red` finished
+    if ((threadIdx.x & 63) < kFinCh) red[wave][cl] = v;
     __syncthreads();
-    red[sl][cl] = v;
-    __syncthreads();
-    for (int s = kFinSl / 2; s > 0; s >>= 1) {
-        if (sl < s) red[sl][cl] += red[sl + s][cl];
-        __syncthreads();
-    }
-    return red[0][cl];
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][cl];
+    return t;
 }
 
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinalizeArgs a) {
@@ -35,51 +40,38 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinalizeArgs a) {
     const int c = blockIdx.x * kFinCh + cl;
     const bool cv = c < a.C;
     const int cc = cv ? c : 0;
-    double n = 0.0, sm = 0.0;
-    {
-        double n4[4] = {0, 0, 0, 0}, s4[4] = {0, 0, 0, 0};
-        int p = sl;
-        for (; p + 3 * kFinSl < a.P; p += 4 * kFinSl) {
+    // ONE pass over the partials, in double, about a per-channel shift s (the first partial's
+    // mean): N = sum k, A = sum k (m - s), B = sum [M2 + k (m - s)^2]; then
+    // mean = s + A/N and M2 = B - A^2/N.  With s within a few sigma of the mean the
+    // subtraction loses nothing in double precision.
+    const double sft = a.P > 0 ? (double)a.part_mean[cc] : 0.0;
+    double n4[4] = {0, 0, 0, 0}, a4[4] = {0, 0, 0, 0}, b4[4] = {0, 0, 0, 0};
+    int p = sl;
+    for (; p + 3 * kFinSl < a.P; p += 4 * kFinSl) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double k = a.part_cnt[p + u * kFinSl];
-                n4[u] += k;
-                s4[u] += k * (double)a.part_mean[(size_t)(p + u * kFinSl) * a.ldp + cc];
-            }
+        for (int u = 0; u < 4; ++u) {
+            const size_t q = (size_t)(p + u * kFinSl) * a.ldp + cc;
+            const double k = a.part_cnt[p + u * kFinSl];
+            const double d = (double)a.part_mean[q] - sft;
+            n4[u] += k;
+            a4[u] += k * d;
+            b4[u] += (double)a.part_m2[q] + k * d * d;
         }
-        for (; p < a.P; p += kFinSl) {
-            const double k = a.part_cnt[p];
-            n4[0] += k;
-            s4[0] += k * (double)a.part_mean[(size_t)p * a.ldp + cc];
-        }
-        n = (n4[0] + n4[1]) + (n4[2] + n4[3]);
-        sm = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
-    const double ntot = fin_block_sum(n, red, sl, cl);
-    const double stot = fin_block_sum(sm, red, sl, cl);
-    const double mean = ntot > 0 ? stot / ntot : 0.0;
-    double m2 = 0.0;
-    {
-        double m4[4] = {0, 0, 0, 0};
-        int p = sl;
-        for (; p + 3 * kFinSl < a.P; p += 4 * kFinSl) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const size_t q = (size_t)(p + u * kFinSl) * a.ldp + cc;
-                const double k = a.part_cnt[p + u * kFinSl];
-                const double d = (double)a.part_mean[q] - mean;
-                m4[u] += (double)a.part_m2[q] + k * d * d;
-            }
-        }
-        for (; p < a.P; p += kFinSl) {
-            const size_t q = (size_t)p * a.ldp + cc;
-            const double k = a.part_cnt[p];
-            const double d = (double)a.part_mean[q] - mean;
-            m4[0] += (double)a.part_m2[q] + k * d * d;
-        }
-        m2 = (m4[0] + m4[1]) + (m4[2] + m4[3]);
+    for (; p < a.P; p += kFinSl) {
+        const size_t q = (size_t)p * a.ldp + cc;
+        const double k = a.part_cnt[p];
+        const double d = (double)a.part_mean[q] - sft;
+        n4[0] += k;
+        a4[0] += k * d;
+        b4[0] += (double)a.part_m2[q] + k * d * d;
     }
-    const double mt = fin_block_sum(m2, red, sl, cl);
+    const double ntot = fin_block_sum((n4[0] + n4[1]) + (n4[2] + n4[3]), red, sl, cl);
+    const double atot = fin_block_sum((a4[0] + a4[1]) + (a4[2] + a4[3]), red, sl, cl);
+    const double btot = fin_block_sum((b4[0] + b4[1]) + (b4[2] + b4[3]), red, sl, cl);
+    const double mean = ntot > 0 ? sft + atot / ntot : 0.0;
+    double mt = ntot > 0 ? btot - atot * atot / ntot : 0.0;
+    if (mt < 0) mt = 0;
     if (sl == 0 && cv) {
         const float var = (float)(ntot > 0 ? mt / ntot : 0.0);
         const float meanf = (float)mean;

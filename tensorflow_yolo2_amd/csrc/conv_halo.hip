@@ -353,6 +353,12 @@ hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t 
         case 63: return halo_pick<T, 4, 2, 2, 2, 64, 2>(a, s);
         case 64: return halo_pick<T, 4, 2, 4, 2, 64, 2>(a, s);       // 512 x 128, 8 waves
         case 65: return halo_pick<T, 4, 2, 3, 2, 128, 2>(a, s);      // 384 x 128, 128-byte chunks
+        case 80: return halo_pick<T, 4, 1, 2, 2, 128, 2>(a, s);      // 256 x 64, 4 waves
+        case 81: return halo_pick<T, 2, 2, 2, 1, 128, 2>(a, s);      // 128 x 64, 4 waves
+        case 82: return halo_pick<T, 4, 2, 2, 1, 128, 2>(a, s);      // 256 x 64, 8 waves
+        case 83: return halo_pick<T, 4, 2, 3, 1, 128, 2>(a, s);      // 384 x 64, 8 waves
+        case 84: return halo_pick<T, 4, 1, 3, 2, 128, 2>(a, s);      // 384 x 64, 4 waves
+        case 85: return halo_pick<T, 4, 2, 4, 1, 128, 2>(a, s);      // 512 x 64, 8 waves
         case 76: return halo_pick<T, 4, 2, 3, 2, 128, 2, 32>(a, s);  // v65 + setprio
         case 77: return halo_pick<T, 4, 2, 2, 2, 64, 2, 32>(a, s);   // v63 + setprio
         case 70: return halo_pick<T, 4, 2, 3, 2, 128, 2, 3>(a, s);   // v65 without loads

@@ -74,6 +74,16 @@ hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H
 hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, int taps, int Cin, int Cout,
                                int Cout_pad, int Kc, int Cin_pad, int Cdy, hipStream_t s);
 hipError_t launch_pack_conv1_weights(int dtype, const float* W, void* wp, hipStream_t s);
+// all layers in one launch: table entry per layer (device copy lives in the workspace)
+struct PackLayer {
+    const float* W;
+    void* wf;
+    void* wd;           // null: no dgrad copy
+    int taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy;
+    int wf_bx, wf_by, wf_blocks, wd_blocks, first_block;
+};
+void pack_layer_plan(PackLayer& L, int first_block);
+hipError_t launch_pack_all(int dtype, const PackLayer* tab_dev, int nlayers, int total_blocks, hipStream_t s);
 hipError_t launch_convert_grad(int dtype, const float* src, void* dst, int M, int C, int ldd, float scale,
                                hipStream_t s);
 hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H, int W, int C, int Cs,

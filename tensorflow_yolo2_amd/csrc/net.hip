@@ -90,8 +90,11 @@ struct y2_ctx {
     size_t part_rows, part_ld;
     size_t total_infer = 0, total_train = 0;
     int dA_cur = 0;
+    size_t o_packtab = 0;
+    std::vector<PackLayer> packtab;
+    int pack_blocks = 0;
     // optional per-launch HIP-event bracketing (bench.py roofline leg)
-    bool prof = false;
+    int prof = 0;   // 0 off, 1 every launch, 2 only the dominant kernel (conv forward + dgrad)
     struct ProfRec { int cat; hipEvent_t a, b; };
     std::vector<ProfRec> prof_recs;
     size_t prof_used = 0;
@@ -107,6 +110,7 @@ struct ProfScope {
     y2_ctx* c; hipStream_t s; int idx = -1;
     ProfScope(y2_ctx* c_, hipStream_t s_, int cat) : c(c_), s(s_) {
         if (!c->prof) return;
+        if (c->prof == 2 && cat != CAT_CONV_FWD && cat != CAT_DGRAD) return;
         if (c->prof_used == c->prof_recs.size()) {
             y2_ctx::ProfRec r; r.cat = cat;
             if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -162,6 +166,7 @@ static void plan(y2_ctx* c) {
     c->o_part_mean = take(max_slab * sizeof(float));
     c->o_part_m2 = take(max_slab * sizeof(float));
     c->o_h32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
+    c->o_packtab = take(c->L.size() * sizeof(PackLayer));
     c->total_infer = off;
     // ---- training-only buffers
     for (size_t l = 0; l < c->L.size(); ++l) c->L[l].dyp = take(c->dy_geom((int)l).bytes(sz));
@@ -283,7 +288,7 @@ void y2_ctx_destroy(y2_ctx* ctx) {
 }
 
 int y2_profile_enable(y2_ctx* c, int on) {
-    c->prof = on != 0;
+    c->prof = on;
     c->prof_used = 0;
     return Y2_OK;
 }
@@ -334,6 +339,26 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
     c->weights_dirty = true; c->fwd_saved = false;
     // borders, guard bands and channel padding must be (and then stay) zero
     HIPCHK(hipMemsetAsync(workspace, 0, need, (hipStream_t)stream));
+    // filter re-pack job table (one launch per step for all layers)
+    c->packtab.clear();
+    int nb = 0;
+    for (size_t l = 0; l < c->L.size(); ++l) {
+        const Layer& y = c->L[l];
+        if (y.first3) continue;
+        PackLayer p{};
+        p.W = params + y.pW;
+        p.wf = c->ws + y.wf;
+        p.wd = (training && l > 0) ? (void*)(c->ws + y.wd) : nullptr;
+        p.taps = y.k * y.k; p.Cin = y.cin; p.Cout = y.cout; p.Cout_pad = y.cout_pad; p.Kc = y.cin_s;
+        p.Cin_pad = y.cin_pad; p.Cdy = y.ldy;
+        pack_layer_plan(p, nb);
+        nb += p.wf_blocks + p.wd_blocks;
+        c->packtab.push_back(p);
+    }
+    c->pack_blocks = nb;
+    if (!c->packtab.empty())
+        HIPCHK(hipMemcpyAsync(c->ws + c->o_packtab, c->packtab.data(), c->packtab.size() * sizeof(PackLayer),
+                              hipMemcpyHostToDevice, (hipStream_t)stream));
     return Y2_OK;
 }
 
@@ -365,16 +390,11 @@ int y2_params_changed(y2_ctx* c) {
 
 static int pack_all_weights(y2_ctx* c, hipStream_t s) {
     PROF(CAT_MISC);
-    for (size_t l = 0; l < c->L.size(); ++l) {
-        const Layer& y = c->L[l];
-        if (y.first3) {
-            HIPCHK(launch_pack_conv1_weights(c->dtype, c->params + y.pW, c->ws + y.wf, s));
-        } else {
-            void* wd = (c->bound_training && l > 0) ? (void*)(c->ws + y.wd) : nullptr;
-            HIPCHK(launch_pack_weights(c->dtype, c->params + y.pW, c->ws + y.wf, wd, y.k * y.k, y.cin, y.cout,
-                                       y.cout_pad, y.cin_s, y.cin_pad, y.ldy, s));
-        }
-    }
+    if (!c->L.empty() && c->L[0].first3)
+        HIPCHK(launch_pack_conv1_weights(c->dtype, c->params + c->L[0].pW, c->ws + c->L[0].wf, s));
+    if (c->pack_blocks > 0)
+        HIPCHK(launch_pack_all(c->dtype, (const PackLayer*)(c->ws + c->o_packtab), (int)c->packtab.size(),
+                               c->pack_blocks, s));
     c->weights_dirty = false;
     return Y2_OK;
 }

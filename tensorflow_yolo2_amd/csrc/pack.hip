@@ -199,6 +199,72 @@ hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, in
     return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------
+// every layer's filters in ONE launch (the per-layer launches were latency-bound:
+// 2 x 21 kernels of ~8 us per step).  A block looks its layer up in a small table.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restrict__ tab, int nlayers) {
+    __shared__ float tile[32][33];
+    int l = 0;
+    const int b = blockIdx.x;
+    while (l + 1 < nlayers && b >= tab[l + 1].first_block) ++l;
+    const PackLayer L = tab[l];
+    const int local = b - L.first_block;
+    const float* __restrict__ W = L.W;
+    if (local < L.wf_blocks) {
+        T* __restrict__ wf = (T*)L.wf;
+        const int bx = local % L.wf_bx, by = (local / L.wf_bx) % L.wf_by, t = local / (L.wf_bx * L.wf_by);
+        const int ci0 = by * 32, co0 = bx * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int r = ty; r < 32; r += 8) {
+            const int ci = ci0 + r, co = co0 + tx;
+            tile[r][tx] = (ci < L.Cin && co < L.Cout) ? W[((size_t)t * L.Cin + ci) * L.Cout + co] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int co = co0 + r, ci = ci0 + tx;
+            if (co < L.Cout_pad && ci < L.Kc) wf[((size_t)co * L.taps + t) * L.Kc + ci] = Elem<T>::from_f32(tile[tx][r]);
+        }
+    } else if (L.wd) {
+        T* __restrict__ wd = (T*)L.wd;
+        const size_t total = (size_t)L.Cin_pad * L.taps * L.Cdy;
+        const size_t i0 = (size_t)(local - L.wf_blocks) * 1024;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = i0 + k * 256 + threadIdx.x;
+            if (i < total) {
+                const int co = (int)(i % L.Cdy);
+                const int t = (int)((i / L.Cdy) % L.taps);
+                const int ci = (int)(i / ((size_t)L.Cdy * L.taps));
+                float v = 0.f;
+                if (ci < L.Cin && co < L.Cout) v = W[((size_t)(L.taps - 1 - t) * L.Cin + ci) * L.Cout + co];
+                wd[i] = Elem<T>::from_f32(v);
+            }
+        }
+    }
+}
+
+void pack_layer_plan(PackLayer& L, int first_block) {
+    L.wf_bx = (L.Cout_pad + 31) / 32;
+    L.wf_by = (L.Kc + 31) / 32;
+    L.wf_blocks = L.wf ? L.wf_bx * L.wf_by * L.taps : 0;
+    const size_t total = (size_t)L.Cin_pad * L.taps * L.Cdy;
+    L.wd_blocks = L.wd ? (int)((total + 1023) / 1024) : 0;
+    L.first_block = first_block;
+}
+
+hipError_t launch_pack_all(int dtype, const PackLayer* tab_dev, int nlayers, int total_blocks, hipStream_t s) {
+    dim3 g(total_blocks), b(256);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(pack_all_kernel<float>, g, b, 0, s, tab_dev, nlayers); break;
+        case 1: hipLaunchKernelGGL(pack_all_kernel<half_t>, g, b, 0, s, tab_dev, nlayers); break;
+        case 2: hipLaunchKernelGGL(pack_all_kernel<bf16_t>, g, b, 0, s, tab_dev, nlayers); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // conv1: W [3][3][3][32] -> wp[co][kh][16]: element kw*4+c (c<3), zero elsewhere
 template <typename T>
 __global__ void pack_conv1_kernel(const float* W, T* wp) {

@@ -165,7 +165,8 @@ class Network:
 
     PROFILE_CATEGORIES = ("conv_fwd", "conv1_fwd", "dgrad", "wgrad", "conv1_wgrad", "bn_fwd", "bn_bwd", "misc")
 
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=1):
+        """0 off, 1 bracket every launch with HIP events, 2 only the conv forward + dgrad launches"""
         check(self.lib.y2_profile_enable(self.h, int(on)))
 
     def profile_collect(self):
