@@ -8,6 +8,9 @@ lib.y2dev_bench_conv.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_float)]
 N = int(os.environ.get("BATCH", "64"))
 shapes = [("L2 64->128 104^2", 104, 64, 128, 3), ("L5 128->256 52^2", 52, 128, 256, 3), ("L8 256->512 26^2", 26, 256, 512, 3),
           ("L13 512->1024 13^2", 13, 512, 1024, 3), ("head 1024->1024 13^2", 13, 1024, 1024, 3), ("L14 1x1 1024->512", 13, 1024, 512, 1)]
+if os.environ.get("SHAPES"):   # "hw,ci,co,k;hw,ci,co,k"
+    shapes = [("%s^2 %s->%s k%s" % tuple(q.split(",")[i] for i in (0, 1, 2, 3)),) + tuple(int(v) for v in q.split(","))
+              for q in os.environ["SHAPES"].split(";")]
 variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,1,2,3,4,5,6,7".split(","))]
 rounds = 3
 for name, hw, ci, co, k in shapes:

@@ -10,6 +10,9 @@ N = int(os.environ.get("BATCH", "64"))
 shapes = [("L1 32->64 208^2", 208, 32, 64, 3), ("L2 64->128 104^2", 104, 64, 128, 3), ("L5 128->256 52^2", 52, 128, 256, 3),
           ("L8 256->512 26^2", 26, 256, 512, 3), ("L13 512->1024 13^2", 13, 512, 1024, 3),
           ("head 1024->1024 13^2", 13, 1024, 1024, 3)]
+if os.environ.get("SHAPES"):   # "hw,ci,co,k;hw,ci,co,k"
+    shapes = [("%s^2 %s->%s k%s" % tuple(q.split(",")[i] for i in (0, 1, 2, 3)),) + tuple(int(v) for v in q.split(","))
+              for q in os.environ["SHAPES"].split(";")]
 cases = [tuple(int(x) for x in c.split(":")) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0:0", "1:0"])]
 for name, hw, ci, co, k in shapes:
     fl = 2.0 * N * hw * hw * k * k * ci * co

@@ -1,17 +1,19 @@
 // Development-only entry points (not part of include/yolo2_hip.h): time one convolution
 // shape with a chosen kernel variant, on buffers allocated here.
 #include <stdio.h>
+#include <stdlib.h>
 #pragma clang diagnostic ignored "-Wunused-value"
 #include <vector>
 #include "kernels.h"
 
 namespace y2 {
 hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc);
-hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp);
 hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s);
 static hipError_t run_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc) {
-    if (variant >= 20 && a.taps == 9) return launch_conv_halo_variant(variant, a, s);
-    if (variant >= 20) variant = 0;
+    if (variant == 100) return launch_conv(1, a, s, bp);   // the product policy
+    if (variant >= 23 && variant < 100 && a.taps == 9) return launch_conv_halo_variant(variant, a, s, bp);
+    if (variant >= 23 && variant < 100) variant = 0;
     return launch_conv_igemm_variant(variant, a, s, bp, bc);
 }
 }
@@ -60,20 +62,28 @@ extern "C" int y2dev_bench_conv(int N, int H, int W, int Cin, int Cout, int k, i
     const int taps = k * k;
     const int cout_pad = (Cout + 255) / 256 * 256;
     void *x = nullptr, *w = nullptr, *y = nullptr;
-    float* bias = nullptr;
-    if (hipMalloc(&x, xpix * Cin * sz) != hipSuccess) return -1;
+    float *bias = nullptr, *part = nullptr;
+    // Y2DEV_BENCH_ROT=n: rotate over n input/output buffer sets (defeats the 256 MB Infinity Cache);
+    // Y2DEV_BENCH_STATS=1: write the batch-norm partial records too
+    const int rot = getenv("Y2DEV_BENCH_ROT") ? atoi(getenv("Y2DEV_BENCH_ROT")) : 1;
+    const bool stats = getenv("Y2DEV_BENCH_STATS") != nullptr;
+    const size_t xbytes = (xpix * Cin * sz + 255) / 256 * 256, ybytes = ((size_t)N * H * W * Cout * sz + 4096 + 255) / 256 * 256;
+    if (hipMalloc(&x, xbytes * rot) != hipSuccess) return -1;
     if (hipMalloc(&w, (size_t)cout_pad * taps * Cin * sz) != hipSuccess) return -1;
-    if (hipMalloc(&y, (size_t)N * H * W * Cout * sz + 4096) != hipSuccess) return -1;
+    if (hipMalloc(&y, ybytes * rot) != hipSuccess) return -1;
     if (hipMalloc(&bias, Cout * 4) != hipSuccess) return -1;
+    const size_t prow = (size_t)(N * H * W + 127) / 128;
+    if (hipMalloc(&part, (prow * (2 * cout_pad + 1)) * 4) != hipSuccess) return -1;
     // pseudo-random f16 contents (finite, sign-varying)
     std::vector<unsigned short> hx(xpix * Cin), hw((size_t)cout_pad * taps * Cin);
     unsigned int r = 12345;
     for (auto& v : hx) { r = r * 1664525u + 1013904223u; v = (unsigned short)(((r >> 16) & 0x83FF) | 0x3800); }
     for (auto& v : hw) { r = r * 1664525u + 1013904223u; v = (unsigned short)(((r >> 16) & 0x83FF) | 0x2C00); }
-    hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+    for (int i = 0; i < rot; ++i) hipMemcpy((char*)x + i * xbytes, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
     hipMemset(bias, 0, Cout * 4);
     ConvArgs a{};
+    if (stats) { a.part_cnt = part; a.part_mean = part + prow; a.part_m2 = part + prow * (1 + cout_pad); }
     a.x = (char*)x + (size_t)(W + 3) * Cin * sz; a.w = w; a.y = y; a.bias = bias;
     a.N = N; a.H = H; a.W = W; a.C = Cin; a.M = N * H * W; a.Cout = Cout; a.ldy = Cout; a.taps = taps;
     hipEvent_t e0, e1;
@@ -82,13 +92,17 @@ extern "C" int y2dev_bench_conv(int N, int H, int W, int Cin, int Cout, int k, i
     for (int i = 0; i < 3; ++i)
         if (run_variant(variant, a, 0, &bp, &bc) != hipSuccess) return -2;
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) run_variant(variant, a, 0, &bp, &bc);
+    for (int i = 0; i < iters; ++i) {
+        a.x = (char*)x + (i % rot) * xbytes + (size_t)(W + 3) * Cin * sz;
+        a.y = (char*)y + (i % rot) * ybytes;
+        run_variant(variant, a, 0, &bp, &bc);
+    }
     hipEventRecord(e1, 0);
     if (hipEventSynchronize(e1) != hipSuccess) return -3;
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / iters;
-    hipFree(x); hipFree(w); hipFree(y); hipFree(bias);
+    hipFree(x); hipFree(w); hipFree(y); hipFree(bias); hipFree(part);
     hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;
 }

@@ -429,6 +429,10 @@ hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, 0, a.P);
     return hipGetLastError();
 }
+hipError_t launch_bn_bwd_dbias(const BnBwdArgs& a, int P, hipStream_t s) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, 1, P);
+    return hipGetLastError();
+}
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s) {
     hipError_t e = hipErrorInvalidValue;
     int P = 0;

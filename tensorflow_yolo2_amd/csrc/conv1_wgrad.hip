@@ -129,4 +129,192 @@ hipError_t launch_conv1_wgrad(int dtype, const Conv1WgradArgs& a, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------
+// Fused form for the pooled first layer: the batch-norm backward APPLY pass
+//   dy = scale * (dz - c1 - xhat*c2),  dz = dA * leaky'(z) at the 2x2 arg-max
+// is computed here, row pair by row pair, straight into the LDS dy images the MFMAs read.
+// dy of the first layer has exactly one consumer (this kernel: there is no dgrad below
+// conv1), so at 416x416x64 the 709 MB tensor is never written nor re-read: the apply pass
+// (886 MB in, 709 MB out) disappears and this kernel streams y + dA (886 MB) instead of dy.
+// Also emits the per-block sum(dy) partials of the conv-bias gradient (psum slot 0).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_wgrad_fused_kernel(Conv1WgradFusedArgs a) {
+    constexpr int SZ = sizeof(T), EPC = 16 / SZ, CPP = 32 / EPC;
+    constexpr int DYP = 32 * SZ, XP = 4 * SZ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wp = (a.W + 15) & ~15;
+    const int dy_bytes = Wp * DYP;
+    const int x_bytes = ((Wp + 4) * XP + 15) & ~15;
+    char* dy_l = smem;                   // [2 rows][Wp][32]
+    char* x_l = smem + 2 * dy_bytes;     // [4 rows][x_bytes]
+    const int x_chunks = x_bytes / 16;
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    const int prs = a.N * Ho;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+
+    // k-padding pixels of the two dy rows: zero, once
+    for (int i = tid; i < 2 * (Wp - a.W) * CPP; i += 256) {
+        const int r = i / ((Wp - a.W) * CPP), j = i % ((Wp - a.W) * CPP);
+        *(u32x4*)(dy_l + r * dy_bytes + a.W * DYP + j * 16) = u32x4{0, 0, 0, 0};
+    }
+    const int ch = tid % CPP, c0 = ch * EPC;
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC], sdy[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = a.scale[c0 + e]; sh[e] = a.shift[c0 + e]; mu[e] = a.mean[c0 + e]; is[e] = a.invstd[c0 + e];
+        c1[e] = a.coef[c0 + e]; c2[e] = a.coef[32 + c0 + e];
+        sdy[e] = 0.f;
+    }
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1[q] = acc2[q] = 0.f;
+
+    for (int pr = blockIdx.x; pr < prs; pr += gridDim.x) {
+        const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho;
+        const char* xrow = (const char*)a.x4 + (bpix(n, h0, 0, a.H, a.W) - (size_t)(a.W + 2)) * XP;
+        const size_t xpitch = (size_t)(a.W + 1) * XP;
+        const char* yrow = (const char*)a.y + ((size_t)(n * a.H + h0) * a.W) * DYP;
+        const char* darow = (const char*)a.dA + ((size_t)(n * Ho + ho) * Wo) * DYP;
+        __syncthreads();   // previous row pair fully consumed
+        for (int kh = 0; kh < 4; ++kh)
+            for (int i0 = w * 64; i0 < x_chunks; i0 += 256) {
+                const int i = i0 + lane;
+                if (i < x_chunks) glds16(xrow + kh * xpitch + (size_t)i * 16, x_l + kh * x_bytes + i0 * 16);
+            }
+        for (int item = tid; item < Wo * CPP; item += 256) {
+            const int wo = item / CPP;
+            Chunk<T> dav = ld_chunk<T>(darow + (size_t)item * 16);
+            Chunk<T> yv[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                yv[d] = ld_chunk<T>(yrow + ((size_t)(d >> 1) * a.W + 2 * wo + (d & 1)) * DYP + ch * 16);
+            int arg[EPC];
+            float zmax[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                arg[e] = 0;
+                zmax[e] = -INFINITY;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float act = leaky01(Elem<T>::to_f32(yv[d].v[e]) * sc[e] + sh[e]);
+                    if (act > zmax[e]) {
+                        zmax[e] = act;
+                        arg[e] = d;
+                    }
+                }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float yy = Elem<T>::to_f32(yv[d].v[e]);
+                    const float z = yy * sc[e] + sh[e];
+                    const float dz = (arg[e] == d) ? Elem<T>::to_f32(dav.v[e]) * leaky01_slope(z) : 0.f;
+                    const float xh = (yy - mu[e]) * is[e];
+                    const float dy = sc[e] * (dz - c1[e] - xh * c2[e]);
+                    o.v[e] = Elem<T>::from_f32(dy);
+                    sdy[e] += dy;
+                }
+                st_chunk<T>(dy_l + (d >> 1) * dy_bytes + (size_t)(2 * wo + (d & 1)) * DYP + ch * 16, o);
+            }
+        }
+        __syncthreads();   // LDS-DMA drained (vmcnt(0)) and the dy images complete
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const char* dyr = dy_l + r * dy_bytes;
+            for (int s = w; s * 16 < a.W; s += 4) {
+                const int w0 = s * 16;
+                if constexpr (SZ == 2) {
+                    const int pix = w0 + 8 * hh + qq;
+                    const char* pb = dyr + pix * DYP + (16 * g1 + 4 * pp) * 2;
+                    typename Elem<T>::frag fb = tr_frag<T>(pb, pb + 4 * DYP);
+                    const char* pa1 = x_l + (r + g1) * x_bytes + (pix + pp) * XP;
+                    typename Elem<T>::frag fa1 = tr_frag<T>(pa1, pa1 + 4 * XP);
+                    const char* pa2 = x_l + (r + 2) * x_bytes + (pix + pp) * XP;
+                    typename Elem<T>::frag fa2 = tr_frag<T>(pa2, pa2 + 4 * XP);
+                    mma32(acc1, fa1, fb);
+                    mma32(acc2, fa2, fb);
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        const int pix = w0 + 2 * k2 + hh;
+                        const float b = *(const float*)(dyr + pix * DYP + r32 * 4);
+                        const float a1 = *(const float*)(x_l + (r + (r32 >> 4)) * x_bytes + pix * XP + (r32 & 15) * 4);
+                        const float a2 = *(const float*)(x_l + (r + 2) * x_bytes + pix * XP + (r32 & 15) * 4);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b, acc2, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- sum(dy) of the block -> psum slot 0 (conv-bias gradient partial)
+    __syncthreads();
+    float* red2 = (float*)smem;   // [256][EPC]
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red2[tid * EPC + e] = sdy[e];
+    __syncthreads();
+    if (tid < 32) {
+        const int chs = tid / EPC, e = tid % EPC;
+        float t = 0.f;
+        for (int j = 0; j < 256 / CPP; ++j) t += red2[(j * CPP + chs) * EPC + e];
+        a.psum[((size_t)blockIdx.x * 2) * 32 + tid] = t;
+    }
+    // ---- reduce the 4 waves through LDS, then one atomic per (tap, c, co)
+    __syncthreads();
+    float* red = (float*)smem;   // [4 waves][48 rows][32 co]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int r = acc_row(q, hh);
+        red[(w * 48 + r) * 32 + r32] = acc1[q];
+        if (r < 16) red[(w * 48 + 32 + r) * 32 + r32] = acc2[q];
+    }
+    __syncthreads();
+    for (int i = tid; i < 48 * 32; i += 256) {
+        const int r = i >> 5, co = i & 31;
+        const int kh = r >> 4, e = r & 15, kw = e >> 2, c = e & 3;
+        if (kw < 3 && c < 3) {
+            const float v = red[i] + red[48 * 32 + i] + red[2 * 48 * 32 + i] + red[3 * 48 * 32 + i];
+            atomicAdd(a.dW + ((kh * 3 + kw) * 3 + c) * 32 + co, v * a.inv_grad_scale);
+        }
+    }
+}
+
+template <typename T>
+static hipError_t c1wgf_T(const Conv1WgradFusedArgs& a, hipStream_t s, int* nblocks) {
+    constexpr int SZ = sizeof(T);
+    const int Wp = (a.W + 15) & ~15;
+    size_t lds = 2 * (size_t)Wp * 32 * SZ + 4 * (size_t)((((Wp + 4) * 4 * SZ) + 15) & ~15);
+    const size_t red = 4 * 48 * 32 * sizeof(float);
+    if (lds < red) lds = red;
+    if (lds > 160 * 1024) return hipErrorOutOfMemory;
+    auto kern = conv1_wgrad_fused_kernel<T>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int prs = a.N * (a.H / 2);
+    const int nb = prs < 512 ? prs : 512;
+    *nblocks = nb;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy) { return pool && (H % 2) == 0 && (W % 2) == 0 && ldy == 32; }
+
+hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s, int* nblocks) {
+    switch (dtype) {
+        case 0: return c1wgf_T<float>(a, s, nblocks);
+        case 1: return c1wgf_T<half_t>(a, s, nblocks);
+        case 2: return c1wgf_T<bf16_t>(a, s, nblocks);
+    }
+    return hipErrorInvalidValue;
+}
+
 }  // namespace y2

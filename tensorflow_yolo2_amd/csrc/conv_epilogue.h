@@ -3,10 +3,11 @@
 //   1. adds the bias, rounds to T and packs 4 couts per LDS store into a wave-private
 //      [pixel][cout] patch (16-byte row pad: conflict-light ds_write_b64/b128),
 //   2. re-reads whole 16-byte chunks per pixel row and stores full lines to y[M][ldy],
-//   3. (training) reduces per-channel batch-norm partials of the values AS STORED:
-//      per-wave two-pass (sum -> mean, squared deviations), Chan-merged over the WP
-//      waves of the block -> one (count, mean, M2) record per block and channel.
+//   3. (training) reduces per-channel batch-norm partials of the values AS STORED: per lane
+//      sums of (y - bias) and (y - bias)^2 over its rows, added over the block through LDS
+//      -> one (count, mean, M2) record per block and channel.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -25,7 +26,7 @@ struct EpiCfg {
 
 // must be entered by ALL threads of the block, after a barrier that retires every read
 // of the staging buffers (the patch aliases them)
-template <typename T, int WP, int WC, int TP, int TC>
+template <typename T, int WP, int WC, int TP, int TC, int EABL = 0>
 Y2_DEV void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TC][TP], char* smem, int w, int lane, int m0, int n0,
                           int pt, int ct) {
     typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
@@ -55,94 +56,83 @@ Y2_DEV void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TC][TP], char* smem, 
             }
         }
     }
-    __syncthreads();
+    if (EABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
 
     constexpr int EPC = 16 / SZ;        // elements per chunk
     constexpr int CPR = TC * 32 / EPC;  // chunks per pixel row
     constexpr int RPIe = 64 / CPR;      // pixel rows per read instruction
     constexpr int NIT = TP * 32 / RPIe;
+    static_assert(Cfg::EPW >= 2 * 64 * EPC * 4, "statistics scratch must fit the wave's patch");
     const int ch = lane % CPR, prow0 = lane / CPR;
     const int mw0 = m0 + wp * TP * 32;  // first pixel of this wave
     const int cch = cw0 + ch * EPC;     // first cout of this lane's chunk
-    float vals[NIT][EPC];
-    float s[EPC];
+    const bool stats = a.part_mean != nullptr;
+    // Statistics of the values AS STORED, as sums of d = y - bias and of d^2: one pass, no value
+    // buffer; the bias is a free pivot (it removes the offset the filter response rides on).
+    float piv[EPC], s1[EPC], s2[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int prow = it * RPIe + prow0;
-        Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
-        const bool pv = (mw0 + prow) < a.M;
-        if (pv && cch < a.ldy) st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            vals[it][e] = pv ? Elem<T>::to_f32(c.v[e]) : 0.f;
-            s[e] += vals[it][e];
-        }
+    for (int e = 0; e < EPC; ++e) {
+        piv[e] = (stats && a.bias && cch + e < a.Cout) ? a.bias[cch + e] : 0.f;
+        s1[e] = 0.f;
+        s2[e] = 0.f;
     }
-    if (a.part_mean) {
-        int cntw = a.M - mw0;
-        cntw = cntw < 0 ? 0 : (cntw > TP * 32 ? TP * 32 : cntw);
-        const float inv = cntw > 0 ? 1.0f / (float)cntw : 0.f;
-        float mean[EPC], m2[EPC];
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-#pragma unroll
-            for (int msk = CPR; msk < 64; msk <<= 1) s[e] = wave_sum_xor(s[e], msk);
-            mean[e] = s[e] * inv;
-            m2[e] = 0.f;
-        }
+    auto sweep = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const bool pv = (mw0 + it * RPIe + prow0) < a.M;
+            const int prow = it * RPIe + prow0;
+            Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
+            const bool pv = FULL || (mw0 + prow) < a.M;
+            if (!(EABL & 1) && pv && cch < a.ldy) st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
+            if (stats) {
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const float d = pv ? vals[it][e] - mean[e] : 0.f;
-                m2[e] += d * d;
+                for (int e = 0; e < EPC; ++e) {
+                    float d = Elem<T>::to_f32(c.v[e]) - piv[e];
+                    if (!FULL) d = pv ? d : 0.f;
+                    s1[e] += d;
+                    s2[e] = fmaf(d, d, s2[e]);
+                }
             }
         }
+    };
+    if (mw0 + TP * 32 <= a.M) sweep(std::true_type{});   // wave-uniform
+    else sweep(std::false_type{});
+    if (stats) {
+        // lane partials -> the wave's own patch (dead now: a wave's LDS operations retire in order),
+        // then one thread per block channel adds the RPIe row groups of the WP waves
+        float* sw = (float*)ew;   // [2][64][EPC]
 #pragma unroll
-        for (int e = 0; e < EPC; ++e)
-#pragma unroll
-            for (int msk = CPR; msk < 64; msk <<= 1) m2[e] = wave_sum_xor(m2[e], msk);
-        // combine the WP waves that share these channels (Chan's parallel update)
-        float* st = (float*)(smem + NW * Cfg::EPW);
-        if (prow0 == 0) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                st[(w * TC * 32 + ch * EPC + e) * 2 + 0] = mean[e];
-                st[(w * TC * 32 + ch * EPC + e) * 2 + 1] = m2[e];
-            }
+        for (int e = 0; e < EPC; e += 4) {
+            *(f32x4*)(sw + lane * EPC + e) = f32x4{s1[e], s1[e + 1], s1[e + 2], s1[e + 3]};
+            *(f32x4*)(sw + 64 * EPC + lane * EPC + e) = f32x4{s2[e], s2[e + 1], s2[e + 2], s2[e + 3]};
         }
         __syncthreads();
-        if (wp == 0 && prow0 == 0) {
+        int cb = a.M - m0;
+        cb = cb > BP ? BP : cb;
+        const float inv = 1.0f / (float)cb;
+        for (int c = threadIdx.x; c < Cfg::BC; c += NW * 64) {
+            const int wcs = c / (TC * 32), cl = c % (TC * 32);
+            const int idx = (cl / EPC) * EPC + (cl % EPC);   // = cl: [chunk][element]
+            float S1 = 0.f, S2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                float n_acc = 0.f, mean_acc = 0.f, m2_acc = 0.f;
-                for (int k = 0; k < WP; ++k) {
-                    int cntk = a.M - (m0 + k * TP * 32);
-                    cntk = cntk < 0 ? 0 : (cntk > TP * 32 ? TP * 32 : cntk);
-                    if (cntk == 0) continue;
-                    const int wk = k * WC + wc;
-                    const float mk = st[(wk * TC * 32 + ch * EPC + e) * 2 + 0];
-                    const float vk = st[(wk * TC * 32 + ch * EPC + e) * 2 + 1];
-                    const float nn = n_acc + (float)cntk;
-                    const float dlt = mk - mean_acc;
-                    mean_acc += dlt * ((float)cntk / nn);
-                    m2_acc += vk + dlt * dlt * (n_acc * (float)cntk / nn);
-                    n_acc = nn;
-                }
-                const int co = cch + e;
-                if (co < a.ldy) {
-                    a.part_mean[(size_t)pt * a.ldy + co] = mean_acc;
-                    a.part_m2[(size_t)pt * a.ldy + co] = m2_acc;
+            for (int k = 0; k < WP; ++k) {
+                const float* q = (const float*)(smem + (k * WC + wcs) * Cfg::EPW);
+#pragma unroll
+                for (int g = 0; g < RPIe; ++g) {
+                    S1 += q[g * CPR * EPC + idx];
+                    S2 += q[64 * EPC + g * CPR * EPC + idx];
                 }
             }
+            const int co = n0 + c;
+            if (co < a.ldy) {
+                const float md = S1 * inv;
+                const float pb = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+                a.part_mean[(size_t)pt * a.ldy + co] = pb + md;
+                a.part_m2[(size_t)pt * a.ldy + co] = fmaxf(S2 - S1 * md, 0.f);
+            }
         }
-        if (threadIdx.x == 0 && ct == 0) {
-            int cb = a.M - m0;
-            a.part_cnt[pt] = (float)(cb > BP ? BP : cb);
-        }
+        if (threadIdx.x == 0 && ct == 0) a.part_cnt[pt] = (float)cb;
     }
 }
 

@@ -13,6 +13,8 @@
 // and the L2 sees long contiguous reads instead of per-tap gathers.  Only the filter
 // tile streams per (tap, chunk) step, through an NSB-deep global_load_lds ring with a
 // counted vmcnt and raw s_barrier (loads stay in flight across the barrier).
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.h"
 #include "conv_epilogue.h"
 #include "kernels.h"
@@ -239,6 +241,7 @@ template <typename T, int WP, int WC, int TP, int TC, int BKB, int NSB, bool ADB
 static hipError_t halo_launch(const ConvArgs& a, hipStream_t s) {
     typedef HaloCfg<T, WP, WC, TP, TC, BKB, NSB, ADB> Cfg;
     typedef EpiCfg<T, WP, WC, TP, TC> Epi;
+    if ((a.C * (int)sizeof(T)) % BKB != 0) return hipErrorInvalidValue;
     const int arows = halo_rows(a.H, a.W, Cfg::BP, Cfg::RPI);
     size_t lds = (size_t)Cfg::NA * arows * BKB + (size_t)NSB * Cfg::BSTAGE;
     if (lds < (size_t)Epi::LDS) lds = Epi::LDS;
@@ -279,7 +282,11 @@ static hipError_t halo_T(const ConvArgs& a, hipStream_t s, int* bp) {
         hipError_t e = hipErrorOutOfMemory;
         if (a.W <= 13 && a.M >= 384 * 8) {
             *bp = 384;
-            e = k128 ? halo_pick<T, 4, 2, 3, 2, 128, 2>(a, s) : halo_pick<T, 4, 2, 3, 2, 64, 2>(a, s);
+            // 384 x 128 tiles would leave half the CUs idle when Cout <= 512 (the 1024 -> 512 dgrads
+            // at 13x13: 116 blocks); 384 x 64 tiles fill them (232 blocks, 184 -> 133 us)
+            const bool narrow = ((a.M + 383) / 384) * ((a.Cout + 127) / 128) < 160 && k128;
+            if (narrow) e = halo_pick<T, 4, 2, 3, 1, 128, 2>(a, s);
+            else e = k128 ? halo_pick<T, 4, 2, 3, 2, 128, 2>(a, s) : halo_pick<T, 4, 2, 3, 2, 64, 2>(a, s);
         } else if (a.M >= 256 * 8) {
             *bp = 256;
             e = halo_pick<T, 4, 2, 2, 2, 64, 2>(a, s);
@@ -305,6 +312,27 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* bp
     return hipErrorInvalidValue;
 }
 
+hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp);
+// development aid: Y2DEV_CONV="W:Cout:variant,..." forces a halo variant for (W, Cout) (f16 only)
+static int dev_rule(int W, int Cout) {
+    static int n = -1;
+    static int rules[32][3];
+    if (n < 0) {
+        n = 0;
+        const char* e = getenv("Y2DEV_CONV");
+        while (e && *e && n < 32) {
+            int w, c, v, used = 0;
+            if (sscanf(e, "%d:%d:%d%n", &w, &c, &v, &used) != 3) break;
+            rules[n][0] = w; rules[n][1] = c; rules[n][2] = v; ++n;
+            e += used;
+            if (*e == ',') ++e;
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (rules[i][0] == W && rules[i][1] == Cout) return rules[i][2];
+    return -1;
+}
+
 // Kernel policy (measured on MI355X, scripts/bench_conv.py): the halo image wins where the
 // image rows are short (13x13, 26x26: the nine taps share ~85 % of their rows); on the large
 // feature maps the image would take a whole CU's LDS, and the per-tap kernel with 8 waves wins.
@@ -312,73 +340,90 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* bp
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels) {
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
-    if (a.taps == 9 && a.W <= 52) e = launch_conv_halo(dtype, a, s, &bp);
+    const int forced = (a.taps == 9 && dtype == 1) ? dev_rule(a.W, a.Cout) : -1;
+    if (forced >= 0) e = launch_conv_halo_variant(forced, a, s, &bp);
+    else if (a.taps == 9 && a.W <= 52) e = launch_conv_halo(dtype, a, s, &bp);
     else e = launch_conv_igemm(dtype, a, s);
     if (block_pixels) *block_pixels = bp;
     return e;
 }
 
 // development variants (f16) for scripts/bench_conv.py
-hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s) {
+#define HV(id, WP, TPARGS...) \
+    case id: if (bp) *bp = halo_bp<WP, TPARGS>(); return halo_pick<T, WP, TPARGS>(a, s);
+template <int WP, int WC, int TP, int TC, int BKB, int NSB, int ABL = 0>
+static constexpr int halo_bp() { return WP * TP * 32; }
+hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp) {
     typedef half_t T;
     switch (variant) {
-        case 20: return halo_pick<T, 2, 2, 2, 2, 128, 3>(a, s);
-        case 21: return halo_pick<T, 2, 2, 2, 2, 128, 2>(a, s);
-        case 22: return halo_pick<T, 2, 4, 2, 1, 128, 3>(a, s);
-        case 23: return halo_pick<T, 2, 4, 2, 1, 128, 2>(a, s);
-        case 24: return halo_pick<T, 4, 2, 2, 2, 128, 3>(a, s);
-        case 25: return halo_pick<T, 2, 4, 2, 2, 128, 3>(a, s);
-        case 26: return halo_pick<T, 2, 4, 2, 2, 128, 2>(a, s);
-        case 27: return halo_pick<T, 2, 2, 2, 2, 128, 4>(a, s);
-        case 28: return halo_pick<T, 2, 2, 2, 2, 64, 3>(a, s);
-        case 29: return halo_pick<T, 2, 2, 2, 2, 64, 2>(a, s);
-        case 40: return halo_pick<T, 2, 2, 2, 2, 64, 4>(a, s);
-        case 41: return halo_pick<T, 2, 4, 2, 1, 64, 3>(a, s);
-        case 42: return halo_pick<T, 4, 1, 1, 4, 128, 2>(a, s);   // wave = 32 px x 128 co
-        case 43: return halo_pick<T, 1, 4, 4, 1, 128, 2>(a, s);   // wave = 128 px x 32 co
+        HV(86, 4, 2, 4, 1, 64, 2)       // 512 x 64, 8 waves, 64-byte chunks
+        HV(87, 4, 2, 3, 1, 64, 2)       // 384 x 64
+        HV(88, 4, 2, 2, 1, 64, 2)       // 256 x 64
+        HV(89, 4, 1, 4, 1, 128, 2)      // 512 x 32, 4 waves
+        HV(90, 8, 1, 2, 1, 128, 2)      // 512 x 32, 8 waves
+        HV(91, 8, 1, 4, 1, 128, 2)      // 1024 x 32, 8 waves
+        HV(92, 8, 1, 2, 1, 64, 2)
+        HV(93, 8, 1, 4, 1, 64, 2)
+        HV(94, 4, 2, 4, 2, 128, 2)      // 512 x 128, 128-byte chunks
+        HV(95, 8, 1, 2, 2, 128, 2)      // 512 x 64, 8 waves of 64x64
+        HV(96, 8, 1, 2, 2, 64, 2)
+        HV(20, 2, 2, 2, 2, 128, 3)
+        HV(21, 2, 2, 2, 2, 128, 2)
+        HV(22, 2, 4, 2, 1, 128, 3)
+        HV(23, 2, 4, 2, 1, 128, 2)
+        HV(24, 4, 2, 2, 2, 128, 3)
+        HV(25, 2, 4, 2, 2, 128, 3)
+        HV(26, 2, 4, 2, 2, 128, 2)
+        HV(27, 2, 2, 2, 2, 128, 4)
+        HV(28, 2, 2, 2, 2, 64, 3)
+        HV(29, 2, 2, 2, 2, 64, 2)
+        HV(40, 2, 2, 2, 2, 64, 4)
+        HV(41, 2, 4, 2, 1, 64, 3)
+        HV(42, 4, 1, 1, 4, 128, 2)   // wave = 32 px x 128 co
+        HV(43, 1, 4, 4, 1, 128, 2)   // wave = 128 px x 32 co
         // ablations of variant 29 (128x128, 64-byte chunks, NSB 2: the product choice)
-        case 50: return halo_pick<T, 2, 2, 2, 2, 64, 2, 3>(a, s);    // no loads
-        case 51: return halo_pick<T, 2, 2, 2, 2, 64, 2, 4>(a, s);    // no MFMA
-        case 52: return halo_pick<T, 2, 2, 2, 2, 64, 2, 8>(a, s);    // no LDS reads
-        case 53: return halo_pick<T, 2, 2, 2, 2, 64, 2, 11>(a, s);   // MFMA only
-        case 54: return halo_pick<T, 2, 2, 2, 2, 64, 2, 12>(a, s);   // loads only
-        case 55: return halo_pick<T, 2, 2, 2, 2, 64, 2, 16>(a, s);   // no epilogue
-        case 56: return halo_pick<T, 2, 2, 2, 2, 64, 2, 2>(a, s);    // no B loads
-        case 57: return halo_pick<T, 2, 2, 3, 2, 64, 2>(a, s);       // 192 x 128 tile
-        case 58: return halo_pick<T, 2, 2, 4, 2, 64, 2>(a, s);       // 256 x 128 tile, 4 waves
-        case 59: return halo_pick<T, 2, 2, 2, 4, 64, 2>(a, s);       // 128 x 256 tile, 4 waves
-        case 60: return halo_pick<T, 4, 2, 3, 2, 64, 3>(a, s);       // 384 x 128, 8 waves
-        case 61: return halo_pick<T, 4, 2, 3, 2, 64, 2>(a, s);
-        case 62: return halo_pick<T, 4, 2, 2, 2, 64, 3>(a, s);       // 256 x 128, 8 waves
-        case 63: return halo_pick<T, 4, 2, 2, 2, 64, 2>(a, s);
-        case 64: return halo_pick<T, 4, 2, 4, 2, 64, 2>(a, s);       // 512 x 128, 8 waves
-        case 65: return halo_pick<T, 4, 2, 3, 2, 128, 2>(a, s);      // 384 x 128, 128-byte chunks
-        case 80: return halo_pick<T, 4, 1, 2, 2, 128, 2>(a, s);      // 256 x 64, 4 waves
-        case 81: return halo_pick<T, 2, 2, 2, 1, 128, 2>(a, s);      // 128 x 64, 4 waves
-        case 82: return halo_pick<T, 4, 2, 2, 1, 128, 2>(a, s);      // 256 x 64, 8 waves
-        case 83: return halo_pick<T, 4, 2, 3, 1, 128, 2>(a, s);      // 384 x 64, 8 waves
-        case 84: return halo_pick<T, 4, 1, 3, 2, 128, 2>(a, s);      // 384 x 64, 4 waves
-        case 85: return halo_pick<T, 4, 2, 4, 1, 128, 2>(a, s);      // 512 x 64, 8 waves
-        case 76: return halo_pick<T, 4, 2, 3, 2, 128, 2, 32>(a, s);  // v65 + setprio
-        case 77: return halo_pick<T, 4, 2, 2, 2, 64, 2, 32>(a, s);   // v63 + setprio
-        case 70: return halo_pick<T, 4, 2, 3, 2, 128, 2, 3>(a, s);   // v65 without loads
-        case 71: return halo_pick<T, 4, 2, 3, 2, 128, 2, 4>(a, s);   // v65 without MFMA
-        case 72: return halo_pick<T, 4, 2, 3, 2, 128, 2, 2>(a, s);   // v65 without filter loads
-        case 73: return halo_pick<T, 4, 2, 3, 2, 128, 2, 1>(a, s);   // v65 without image loads
-        case 74: return halo_pick<T, 4, 2, 3, 2, 128, 2, 16>(a, s);  // v65 without epilogue
-        case 75: return halo_pick<T, 4, 2, 3, 2, 128, 2, 8>(a, s);   // v65 without LDS reads
-        case 66: return halo_pick<T, 2, 4, 3, 1, 64, 2>(a, s);       // 192 x 128, 8 waves of 96x32
-        case 67: return halo_pick<T, 4, 2, 1, 2, 64, 2>(a, s);       // 128 x 128, 8 waves of 32x64
+        HV(50, 2, 2, 2, 2, 64, 2, 3)    // no loads
+        HV(51, 2, 2, 2, 2, 64, 2, 4)    // no MFMA
+        HV(52, 2, 2, 2, 2, 64, 2, 8)    // no LDS reads
+        HV(53, 2, 2, 2, 2, 64, 2, 11)   // MFMA only
+        HV(54, 2, 2, 2, 2, 64, 2, 12)   // loads only
+        HV(55, 2, 2, 2, 2, 64, 2, 16)   // no epilogue
+        HV(56, 2, 2, 2, 2, 64, 2, 2)    // no B loads
+        HV(57, 2, 2, 3, 2, 64, 2)       // 192 x 128 tile
+        HV(58, 2, 2, 4, 2, 64, 2)       // 256 x 128 tile, 4 waves
+        HV(59, 2, 2, 2, 4, 64, 2)       // 128 x 256 tile, 4 waves
+        HV(60, 4, 2, 3, 2, 64, 3)       // 384 x 128, 8 waves
+        HV(61, 4, 2, 3, 2, 64, 2)
+        HV(62, 4, 2, 2, 2, 64, 3)       // 256 x 128, 8 waves
+        HV(63, 4, 2, 2, 2, 64, 2)
+        HV(64, 4, 2, 4, 2, 64, 2)       // 512 x 128, 8 waves
+        HV(65, 4, 2, 3, 2, 128, 2)      // 384 x 128, 128-byte chunks
+        HV(80, 4, 1, 2, 2, 128, 2)      // 256 x 64, 4 waves
+        HV(81, 2, 2, 2, 1, 128, 2)      // 128 x 64, 4 waves
+        HV(82, 4, 2, 2, 1, 128, 2)      // 256 x 64, 8 waves
+        HV(83, 4, 2, 3, 1, 128, 2)      // 384 x 64, 8 waves
+        HV(84, 4, 1, 3, 2, 128, 2)      // 384 x 64, 4 waves
+        HV(85, 4, 2, 4, 1, 128, 2)      // 512 x 64, 8 waves
+        HV(76, 4, 2, 3, 2, 128, 2, 32)  // v65 + setprio
+        HV(77, 4, 2, 2, 2, 64, 2, 32)   // v63 + setprio
+        HV(70, 4, 2, 3, 2, 128, 2, 3)   // v65 without loads
+        HV(71, 4, 2, 3, 2, 128, 2, 4)   // v65 without MFMA
+        HV(72, 4, 2, 3, 2, 128, 2, 2)   // v65 without filter loads
+        HV(73, 4, 2, 3, 2, 128, 2, 1)   // v65 without image loads
+        HV(74, 4, 2, 3, 2, 128, 2, 16)  // v65 without epilogue
+        HV(75, 4, 2, 3, 2, 128, 2, 8)   // v65 without LDS reads
+        HV(66, 2, 4, 3, 1, 64, 2)       // 192 x 128, 8 waves of 96x32
+        HV(67, 4, 2, 1, 2, 64, 2)       // 128 x 128, 8 waves of 32x64
         // ablations of variant 24 (256x128, 8 waves, NSB 3)
-        case 30: return halo_pick<T, 4, 2, 2, 2, 128, 3, 3>(a, s);    // no loads
-        case 31: return halo_pick<T, 4, 2, 2, 2, 128, 3, 4>(a, s);    // no MFMA
-        case 32: return halo_pick<T, 4, 2, 2, 2, 128, 3, 8>(a, s);    // no LDS reads
-        case 33: return halo_pick<T, 4, 2, 2, 2, 128, 3, 16>(a, s);   // no epilogue
-        case 34: return halo_pick<T, 4, 2, 2, 2, 128, 3, 11>(a, s);   // MFMA only
-        case 35: return halo_pick<T, 4, 2, 2, 2, 128, 3, 27>(a, s);   // MFMA only, no epilogue
-        case 36: return halo_pick<T, 4, 2, 2, 2, 128, 3, 12>(a, s);   // loads only
-        case 37: return halo_pick<T, 4, 2, 2, 2, 128, 3, 1>(a, s);    // no A loads
-        case 38: return halo_pick<T, 4, 2, 2, 2, 128, 3, 2>(a, s);    // no B loads
+        HV(30, 4, 2, 2, 2, 128, 3, 3)    // no loads
+        HV(31, 4, 2, 2, 2, 128, 3, 4)    // no MFMA
+        HV(32, 4, 2, 2, 2, 128, 3, 8)    // no LDS reads
+        HV(33, 4, 2, 2, 2, 128, 3, 16)   // no epilogue
+        HV(34, 4, 2, 2, 2, 128, 3, 11)   // MFMA only
+        HV(35, 4, 2, 2, 2, 128, 3, 27)   // MFMA only, no epilogue
+        HV(36, 4, 2, 2, 2, 128, 3, 12)   // loads only
+        HV(37, 4, 2, 2, 2, 128, 3, 1)    // no A loads
+        HV(38, 4, 2, 2, 2, 128, 3, 2)    // no B loads
     }
     return hipErrorInvalidValue;
 }

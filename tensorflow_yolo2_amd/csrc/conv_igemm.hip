@@ -196,8 +196,16 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
         ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
     }
     __syncthreads();
-
-    conv_epilogue<T, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    if (ABL & 16) {   // dev: skip the epilogue (keep the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) t += acc[i][j][0] + acc[i][j][7];
+        if (t == 123.456f) ((float*)a.y)[0] = t;
+        return;
+    }
+    conv_epilogue<T, WP, WC, TP, TC, (ABL >> 6)>(a, acc, smem, w, lane, m0, n0, pt, ct);
 }
 
 template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0>
@@ -264,6 +272,25 @@ hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t
         case 6: *bp = 128; *bc = 256; return launch_cfg<T, 2, 4, 2, 2, 128, 3>(a, s);
         case 7: *bp = 128; *bc = 128; return launch_cfg<T, 2, 4, 2, 1, 128, 3>(a, s);
         case 8: *bp = 256; *bc = 256; return launch_cfg<T, 4, 2, 2, 4, 128, 2>(a, s);
+        // the Cout <= 64 product tile (64-byte chunks) and its ablations
+        case 17: *bp = 256; *bc = 64; return launch_cfg<T, 4, 1, 2, 2, 64, 2>(a, s);
+        case 18: *bp = 256; *bc = 64; return launch_cfg<T, 4, 1, 2, 2, 64, 2, 3>(a, s);    // no loads
+        case 19: *bp = 256; *bc = 64; return launch_cfg<T, 4, 1, 2, 2, 64, 2, 16>(a, s);   // no epilogue
+        case 20: *bp = 256; *bc = 64; return launch_cfg<T, 4, 1, 2, 2, 64, 2, 64>(a, s);   // no global stores
+        case 21: *bp = 256; *bc = 64; return launch_cfg<T, 4, 1, 2, 2, 64, 2, 128>(a, s);  // wave-level sync in the epilogue
+        case 22: *bp = 256; *bc = 64; return launch_cfg<T, 4, 1, 2, 2, 64, 2, 67>(a, s);   // no loads, no stores
+        // smaller / more numerous tiles for the small-K, large-M layers
+        case 200: *bp = 128; *bc = 64; return launch_cfg<T, 2, 2, 2, 1, 64, 2>(a, s);
+        case 201: *bp = 256; *bc = 64; return launch_cfg<T, 4, 2, 2, 1, 64, 2>(a, s);
+        case 202: *bp = 128; *bc = 64; return launch_cfg<T, 2, 2, 2, 1, 128, 2>(a, s);
+        case 203: *bp = 256; *bc = 64; return launch_cfg<T, 4, 2, 2, 1, 128, 2>(a, s);
+        case 204: *bp = 128; *bc = 64; return launch_cfg<T, 4, 1, 1, 2, 64, 2>(a, s);
+        case 205: *bp = 128; *bc = 64; return launch_cfg<T, 4, 1, 1, 2, 128, 2>(a, s);
+        case 206: *bp = 256; *bc = 64; return launch_cfg<T, 4, 1, 2, 2, 128, 2>(a, s);   // product, Cout <= 64
+        case 207: *bp = 128; *bc = 128; return launch_cfg<T, 2, 4, 2, 1, 64, 2>(a, s);  // product, Cout > 64
+        case 208: *bp = 128; *bc = 128; return launch_cfg<T, 2, 4, 2, 1, 128, 2>(a, s);
+        case 209: *bp = 256; *bc = 32; return launch_cfg<T, 4, 1, 2, 1, 128, 2>(a, s);   // product, Cout <= 32
+        case 210: *bp = 512; *bc = 32; return launch_cfg<T, 8, 1, 2, 1, 128, 2>(a, s);
         // ablations of variant 0
         case 10: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 1>(a, s);
         case 11: *bp = 128; *bc = 128; return launch_cfg<T, 2, 2, 2, 2, 128, 2, 2>(a, s);

@@ -50,6 +50,20 @@ struct Conv1WgradArgs {
     float scale;        // 1 / grad_scale
 };
 hipError_t launch_conv1_wgrad(int dtype, const Conv1WgradArgs& a, hipStream_t s);
+// pooled first layer: BN-backward apply fused into the weight gradient (dy never reaches HBM)
+struct Conv1WgradFusedArgs {
+    const void* x4;       // [N][H+2][W+2][4]
+    const void* y;        // conv output [M][32]
+    const void* dA;       // grad wrt the pooled layer output [N*Ho*Wo][32]
+    const float *scale, *shift, *mean, *invstd;
+    const float* coef;    // [2][32]
+    float* psum;          // [P][2][32]: slot 0 receives the block's sum(dy)
+    float* dW;            // [3][3][3][32] fp32, atomics (pre-zeroed)
+    int N, H, W;
+    float inv_grad_scale;
+};
+bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy);
+hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s, int* nblocks);
 
 // ---- weight-gradient GEMM  dW[t][ci][co] += sum_p X[p+t][ci] * dY[p][co]
 struct WgradArgs {
@@ -148,6 +162,7 @@ int bn_bwd_partials(const BnBwdArgs& a);
 hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s);
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s);
+hipError_t launch_bn_bwd_dbias(const BnBwdArgs& a, int P, hipStream_t s);   // psum slot 0 of P blocks -> dbias
 
 // ---- loss / heads
 struct LossArgs {

@@ -95,7 +95,8 @@ struct y2_ctx {
     int pack_blocks = 0;
     // optional per-launch HIP-event bracketing (bench.py roofline leg)
     int prof = 0;   // 0 off, 1 every launch, 2 only the dominant kernel (conv forward + dgrad)
-    struct ProfRec { int cat; hipEvent_t a, b; };
+    struct ProfRec { int cat, layer; hipEvent_t a, b; };
+    int prof_layer = -1;
     std::vector<ProfRec> prof_recs;
     size_t prof_used = 0;
     size_t sz() const { return dtype_size(dtype); }
@@ -118,6 +119,7 @@ struct ProfScope {
         }
         idx = (int)c->prof_used++;
         c->prof_recs[idx].cat = cat;
+        c->prof_recs[idx].layer = c->prof_layer;
         (void)hipEventRecord(c->prof_recs[idx].a, s);
     }
     ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c->prof_recs[idx].b, s); }
@@ -306,6 +308,19 @@ int y2_profile_collect(y2_ctx* c, double* ms, int* count, int ncat) {
     c->prof_used = 0;
     return Y2_OK;
 }
+// dev only (not in the header): per-layer, per-category milliseconds [num_layers][CAT_COUNT]; does not reset
+extern "C" int y2dev_profile_layers(y2_ctx* c, double* ms) {
+    const int nl = (int)c->L.size();
+    for (int i = 0; i < nl * CAT_COUNT; ++i) ms[i] = 0.0;
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        auto& r = c->prof_recs[i];
+        HIPCHK(hipEventSynchronize(r.b));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
+        if (r.layer >= 0 && r.layer < nl) ms[r.layer * CAT_COUNT + r.cat] += t;
+    }
+    return Y2_OK;
+}
 int y2_num_layers(const y2_ctx* c) { return (int)c->L.size(); }
 int y2_layer_info(const y2_ctx* c, int l, int info[8]) {
     if (l < 0 || l >= (int)c->L.size()) return fail(Y2_ERR_ARG, "layer out of range");
@@ -413,6 +428,7 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
     float* part_m2 = (float*)(c->ws + c->o_part_m2);
     const int nl = (int)c->L.size();
     for (int l = 0; l < nl; ++l) {
+        c->prof_layer = l;
         const Layer& y = c->L[l];
         const int training = (l < c->core_layers) ? train_core : train_head;
         c->fwd_training[l] = training;
@@ -501,6 +517,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
     }
     float* psum = (float*)(c->ws + c->o_psum);
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
+        c->prof_layer = l;
         const Layer& y = c->L[l];
         float* stat = (float*)(c->ws + y.stat);
         char* dyp = c->ws + y.dyp + c->dy_geom(l).base_off(sz);
@@ -514,14 +531,25 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         b.N = c->N; b.H = y.H; b.W = y.W; b.C = y.cout; b.ldy = y.ldy;
         b.ldd = y.ldy;
         b.pool = y.pool; b.training = c->fwd_training[l]; b.inv_grad_scale = inv_gs;
+        const bool fused1 = y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy);
         {
             PROF(CAT_BN_BWD);
             HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
             HIPCHK(launch_bn_bwd_finalize(b, s));
-            HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
+            if (!fused1) HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
         }
         char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
-        if (y.first3) {
+        if (fused1) {
+            // the first layer's dy has one consumer: apply pass and weight gradient in one kernel
+            Conv1WgradFusedArgs g{};
+            g.x4 = xin; g.y = b.y; g.dA = b.dA;
+            g.scale = b.scale; g.shift = b.shift; g.mean = b.mean; g.invstd = b.invstd; g.coef = b.coef;
+            g.psum = psum; g.dW = c->grads + y.pW;
+            g.N = c->N; g.H = y.H; g.W = y.W; g.inv_grad_scale = inv_gs;
+            int P = 0;
+            { PROF(CAT_CONV1_WGRAD); HIPCHK(launch_conv1_wgrad_fused(c->dtype, g, s, &P)); }
+            { PROF(CAT_BN_BWD); HIPCHK(launch_bn_bwd_dbias(b, P, s)); }
+        } else if (y.first3) {
             Conv1WgradArgs g{};
             g.x4 = xin; g.dy = dyp; g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M; g.scale = inv_gs;
@@ -561,6 +589,8 @@ int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
         HIPCHK(launch_cast_to_f32(c->dtype, c->ws + y.y, dst, (size_t)y.M, y.cout, y.ldy, s));
     } else if (what == 2) {
         if (!c->bound_training) return fail(Y2_ERR_STATE, "no gradients in inference binding");
+        if (y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy))
+            return fail(Y2_ERR_STATE, "the first layer's dy is fused into its weight gradient and never stored");
         HIPCHK(launch_unpack_act(c->dtype, c->ws + y.dyp + c->dy_geom(l).base_off(sz), dst, c->N, y.H, y.W, y.cout,
                                  y.ldy, s));
     } else {

@@ -198,7 +198,10 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s) {
     const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
     const int tiles = a.taps * nIT * nOT;
     if (a.splitk <= 0) {
-        long sk = (1536 + tiles - 1) / tiles;       // aim at ~6 blocks per CU
+        // 1x1: the fp32 atomics of the split-K partial tiles cost as much as the streaming reads --
+        // one block per CU is the measured optimum (scripts/bench_wgrad.py); 3x3 fallback: ~6 per CU
+        const int target = a.taps == 1 ? 256 : 1536;
+        long sk = (target + tiles - 1) / tiles;
         const long maxsk = (ksteps + 7) / 8;         // at least 8 K steps per block
         if (sk > maxsk) sk = maxsk;
         if (sk < 1) sk = 1;
