@@ -118,27 +118,43 @@ hipError_t launch_bn_infer_prepare(const float* gamma, const float* beta, const 
 // ---------------------------------------------------------------------------
 // forward: out = maxpool2x2?( leaky( y*scale + shift ) )
 // ---------------------------------------------------------------------------
+// block = (256 / cpr) pixel rows x cpr 16-byte channel chunks over a contiguous pixel range: the
+// channel chunk of a thread is fixed (scale/shift live in registers) and (n, ho, wo) advance
+// incrementally -- no per-element div/mod (64-bit ones cost more than the pass's arithmetic)
 template <typename T, bool POOL, bool OUTF32>
 __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
     constexpr int EPC = 16 / sizeof(T);
-    const int cpr = a.ldy / EPC;
+    const int cpr = a.ldy / EPC;           // <= 256 (checked by the launcher)
+    const int rows = 256 / cpr;
     const int Ho = POOL ? (a.H + 1) / 2 : a.H, Wo = POOL ? (a.W + 1) / 2 : a.W;
-    const size_t total = (size_t)a.N * Ho * Wo * cpr;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % cpr);
-        const size_t po = idx / cpr;
-        const int wo = (int)(po % Wo);
-        const int ho = (int)((po / Wo) % Ho);
-        const int n = (int)(po / ((size_t)Wo * Ho));
-        const int c0 = ch * EPC;
-        if (!OUTF32 && c0 >= a.C) continue;
-        float sc[EPC], sh[EPC], r[EPC];
+    const uint32_t mout = (uint32_t)a.N * Ho * Wo;
+    const int tid = threadIdx.x;
+    const int ch = tid % cpr, row = tid / cpr;
+    const int c0 = ch * EPC;
+    if (row >= rows || (!OUTF32 && c0 >= a.C)) return;
+    const uint32_t per_blk = (mout + gridDim.x - 1) / gridDim.x;
+    const uint32_t p_begin = blockIdx.x * per_blk;
+    uint32_t p_end = p_begin + per_blk;
+    if (p_end > mout) p_end = mout;
+    float sc[EPC], sh[EPC];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            sc[e] = a.scale[c0 + e];
-            sh[e] = a.shift[c0 + e];
-        }
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = a.scale[c0 + e];
+        sh[e] = a.shift[c0 + e];
+    }
+    int wo, ho, n;
+    {
+        const uint32_t p0 = p_begin + row;
+        wo = (int)(p0 % (uint32_t)Wo);
+        const uint32_t q = p0 / (uint32_t)Wo;
+        ho = (int)(q % (uint32_t)Ho);
+        n = (int)(q / (uint32_t)Ho);
+    }
+    const int drow = rows / Wo, dcol = rows % Wo;
+    for (uint32_t po = p_begin + row; po < p_end; po += rows, wo += dcol, ho += drow) {
+        if (wo >= Wo) { wo -= Wo; ++ho; }
+        while (ho >= Ho) { ho -= Ho; ++n; }
+        float r[EPC];
         if (POOL) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
@@ -154,12 +170,12 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
                 }
             }
         } else {
-            Chunk<T> v = ld_chunk<T>((const char*)a.y + ((po * a.ldy) + c0) * sizeof(T));
+            Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
 #pragma unroll
             for (int e = 0; e < EPC; ++e) r[e] = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
         }
         if (OUTF32) {
-            float* o = (float*)a.out + po * a.C;
+            float* o = (float*)a.out + (size_t)po * a.C;
 #pragma unroll
             for (int e = 0; e < EPC; ++e)
                 if (c0 + e < a.C) o[c0 + e] = r[e];
@@ -177,8 +193,12 @@ template <typename T>
 static hipError_t bn_act_T(const BnActArgs& a, hipStream_t s) {
     constexpr int EPC = 16 / sizeof(T);
     const int Ho = a.pool ? (a.H + 1) / 2 : a.H, Wo = a.pool ? (a.W + 1) / 2 : a.W;
-    const size_t total = (size_t)a.N * Ho * Wo * (a.ldy / EPC);
-    size_t nb = (total + 255) / 256;
+    const int cpr = a.ldy / EPC;
+    if (cpr < 1 || cpr > 256) return hipErrorInvalidValue;
+    const size_t mout = (size_t)a.N * Ho * Wo;
+    if (mout >= (1ull << 31)) return hipErrorInvalidValue;
+    const int rows = 256 / cpr;
+    size_t nb = (mout + (size_t)rows * 4 - 1) / ((size_t)rows * 4);   // >= 4 pixels per thread row
     if (nb > 256 * 16) nb = 256 * 16;
     if (nb == 0) nb = 1;
     dim3 g((unsigned)nb), b(256);
@@ -202,10 +222,16 @@ hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------
 // backward.  For one output pixel (pooled resolution when POOL) and EPC channels:
-//   z_d   = y_d*scale + shift              (d = the 1 or 4 input pixels)
-//   dz_d  = dA * slope(z_d) at the first arg-max d (row-major), 0 elsewhere
-//   pass 1: S1 += dz, S2 += dz * xhat      (xhat = (y - mean)*invstd)
-//   pass 2: dy_d = scale * (dz_d - c1 - xhat_d*c2)   c1 = S1/M, c2 = S2/M
+//   z_d  = y_d*scale + shift                 (d = the 1 or 4 input pixels)
+//   g    = dA * leaky'(z) at the first arg-max d of leaky(z_d) (row-major); dz_d = g there, 0 elsewhere
+//   pass 1 (reduce): S1 += g, S2 += g*y       -> dbeta = S1, dgamma = invstd*(S2 - mean*S1)
+//   pass 2 (apply):  dy_d = scale*(dz_d - c1 - xhat_d*c2) = scale*dz_d - (ka + kb*y_d)
+//                    with c1 = S1/M, c2 = dgamma/M, kb = scale*c2*invstd, ka = scale*c1 - kb*mean
+// Only the arg-max position carries dz, so pass 1 touches one y per pooled pixel in its sums and
+// pass 2 is one fma per element plus the arg-max search: both passes are VALU-lean enough to
+// stay HBM-bound at three waves per SIMD.
+// The conv-bias gradient sum(dy) is analytic: scale*(S1 - M*c1) (zero up to the rounding of c1
+// with batch statistics, scale*S1 with moving statistics) -- no third reduction.
 // ---------------------------------------------------------------------------
 struct BwdGeom {
     int cpr, CT, rows, Ho, Wo;
@@ -227,117 +253,113 @@ __host__ __device__ inline BwdGeom bwd_geom(const BnBwdArgs& a) {
 template <typename T, bool POOL, bool APPLY>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
     constexpr int EPC = 16 / sizeof(T);
-    __shared__ float red[256 * 8 * 2 / 2 + 8];  // [rows][CT][EPC] * up to 2 sums (EPC<=8, CT*rows<=256)
+    __shared__ float red[APPLY ? 1 : (256 * 8 + 8)];  // [rows][CT][EPC] (EPC<=8, CT*rows<=256)
     const BwdGeom g = bwd_geom<T>(a);
     const int tid = threadIdx.x;
     const bool active = tid < g.CT * g.rows;
     const int ch = tid % g.CT, row = tid / g.CT;
     const int c0 = ch * EPC;
-    const size_t per_blk = (g.mout + gridDim.x - 1) / gridDim.x;
-    const size_t p_begin = (size_t)blockIdx.x * per_blk;
-    size_t p_end = p_begin + per_blk;
-    if (p_end > g.mout) p_end = g.mout;
+    // 32-bit pixel indices (N*H*W < 2^31 for anything that fits HBM), (n, ho, wo) advance incrementally
+    const uint32_t mout = (uint32_t)g.mout;
+    const uint32_t per_blk = (mout + gridDim.x - 1) / gridDim.x;
+    const uint32_t p_begin = blockIdx.x * per_blk;
+    uint32_t p_end = p_begin + per_blk;
+    if (p_end > mout) p_end = mout;
 
-    float sc[EPC], sh[EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC], s1[EPC], s2[EPC];
+    float sc[EPC], sh[EPC], nka[EPC], nkb[EPC], s1[EPC], s2[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        sc[e] = sh[e] = mu[e] = is[e] = c1[e] = c2[e] = 0.f;
-        s1[e] = s2[e] = 0.f;
-    }
+    for (int e = 0; e < EPC; ++e) sc[e] = sh[e] = nka[e] = nkb[e] = s1[e] = s2[e] = 0.f;
     if (active) {
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
             sc[e] = a.scale[c0 + e];
             sh[e] = a.shift[c0 + e];
-            mu[e] = a.mean[c0 + e];
-            is[e] = a.invstd[c0 + e];
             if (APPLY) {
-                c1[e] = a.coef[c0 + e];
-                c2[e] = a.coef[a.ldy + c0 + e];
+                nka[e] = -a.coef[c0 + e];
+                nkb[e] = -a.coef[a.ldy + c0 + e];
             }
         }
-        for (size_t po = p_begin + row; po < p_end; po += g.rows) {
-            const int wo = (int)(po % g.Wo);
-            const int ho = (int)((po / g.Wo) % g.Ho);
-            const int n = (int)(po / ((size_t)g.Wo * g.Ho));
-            Chunk<T> dav = ld_chunk<T>((const char*)a.dA + (po * a.ldd + c0) * sizeof(T));
-            float da[EPC];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) da[e] = Elem<T>::to_f32(dav.v[e]);
+        int wo, ho, n;
+        {
+            const uint32_t p0 = p_begin + row;
+            wo = (int)(p0 % (uint32_t)g.Wo);
+            const uint32_t q = p0 / (uint32_t)g.Wo;
+            ho = (int)(q % (uint32_t)g.Ho);
+            n = (int)(q / (uint32_t)g.Ho);
+        }
+        const int drow = g.rows / g.Wo, dcol = g.rows % g.Wo;   // per-iteration advance
+        for (uint32_t po = p_begin + row; po < p_end; po += g.rows, wo += dcol, ho += drow) {
+            if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
+            while (ho >= g.Ho) { ho -= g.Ho; ++n; }
+            Chunk<T> dav = ld_chunk<T>((const char*)a.dA + ((size_t)po * a.ldd + c0) * sizeof(T));
             if (POOL) {
-                float yv[4][EPC];
+                Chunk<T> yc[4];
                 bool valid[4];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
                     valid[d] = hi < a.H && wi < a.W;
-                    if (valid[d]) {
-                        Chunk<T> v = ld_chunk<T>((const char*)a.y +
-                                                 (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
-#pragma unroll
-                        for (int e = 0; e < EPC; ++e) yv[d][e] = Elem<T>::to_f32(v.v[e]);
-                    }
+                    if (valid[d])
+                        yc[d] = ld_chunk<T>((const char*)a.y + (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
                 }
                 int arg[EPC];
-                float zmax[EPC];
+                float amax[EPC], yb[EPC], gz[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     arg[e] = 0;
-                    zmax[e] = -INFINITY;
+                    amax[e] = -INFINITY;
+                    yb[e] = 0.f;
                 }
 #pragma unroll
                 for (int d = 0; d < 4; ++d)
                     if (valid[d]) {
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) {
-                            // the pooled quantity is leaky(z); leaky is strictly increasing
-                            const float act = leaky01(yv[d][e] * sc[e] + sh[e]);
-                            if (act > zmax[e]) {
-                                zmax[e] = act;
-                                arg[e] = d;
+                            // the pooled quantity is leaky(z): compare what the forward pass compared
+                            const float yv = Elem<T>::to_f32(yc[d].v[e]);
+                            const float act = leaky01(fmaf(yv, sc[e], sh[e]));
+                            if (act > amax[e]) {
+                                amax[e] = act;
+                                yb[e] = yv;
+                                if (APPLY) arg[e] = d;
                             }
                         }
                     }
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if (!valid[d]) continue;
-                    const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
-                    Chunk<T> o;
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const float z = yv[d][e] * sc[e] + sh[e];
-                        const float dz = (arg[e] == d) ? da[e] * leaky01_slope(z) : 0.f;
-                        const float xh = (yv[d][e] - mu[e]) * is[e];
-                        if (APPLY) {
-                            const float dy = sc[e] * (dz - c1[e] - xh * c2[e]);
-                            o.v[e] = Elem<T>::from_f32(dy);
-                            s1[e] += dy;
-                        } else {
-                            s1[e] += dz;
-                            s2[e] += dz * xh;
-                        }
+                for (int e = 0; e < EPC; ++e) {
+                    gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yb[e], sc[e], sh[e]));
+                    if (!APPLY) {
+                        s1[e] += gz[e];
+                        s2[e] = fmaf(gz[e], yb[e], s2[e]);
                     }
-                    if (APPLY) {
+                }
+                if (APPLY) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        if (!valid[d]) continue;
+                        const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
+                        Chunk<T> o;
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            const float t = fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
+                            o.v[e] = Elem<T>::from_f32((arg[e] == d) ? fmaf(sc[e], gz[e], t) : t);
+                        }
                         const size_t off = (bpix(n, hi, wi, a.H, a.W) * a.ldy + c0) * sizeof(T);
                         st_chunk<T>((char*)a.dyp + off, o);
                     }
                 }
             } else {
-                Chunk<T> v = ld_chunk<T>((const char*)a.y + (po * a.ldy + c0) * sizeof(T));
+                Chunk<T> v = ld_chunk<T>((const char*)a.y + ((size_t)po * a.ldy + c0) * sizeof(T));
                 Chunk<T> o;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float yv = Elem<T>::to_f32(v.v[e]);
-                    const float z = yv * sc[e] + sh[e];
-                    const float dz = da[e] * leaky01_slope(z);
-                    const float xh = (yv - mu[e]) * is[e];
+                    const float gz = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yv, sc[e], sh[e]));
                     if (APPLY) {
-                        const float dy = sc[e] * (dz - c1[e] - xh * c2[e]);
-                        o.v[e] = Elem<T>::from_f32(dy);
-                        s1[e] += dy;
+                        o.v[e] = Elem<T>::from_f32(fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e])));
                     } else {
-                        s1[e] += dz;
-                        s2[e] += dz * xh;
+                        s1[e] += gz;
+                        s2[e] = fmaf(gz, yv, s2[e]);
                     }
                 }
                 if (APPLY) {
@@ -347,9 +369,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
             }
         }
     }
+    if (APPLY) return;
     // ---- block reduction over `rows`
-    constexpr int NS = APPLY ? 1 : 2;
-    for (int k = 0; k < NS; ++k) {
+    for (int k = 0; k < 2; ++k) {
         __syncthreads();
         if (active) {
 #pragma unroll
@@ -361,23 +383,21 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
             for (int e = 0; e < EPC; ++e) {
                 float t = 0.f;
                 for (int r = 0; r < g.rows; ++r) t += red[(r * g.CT + ch) * EPC + e];
-                // APPLY: slot 0 holds the block's sum(dy) (conv-bias gradient partial)
                 if (c0 + e < a.C) a.psum[((size_t)blockIdx.x * 2 + k) * a.ldy + c0 + e] = t;
             }
         }
     }
 }
 
-// mode 0: after the reduce pass -> dbeta, dgamma, coef.  mode 1: after the apply pass -> dbias.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs a, int mode, int P) {
+// after the reduce pass: dbeta, dgamma, dbias and the apply-pass constants coef = [ka][kb]
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs a, int P) {
     __shared__ double red[kFinSl][kFinCh];
     const int cl = threadIdx.x % kFinCh, sl = threadIdx.x / kFinCh;
     const int c = blockIdx.x * kFinCh + cl;
     const bool cv = c < a.C;
     const int cc = cv ? c : 0;
     double t[2] = {0.0, 0.0};
-    const int nk = mode == 0 ? 2 : 1;
-    for (int k = 0; k < nk; ++k) {
+    for (int k = 0; k < 2; ++k) {
         double v4[4] = {0, 0, 0, 0};
         int p = sl;
         for (; p + 3 * kFinSl < P; p += 4 * kFinSl) {
@@ -388,15 +408,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs a, int 
         t[k] = fin_block_sum((v4[0] + v4[1]) + (v4[2] + v4[3]), red, sl, cl);
     }
     if (sl == 0 && cv) {
-        if (mode == 0) {
-            const double m = (double)a.N * a.H * a.W;
-            a.dbeta[c] = (float)(t[0] * a.inv_grad_scale);
-            a.dgamma[c] = (float)(t[1] * a.inv_grad_scale);
-            a.coef[c] = a.training ? (float)(t[0] / m) : 0.f;
-            a.coef[a.ldy + c] = a.training ? (float)(t[1] / m) : 0.f;
-        } else {
-            a.dbias[c] = (float)(t[0] * a.inv_grad_scale);
-        }
+        const double m = (double)a.N * a.H * a.W;
+        const double mu = a.mean[c], is = a.invstd[c], sc = a.scale[c];
+        const double dgam = is * (t[1] - mu * t[0]);          // sum(dz * xhat)
+        a.dbeta[c] = (float)(t[0] * a.inv_grad_scale);
+        a.dgamma[c] = (float)(dgam * a.inv_grad_scale);
+        const float c1 = a.training ? (float)(t[0] / m) : 0.f;
+        const float c2 = a.training ? (float)(dgam / m) : 0.f;
+        const double kb = sc * (double)c2 * is;
+        a.coef[c] = (float)(sc * (double)c1 - kb * mu);
+        a.coef[a.ldy + c] = (float)kb;
+        if (a.dbias) a.dbias[c] = (float)(sc * (t[0] - m * (double)c1) * a.inv_grad_scale);
     }
 }
 
@@ -426,25 +448,16 @@ hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, 0, a.P);
-    return hipGetLastError();
-}
-hipError_t launch_bn_bwd_dbias(const BnBwdArgs& a, int P, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, 1, P);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, a.P);
     return hipGetLastError();
 }
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s) {
-    hipError_t e = hipErrorInvalidValue;
-    int P = 0;
     switch (dtype) {
-        case 0: P = bwd_blocks<float>(a); e = bn_bwd_T<float, true>(a, s); break;
-        case 1: P = bwd_blocks<half_t>(a); e = bn_bwd_T<half_t, true>(a, s); break;
-        case 2: P = bwd_blocks<bf16_t>(a); e = bn_bwd_T<bf16_t, true>(a, s); break;
+        case 0: return bn_bwd_T<float, true>(a, s);
+        case 1: return bn_bwd_T<half_t, true>(a, s);
+        case 2: return bn_bwd_T<bf16_t, true>(a, s);
     }
-    if (e != hipSuccess) return e;
-    if (a.dbias)   // conv-bias gradient = sum(dy): block partials -> one tiny reduction (no contended atomics)
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, 1, P);
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 }  // namespace y2

@@ -10,8 +10,13 @@
 //     overlapping 32-byte windows of the x4 row image directly (no im2col)
 //   * accumulators live in registers across all rows of the block; one LDS reduction
 //     over the 4 waves and 864 float atomics per block at the end.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
+
+#ifndef Y2_C1F_MAXI
+#define Y2_C1F_MAXI 0   // register-prefetched items per thread in the fused kernel (f16/bf16)
+#endif
 
 namespace y2 {
 
@@ -131,17 +136,17 @@ hipError_t launch_conv1_wgrad(int dtype, const Conv1WgradArgs& a, hipStream_t s)
 
 // ---------------------------------------------------------------------------
 // Fused form for the pooled first layer: the batch-norm backward APPLY pass
-//   dy = scale * (dz - c1 - xhat*c2),  dz = dA * leaky'(z) at the 2x2 arg-max
+//   dy_d = scale*dz_d - (ka + kb*y_d),  dz = dA * leaky'(z) at the 2x2 arg-max   (bn.hip)
 // is computed here, row pair by row pair, straight into the LDS dy images the MFMAs read.
 // dy of the first layer has exactly one consumer (this kernel: there is no dgrad below
 // conv1), so at 416x416x64 the 709 MB tensor is never written nor re-read: the apply pass
 // (886 MB in, 709 MB out) disappears and this kernel streams y + dA (886 MB) instead of dy.
-// Also emits the per-block sum(dy) partials of the conv-bias gradient (psum slot 0).
 // ---------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void conv1_wgrad_fused_kernel(Conv1WgradFusedArgs a) {
+template <typename T, int MAXI>
+__global__ __launch_bounds__(256, 2) void conv1_wgrad_fused_kernel(Conv1WgradFusedArgs a) {
     constexpr int SZ = sizeof(T), EPC = 16 / SZ, CPP = 32 / EPC;
     constexpr int DYP = 32 * SZ, XP = 4 * SZ;
+    constexpr int NTH = 256, NW = NTH / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,80 +162,125 @@ __global__ __launch_bounds__(256) void conv1_wgrad_fused_kernel(Conv1WgradFusedA
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
 
     // k-padding pixels of the two dy rows: zero, once
-    for (int i = tid; i < 2 * (Wp - a.W) * CPP; i += 256) {
+    for (int i = tid; i < 2 * (Wp - a.W) * CPP; i += NTH) {
         const int r = i / ((Wp - a.W) * CPP), j = i % ((Wp - a.W) * CPP);
         *(u32x4*)(dy_l + r * dy_bytes + a.W * DYP + j * 16) = u32x4{0, 0, 0, 0};
     }
     const int ch = tid % CPP, c0 = ch * EPC;
-    float sc[EPC], sh[EPC], mu[EPC], is[EPC], c1[EPC], c2[EPC], sdy[EPC];
+    float sc[EPC], sh[EPC], nka[EPC], nkb[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-        sc[e] = a.scale[c0 + e]; sh[e] = a.shift[c0 + e]; mu[e] = a.mean[c0 + e]; is[e] = a.invstd[c0 + e];
-        c1[e] = a.coef[c0 + e]; c2[e] = a.coef[32 + c0 + e];
-        sdy[e] = 0.f;
+        sc[e] = a.scale[c0 + e];
+        sh[e] = a.shift[c0 + e];
+        nka[e] = -a.coef[c0 + e];
+        nkb[e] = -a.coef[32 + c0 + e];
     }
 
     f32x16 acc1, acc2;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc1[q] = acc2[q] = 0.f;
 
+    // one work item = one pooled pixel x EPC channels: 1 dA chunk + 4 y chunks in, 4 dy chunks out.
+    // The first MAXI items per thread of the NEXT row pair are loaded into registers before the
+    // MFMA phase of the current one (HBM latency hides behind it); the rest load in place.
+    const int nitems = Wo * CPP;
+    u32x4 pda[MAXI ? MAXI : 1], py[MAXI ? MAXI : 1][4];   // raw 16-byte vectors (kept packed)
+    auto item_ptrs = [&](int pr, const char*& yrow, const char*& darow) {
+        const int n = pr / Ho, ho = pr - n * Ho;
+        yrow = (const char*)a.y + ((size_t)(n * a.H + 2 * ho) * a.W) * DYP;
+        darow = (const char*)a.dA + ((size_t)(n * Ho + ho) * Wo) * DYP;
+    };
+    auto prefetch = [&](int pr) {
+        const char *yrow, *darow;
+        item_ptrs(pr, yrow, darow);
+#pragma unroll
+        for (int k = 0; k < MAXI; ++k) {
+            const int item = tid + k * NTH;
+            if (item < nitems) {
+                const int wo = item / CPP;
+                pda[k] = *(const u32x4*)(darow + (size_t)item * 16);
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    py[k][d] = *(const u32x4*)(yrow + ((size_t)(d >> 1) * a.W + 2 * wo + (d & 1)) * DYP + ch * 16);
+            }
+        }
+    };
+    auto process = [&](const u32x4& dar, const u32x4 (&yr)[4], int item) {
+        const int wo = item / CPP;
+        Chunk<T> dav, yv[4];
+        *(u32x4*)dav.v = dar;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) *(u32x4*)yv[d].v = yr[d];
+        int arg[EPC];
+        float amax[EPC], yb[EPC], gz[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            arg[e] = 0;
+            amax[e] = -INFINITY;
+            yb[e] = 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float yy = Elem<T>::to_f32(yv[d].v[e]);
+                const float act = leaky01(fmaf(yy, sc[e], sh[e]));
+                if (act > amax[e]) {
+                    amax[e] = act;
+                    yb[e] = yy;
+                    arg[e] = d;
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+            gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yb[e], sc[e], sh[e]));
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            Chunk<T> o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float t = fmaf(nkb[e], Elem<T>::to_f32(yv[d].v[e]), nka[e]);
+                o.v[e] = Elem<T>::from_f32((arg[e] == d) ? fmaf(sc[e], gz[e], t) : t);
+            }
+            st_chunk<T>(dy_l + (d >> 1) * dy_bytes + (size_t)(2 * wo + (d & 1)) * DYP + ch * 16, o);
+        }
+    };
+    if (MAXI && blockIdx.x < prs) prefetch(blockIdx.x);
+
     for (int pr = blockIdx.x; pr < prs; pr += gridDim.x) {
         const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho;
         const char* xrow = (const char*)a.x4 + (bpix(n, h0, 0, a.H, a.W) - (size_t)(a.W + 2)) * XP;
         const size_t xpitch = (size_t)(a.W + 1) * XP;
-        const char* yrow = (const char*)a.y + ((size_t)(n * a.H + h0) * a.W) * DYP;
-        const char* darow = (const char*)a.dA + ((size_t)(n * Ho + ho) * Wo) * DYP;
         __syncthreads();   // previous row pair fully consumed
         for (int kh = 0; kh < 4; ++kh)
-            for (int i0 = w * 64; i0 < x_chunks; i0 += 256) {
+            for (int i0 = w * 64; i0 < x_chunks; i0 += NTH) {
                 const int i = i0 + lane;
                 if (i < x_chunks) glds16(xrow + kh * xpitch + (size_t)i * 16, x_l + kh * x_bytes + i0 * 16);
             }
-        for (int item = tid; item < Wo * CPP; item += 256) {
-            const int wo = item / CPP;
-            Chunk<T> dav = ld_chunk<T>(darow + (size_t)item * 16);
-            Chunk<T> yv[4];
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-                yv[d] = ld_chunk<T>(yrow + ((size_t)(d >> 1) * a.W + 2 * wo + (d & 1)) * DYP + ch * 16);
-            int arg[EPC];
-            float zmax[EPC];
+        for (int k = 0; k < MAXI; ++k) {
+            const int item = tid + k * NTH;
+            if (item < nitems) process(pda[k], py[k], item);
+        }
+        {
+            const char *yrow, *darow;
+            item_ptrs(pr, yrow, darow);
+            for (int item = tid + MAXI * NTH; item < nitems; item += NTH) {
+                const int wo = item / CPP;
+                const u32x4 dav = *(const u32x4*)(darow + (size_t)item * 16);
+                u32x4 yv[4];
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                arg[e] = 0;
-                zmax[e] = -INFINITY;
-            }
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const float act = leaky01(Elem<T>::to_f32(yv[d].v[e]) * sc[e] + sh[e]);
-                    if (act > zmax[e]) {
-                        zmax[e] = act;
-                        arg[e] = d;
-                    }
-                }
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                Chunk<T> o;
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const float yy = Elem<T>::to_f32(yv[d].v[e]);
-                    const float z = yy * sc[e] + sh[e];
-                    const float dz = (arg[e] == d) ? Elem<T>::to_f32(dav.v[e]) * leaky01_slope(z) : 0.f;
-                    const float xh = (yy - mu[e]) * is[e];
-                    const float dy = sc[e] * (dz - c1[e] - xh * c2[e]);
-                    o.v[e] = Elem<T>::from_f32(dy);
-                    sdy[e] += dy;
-                }
-                st_chunk<T>(dy_l + (d >> 1) * dy_bytes + (size_t)(2 * wo + (d & 1)) * DYP + ch * 16, o);
+                for (int d = 0; d < 4; ++d)
+                    yv[d] = *(const u32x4*)(yrow + ((size_t)(d >> 1) * a.W + 2 * wo + (d & 1)) * DYP + ch * 16);
+                process(dav, yv, item);
             }
         }
+        if (MAXI && pr + (int)gridDim.x < prs) prefetch(pr + gridDim.x);
         __syncthreads();   // LDS-DMA drained (vmcnt(0)) and the dy images complete
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const char* dyr = dy_l + r * dy_bytes;
-            for (int s = w; s * 16 < a.W; s += 4) {
+            for (int s = w; s * 16 < a.W; s += NW) {
                 const int w0 = s * 16;
                 if constexpr (SZ == 2) {
                     const int pix = w0 + 8 * hh + qq;
@@ -256,21 +306,9 @@ __global__ __launch_bounds__(256) void conv1_wgrad_fused_kernel(Conv1WgradFusedA
             }
         }
     }
-    // ---- sum(dy) of the block -> psum slot 0 (conv-bias gradient partial)
+    // ---- reduce the waves through LDS, then one atomic per (tap, c, co)
     __syncthreads();
-    float* red2 = (float*)smem;   // [256][EPC]
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) red2[tid * EPC + e] = sdy[e];
-    __syncthreads();
-    if (tid < 32) {
-        const int chs = tid / EPC, e = tid % EPC;
-        float t = 0.f;
-        for (int j = 0; j < 256 / CPP; ++j) t += red2[(j * CPP + chs) * EPC + e];
-        a.psum[((size_t)blockIdx.x * 2) * 32 + tid] = t;
-    }
-    // ---- reduce the 4 waves through LDS, then one atomic per (tap, c, co)
-    __syncthreads();
-    float* red = (float*)smem;   // [4 waves][48 rows][32 co]
+    float* red = (float*)smem;   // [NW waves][48 rows][32 co]
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int r = acc_row(q, hh);
@@ -278,41 +316,52 @@ __global__ __launch_bounds__(256) void conv1_wgrad_fused_kernel(Conv1WgradFusedA
         if (r < 16) red[(w * 48 + 32 + r) * 32 + r32] = acc2[q];
     }
     __syncthreads();
-    for (int i = tid; i < 48 * 32; i += 256) {
+    for (int i = tid; i < 48 * 32; i += NTH) {
         const int r = i >> 5, co = i & 31;
         const int kh = r >> 4, e = r & 15, kw = e >> 2, c = e & 3;
         if (kw < 3 && c < 3) {
-            const float v = red[i] + red[48 * 32 + i] + red[2 * 48 * 32 + i] + red[3 * 48 * 32 + i];
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) v += red[k * 48 * 32 + i];
             atomicAdd(a.dW + ((kh * 3 + kw) * 3 + c) * 32 + co, v * a.inv_grad_scale);
         }
     }
 }
 
-template <typename T>
-static hipError_t c1wgf_T(const Conv1WgradFusedArgs& a, hipStream_t s, int* nblocks) {
+template <typename T, int MAXI>
+static hipError_t c1wgf_M(const Conv1WgradFusedArgs& a, hipStream_t s) {
     constexpr int SZ = sizeof(T);
     const int Wp = (a.W + 15) & ~15;
     size_t lds = 2 * (size_t)Wp * 32 * SZ + 4 * (size_t)((((Wp + 4) * 4 * SZ) + 15) & ~15);
     const size_t red = 4 * 48 * 32 * sizeof(float);
     if (lds < red) lds = red;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    auto kern = conv1_wgrad_fused_kernel<T>;
+    auto kern = conv1_wgrad_fused_kernel<T, MAXI>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int prs = a.N * (a.H / 2);
     const int nb = prs < 512 ? prs : 512;
-    *nblocks = nb;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
-bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy) { return pool && (H % 2) == 0 && (W % 2) == 0 && ldy == 32; }
+template <typename T>
+static hipError_t c1wgf_T(const Conv1WgradFusedArgs& a, hipStream_t s) {
+    // measured at 416x416x64: prefetching the next row pair into registers (MAXI 2) is no faster
+    // than loading in place with two blocks per CU (249 vs 245 us), so the simple form ships
+    if (sizeof(T) == 2 && Y2_C1F_MAXI > 0) return c1wgf_M<T, Y2_C1F_MAXI>(a, s);
+    return c1wgf_M<T, 0>(a, s);
+}
 
-hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s, int* nblocks) {
+bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy) {
+    return pool && (H % 2) == 0 && (W % 2) == 0 && ldy == 32;
+}
+
+hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s) {
     switch (dtype) {
-        case 0: return c1wgf_T<float>(a, s, nblocks);
-        case 1: return c1wgf_T<half_t>(a, s, nblocks);
-        case 2: return c1wgf_T<bf16_t>(a, s, nblocks);
+        case 0: return c1wgf_T<float>(a, s);
+        case 1: return c1wgf_T<half_t>(a, s);
+        case 2: return c1wgf_T<bf16_t>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -55,15 +55,14 @@ struct Conv1WgradFusedArgs {
     const void* x4;       // [N][H+2][W+2][4]
     const void* y;        // conv output [M][32]
     const void* dA;       // grad wrt the pooled layer output [N*Ho*Wo][32]
-    const float *scale, *shift, *mean, *invstd;
-    const float* coef;    // [2][32]
-    float* psum;          // [P][2][32]: slot 0 receives the block's sum(dy)
+    const float *scale, *shift;
+    const float* coef;    // [2][32]: ka, kb (bn_bwd_finalize)
     float* dW;            // [3][3][3][32] fp32, atomics (pre-zeroed)
     int N, H, W;
     float inv_grad_scale;
 };
 bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy);
-hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s, int* nblocks);
+hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s);
 
 // ---- weight-gradient GEMM  dW[t][ci][co] += sum_p X[p+t][ci] * dY[p][co]
 struct WgradArgs {
@@ -146,11 +145,11 @@ struct BnBwdArgs {
     const float* shift;
     const float* mean;
     const float* invstd;
-    float* psum;          // [P][2][C] partial sums (dz, dz*xhat)
+    float* psum;          // [P][2][C] partial sums (dz, dz*y)
     float* dgamma;        // out (unscaled)
     float* dbeta;
-    float* dbias;         // out: sum(dy) (atomics, pre-zeroed)
-    float* coef;          // [2][C]: c1 = sum(dz)/M, c2 = sum(dz*xhat)/M   (scaled domain)
+    float* dbias;         // out: sum(dy), analytic (see bn.hip)
+    float* coef;          // [2][ldy]: ka, kb of dy = scale*dz - (ka + kb*y)   (scaled domain)
     void* dyp;            // out: zero-bordered [N][H+2][W+2][ldy] of T
     int N, H, W, C, ldy, ldd;
     int pool;
@@ -162,7 +161,6 @@ int bn_bwd_partials(const BnBwdArgs& a);
 hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s);
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s);
-hipError_t launch_bn_bwd_dbias(const BnBwdArgs& a, int P, hipStream_t s);   // psum slot 0 of P blocks -> dbias
 
 // ---- loss / heads
 struct LossArgs {

@@ -543,12 +543,10 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             // the first layer's dy has one consumer: apply pass and weight gradient in one kernel
             Conv1WgradFusedArgs g{};
             g.x4 = xin; g.y = b.y; g.dA = b.dA;
-            g.scale = b.scale; g.shift = b.shift; g.mean = b.mean; g.invstd = b.invstd; g.coef = b.coef;
-            g.psum = psum; g.dW = c->grads + y.pW;
+            g.scale = b.scale; g.shift = b.shift; g.coef = b.coef;
+            g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.inv_grad_scale = inv_gs;
-            int P = 0;
-            { PROF(CAT_CONV1_WGRAD); HIPCHK(launch_conv1_wgrad_fused(c->dtype, g, s, &P)); }
-            { PROF(CAT_BN_BWD); HIPCHK(launch_bn_bwd_dbias(b, P, s)); }
+            { PROF(CAT_CONV1_WGRAD); HIPCHK(launch_conv1_wgrad_fused(c->dtype, g, s)); }
         } else if (y.first3) {
             Conv1WgradArgs g{};
             g.x4 = xin; g.dy = dyp; g.dW = c->grads + y.pW;
