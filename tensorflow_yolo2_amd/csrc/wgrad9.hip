@@ -9,6 +9,7 @@
 // wave between barriers, and the dY fragment is shared by the nine MFMAs of a k-group.
 // K runs linearly over the bordered pixel space (dY border = 0); fragments come out of
 // the [pixel][channel] images through ds_read_b64_tr_b16.
+#include <stdlib.h>
 #include "common.h"
 #include "conv_epilogue.h"
 #include "kernels.h"
@@ -211,6 +212,221 @@ __global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9_kernel(WgradArgs a, in
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// RING form for long image rows (f16/bf16).  The X window of a K step is
+// 64 + 2*pitch + 2 bordered pixels; consecutive steps overlap in all but 64 of them, and
+// at W = 104 / 208 re-staging the whole window per step costs 4.3x / 7.6x the traffic of the
+// step itself (measured: those layers were bound by the global->LDS fill).  Here the X rows
+// live in an LDS ring of R = 2^k rows: every step stages only its 64 NEW rows (one aligned
+// group), the nine taps read row-shifted views of the ring, and the wrap is one AND on the
+// byte offset (v_add + v_and_or per address, hidden in the MFMA shadow).
+//   group g = window rows [64g, 64g+64); step st reads groups st .. st+G-1, G = ceil(wrows/64);
+//   group st+G is in flight during step st, so R >= 64*(G+1).
+// ---------------------------------------------------------------------------
+template <typename T>
+Y2_DEV typename Elem<T>::frag tr_frag_off(uint32_t o0, uint32_t o1) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)o0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)o1);
+    s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(typename Elem<T>::frag, both);
+}
+
+template <typename T, int WI, int WO, int TG, int T0, int NTAP>
+Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
+    typedef Wg9Cfg<T, WI, WO, TG> Cfg;
+    constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
+    constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
+    static_assert(SZ == 2 && BKP == 64, "ring form: 16-bit elements");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = w % (WI * WO);
+    const int wi = wq / WO, wo = wq % WO;
+    const int pitch = a.W + 1;
+    const uint32_t R = 1u << lgR;
+    const uint32_t ringB = R * ROWX, maskB = ringB - 1;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    if (lbase & maskB) __builtin_trap();   // the wrap ORs the column bits into the masked row offset
+
+    const int nIT = (a.Cin + BI - 1) / BI, nOT = (a.Cout + BO - 1) / BO;
+    int b = blockIdx.x;
+    const int ot = b % nOT; b /= nOT;
+    const int it = b % nIT;
+    const int split = b / nIT;
+    const int ci0 = it * BI, co0 = ot * BO;
+
+    const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
+    const long ksteps = (Mp + BKP - 1) / BKP;
+    const long spb = (ksteps + a.splitk - 1) / a.splitk;
+    const long s_begin = (long)split * spb;
+    long s_end = s_begin + spb;
+    if (s_end > ksteps) s_end = ksteps;
+    const int nsteps = (int)(s_end > s_begin ? s_end - s_begin : 0);
+
+    const long kb = s_begin * BKP;
+    const char* xg = (const char*)a.x + ((kb - pitch - 1) * a.Cin + ci0) * SZ;   // window row 0 of step 0
+    const char* yg = (const char*)a.dy + (kb * a.Cdy + co0) * SZ;
+    const long xstep = (long)BKP * a.Cin * SZ, ystep = (long)BKP * a.Cdy * SZ;
+    char* const ybase = smem + ringB;
+
+    const int lrx = lane / Cfg::LPRX, lsx = lane % Cfg::LPRX;
+    uint32_t voffy[Cfg::IPWY];
+#pragma unroll
+    for (int i = 0; i < Cfg::IPWY; ++i) {
+        const int row = (i * NW + w) * Cfg::RPIY + lane / Cfg::LPRY;
+        const int sl = (lane % Cfg::LPRY) ^ wg9_swz<ROWY, SZ>(row);
+        voffy[i] = (uint32_t)row * (uint32_t)(a.Cdy * SZ) + sl * 16;
+    }
+    auto stage_x = [&](int g) {   // 64 rows: 64 / RPIX pieces of 1 KiB (aligned: a piece never wraps)
+        const char* xs = xg + (long)g * xstep;
+        char* dst = smem + (((uint32_t)g * 64u * ROWX) & maskB);
+        for (int i = w; i < 64 / Cfg::RPIX; i += NW) {
+            const int row = i * Cfg::RPIX + lrx;   // row & 3 == LDS row & 3 (groups are 64-row aligned)
+            const uint32_t off = (uint32_t)row * (uint32_t)(a.Cin * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
+            glds16(xs + off, dst + i * 1024);
+        }
+    };
+    auto stage_y = [&](int st, int buf) {
+        const char* ys = yg + (long)st * ystep;
+        char* lb = ybase + buf * Cfg::YS;
+#pragma unroll
+        for (int i = 0; i < Cfg::IPWY; ++i) {
+            const int ii = i * NW + w;
+            if ((i + 1) * NW <= Cfg::NIY || ii < Cfg::NIY) glds16(ys + voffy[i], lb + ii * 1024);
+        }
+    };
+
+    f32x16 acc[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+    // per tap: byte offset of this lane's first row in the ring (advances 64 rows per step) and the
+    // constant column part (swizzle follows row & 3, which neither the step nor the wrap changes)
+    uint32_t rbB[NTAP], cb[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const int row = 8 * hh + qq + ((T0 + t) / 3) * pitch + ((T0 + t) % 3);
+        const int fx = wg9_swz<ROWX, SZ>(row);
+        rbB[t] = ((uint32_t)row * ROWX) & maskB;
+        cb[t] = lbase | (uint32_t)((((wi * 4 + 2 * g1 + (pp >> 1)) ^ fx) * 16) + (pp & 1) * 8);
+    }
+
+    if (nsteps > 0) {
+        for (int g = 0; g < G; ++g) stage_x(g);
+        stage_y(0, 0);
+    }
+    for (int st = 0; st < nsteps; ++st) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (st + 1 < nsteps) {
+            stage_x(st + G);
+            stage_y(st + 1, (st + 1) & 1);
+        }
+        const char* ys = ybase + (st & 1) * Cfg::YS;
+        const int fy = wg9_swz<ROWY, SZ>(qq);
+        const char* pyb = ys + (8 * hh + qq) * ROWY + (((wo * 4 + 2 * g1 + (pp >> 1)) ^ fy) * 16) + (pp & 1) * 8;
+        typedef typename Elem<T>::frag frag_t;
+        frag_t fa0[NTAP], fa1[NTAP], fb0, fb1;
+        auto load_group = [&](int kg, frag_t (&fa)[NTAP], frag_t& fb) {
+            const char* py = pyb + kg * 16 * ROWY;
+            fb = tr_frag<T>(py, py + 4 * ROWY);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const uint32_t o0 = ((rbB[t] + (uint32_t)(kg * 16 * ROWX)) & maskB) | cb[t];
+                const uint32_t o1 = ((rbB[t] + (uint32_t)((kg * 16 + 4) * ROWX)) & maskB) | cb[t];
+                fa[t] = tr_frag_off<T>(o0, o1);
+            }
+        };
+        load_group(0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kg = 0; kg < BKP / 16; kg += 2) {
+            load_group(kg + 1, fa1, fb1);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) mma32(acc[t], fa0[t], fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kg + 2 < BKP / 16) load_group(kg + 2, fa0, fb0);
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) mma32(acc[t], fa1[t], fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) rbB[t] = (rbB[t] + 64u * ROWX) & maskB;
+    }
+    const int co = co0 + wo * 32 + r32;
+    if (co < a.Cout) {
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int ci = ci0 + wi * 32 + acc_row(q, hh);
+                if (ci < a.Cin) {
+                    float* dst = a.dW + ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
+                    if (a.splitk == 1) *dst = acc[t][q] * a.scale;
+                    else atomicAdd(dst, acc[t][q] * a.scale);
+                }
+            }
+    }
+}
+
+template <typename T, int WI, int WO, int TG>
+__global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9r_kernel(WgradArgs a, int lgR, int G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (TG == 1) {
+        wg9r_body<T, WI, WO, 1, 0, 9>(a, lgR, G, smem);
+    } else {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (w < WI * WO) wg9r_body<T, WI, WO, 2, 0, 5>(a, lgR, G, smem);
+        else wg9r_body<T, WI, WO, 2, 5, 4>(a, lgR, G, smem);
+    }
+}
+
+// blocks_target: split-K so that tiles * splitk ~ blocks_target; 0 = one full wave of resident
+// blocks (256 CUs x blocks per CU by LDS, at most 3: measured best on every long-row shape --
+// 1.5 waves of blocks cost 30 % at 104x104)
+template <typename T, int WI, int WO, int TG>
+static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0) {
+    typedef Wg9Cfg<T, WI, WO, TG> Cfg;
+    static_assert(Cfg::NIY % Cfg::NW == 0, "dY pieces must split evenly over waves");
+    const int pitch = a.W + 1;
+    const int wrows = Cfg::BKP + 2 * pitch + 2;
+    const int G = (wrows + 63) / 64;
+    int lgR = 7;
+    while ((1 << lgR) < 64 * (G + 1)) ++lgR;
+    const size_t lds = ((size_t)Cfg::ROWX << lgR) + 2 * (size_t)Cfg::YS;
+    if (lds > 160 * 1024) return hipErrorOutOfMemory;
+    auto kern = wgrad9r_kernel<T, WI, WO, TG>;
+    const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
+    const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
+    const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
+    const int tiles = nIT * nOT;
+    if (blocks_target <= 0) {
+        int bpc = (int)((160 * 1024) / lds);
+        bpc = bpc > 3 ? 3 : (bpc < 1 ? 1 : bpc);
+        blocks_target = 256 * bpc;
+    }
+    if (a.splitk <= 0) {
+        long sk = blocks_target / tiles;
+        const long maxsk = (ksteps + 4 * G - 1) / (4 * G);   // the G-group prologue must stay a small part of a block
+        if (sk > maxsk) sk = maxsk;
+        if (sk < 1) sk = 1;
+        a.splitk = (int)sk;
+    }
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), lds, s, a, lgR, G);
+    return hipGetLastError();
+}
+
 template <typename T, int WI, int WO, int NS, int TG = 1>
 static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s) {
     typedef Wg9Cfg<T, WI, WO, TG> Cfg;
@@ -265,6 +481,19 @@ template <typename T>
 static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
     // measured (scripts/bench_wgrad.py): narrow co tiles with the taps split over two waves --
     // many small blocks, two waves per SIMD -- beat 64x64 tiles on every Darknet-19 shape
+    if constexpr (sizeof(T) == 2) {
+        // long rows: the ring form stages 64 new rows per step instead of the whole window
+        static const int minw = getenv("Y2DEV_WG9R_MINW") ? atoi(getenv("Y2DEV_WG9R_MINW")) : 52;
+        if (a.W >= minw) {
+            hipError_t e;
+            // 32 ci x 64 co tiles (64-byte X rows: a smaller ring, three blocks per CU) from 104 up
+            if (a.Cin >= 64 && !(a.W >= 104 && a.Cdy >= 64)) e = wg9r_launch<T, 2, 1, 2>(a, s);
+            else if (a.Cdy >= 64) e = wg9r_launch<T, 1, 2, 2>(a, s);
+            else e = wg9r_launch<T, 1, 1, 2>(a, s);
+            if (e != hipErrorOutOfMemory) return e;
+            (void)hipGetLastError();
+        }
+    }
     if (a.Cin >= 64) return wg9_launch_ns<T, 2, 1, 2, 2>(a, s);     // 64 ci x 32 co, 4 waves
     if (a.Cdy >= 64) return wg9_launch_ns<T, 1, 2, 2, 2>(a, s);     // 32 ci x 64 co, 4 waves
     return wg9_launch_ns<T, 1, 1, 2, 2>(a, s);
@@ -303,6 +532,21 @@ hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s)
         case 13: return wg9_launch_ns<half_t, 1, 2, 2, 2>(a, s);     // 32 x 64 tiles, 4 waves
         case 14: return wg9_launch_ns<half_t, 2, 1, 3, 2>(a, s);     // 64 x 32, 3 stages
         case 16: return wg9_launch_ns<half_t, 2, 1, 2, 1>(a, s);     // 64 x 32 tiles, 2 waves (no tap split)
+        // ring form (long rows)
+        case 30: return wg9r_launch<half_t, 2, 1, 2>(a, s, 768);     // 64 x 32, 4 waves
+        case 31: return wg9r_launch<half_t, 1, 2, 2>(a, s, 768);     // 32 x 64, 4 waves
+        case 32: return wg9r_launch<half_t, 1, 1, 2>(a, s, 768);     // 32 x 32, 2 waves
+        case 33: return wg9r_launch<half_t, 2, 2, 2>(a, s, 768);     // 64 x 64, 8 waves
+        case 34: return wg9r_launch<half_t, 2, 1, 2>(a, s, 512);
+        case 35: return wg9r_launch<half_t, 1, 2, 2>(a, s, 512);
+        case 36: return wg9r_launch<half_t, 2, 2, 2>(a, s, 512);
+        case 37: return wg9r_launch<half_t, 2, 1, 2>(a, s, 1024);
+        case 38: return wg9r_launch<half_t, 1, 2, 2>(a, s, 1024);
+        case 39: return wg9r_launch<half_t, 2, 2, 2>(a, s, 1024);
+        case 40: return wg9r_launch<half_t, 1, 2, 2>(a, s, 384);
+        case 41: return wg9r_launch<half_t, 1, 2, 2>(a, s, 256);
+        case 42: return wg9r_launch<half_t, 2, 1, 2>(a, s, 384);
+        case 43: return wg9r_launch<half_t, 2, 1, 2>(a, s, 256);
     }
     return hipErrorInvalidValue;
 }
