@@ -95,7 +95,7 @@ struct PackLayer {
     int taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy;
     int wf_bx, wf_by, wf_blocks, wd_blocks, first_block;
 };
-void pack_layer_plan(PackLayer& L, int first_block);
+void pack_layer_plan(PackLayer& L, int first_block, int elem_size);
 hipError_t launch_pack_all(int dtype, const PackLayer* tab_dev, int nlayers, int total_blocks, hipStream_t s);
 hipError_t launch_convert_grad(int dtype, const float* src, void* dst, int M, int C, int ldd, float scale,
                                hipStream_t s);

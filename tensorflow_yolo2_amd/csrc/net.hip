@@ -366,7 +366,7 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
         p.wd = (training && l > 0) ? (void*)(c->ws + y.wd) : nullptr;
         p.taps = y.k * y.k; p.Cin = y.cin; p.Cout = y.cout; p.Cout_pad = y.cout_pad; p.Kc = y.cin_s;
         p.Cin_pad = y.cin_pad; p.Cdy = y.ldy;
-        pack_layer_plan(p, nb);
+        pack_layer_plan(p, nb, (int)c->sz());
         nb += p.wf_blocks + p.wd_blocks;
         c->packtab.push_back(p);
     }

@@ -205,51 +205,80 @@ hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, in
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restrict__ tab, int nlayers) {
-    __shared__ float tile[32][33];
+    constexpr int EPC = 16 / sizeof(T);       // elements per 16-byte store
+    constexpr int CPR = 64 / EPC;             // chunks per 64-element tile row
+    constexpr int RPP = 256 / CPR;            // tile rows per pass of the block
+    __shared__ float tile[64][65];
     int l = 0;
     const int b = blockIdx.x;
     while (l + 1 < nlayers && b >= tab[l + 1].first_block) ++l;
     const PackLayer L = tab[l];
     const int local = b - L.first_block;
     const float* __restrict__ W = L.W;
+    const int tid = threadIdx.x;
     if (local < L.wf_blocks) {
+        // wf[co][t][ci] <- W[t][ci][co]: 64 x 64 transpose through LDS, 256-byte rows in, 16-byte chunks out
         T* __restrict__ wf = (T*)L.wf;
         const int bx = local % L.wf_bx, by = (local / L.wf_bx) % L.wf_by, t = local / (L.wf_bx * L.wf_by);
-        const int ci0 = by * 32, co0 = bx * 32;
-        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-        for (int r = ty; r < 32; r += 8) {
+        const int ci0 = by * 64, co0 = bx * 64;
+        const int tx = tid & 63, ty = tid >> 6;
+        for (int r = ty; r < 64; r += 4) {
             const int ci = ci0 + r, co = co0 + tx;
             tile[r][tx] = (ci < L.Cin && co < L.Cout) ? W[((size_t)t * L.Cin + ci) * L.Cout + co] : 0.f;
         }
         __syncthreads();
-        for (int r = ty; r < 32; r += 8) {
-            const int co = co0 + r, ci = ci0 + tx;
-            if (co < L.Cout_pad && ci < L.Kc) wf[((size_t)co * L.taps + t) * L.Kc + ci] = Elem<T>::from_f32(tile[tx][r]);
+        const int cs = tid % CPR, cr = tid / CPR;
+#pragma unroll
+        for (int p = 0; p < 64 / RPP; ++p) {
+            const int col = p * RPP + cr;
+            const int co = co0 + col, ci = ci0 + cs * EPC;
+            if (co < L.Cout_pad && ci < L.Kc) {
+                Chunk<T> o;
+#pragma unroll
+                for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[cs * EPC + k][col]);
+                st_chunk<T>(wf + ((size_t)co * L.taps + t) * L.Kc + ci, o);
+            }
         }
     } else if (L.wd) {
+        // wd[ci][t][co] <- W[taps-1-t][ci][co]: rows stay co-contiguous, 16-byte chunks both ways
         T* __restrict__ wd = (T*)L.wd;
-        const size_t total = (size_t)L.Cin_pad * L.taps * L.Cdy;
-        const size_t i0 = (size_t)(local - L.wf_blocks) * 1024;
+        const int cpr = L.Cdy / EPC;                                    // chunks per row
+        const uint32_t total = (uint32_t)L.Cin_pad * L.taps * cpr;
+        const uint32_t i0 = (uint32_t)(local - L.wf_blocks) * 1024u;
+        const bool vec = (L.Cout % 4) == 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const size_t i = i0 + k * 256 + threadIdx.x;
+            const uint32_t i = i0 + k * 256 + tid;
             if (i < total) {
-                const int co = (int)(i % L.Cdy);
-                const int t = (int)((i / L.Cdy) % L.taps);
-                const int ci = (int)(i / ((size_t)L.Cdy * L.taps));
-                float v = 0.f;
-                if (ci < L.Cin && co < L.Cout) v = W[((size_t)(L.taps - 1 - t) * L.Cin + ci) * L.Cout + co];
-                wd[i] = Elem<T>::from_f32(v);
+                const int cc = (int)(i % (uint32_t)cpr);
+                const uint32_t q = i / (uint32_t)cpr;
+                const int tt = (int)(q % (uint32_t)L.taps), ci = (int)(q / (uint32_t)L.taps);
+                const int co = cc * EPC;
+                Chunk<T> o;
+                const float* src = W + ((size_t)(L.taps - 1 - tt) * L.Cin + ci) * L.Cout + co;
+                if (ci < L.Cin && vec && co + EPC <= L.Cout) {
+#pragma unroll
+                    for (int e4 = 0; e4 < EPC; e4 += 4) {
+                        const f32x4 v = *(const f32x4*)(src + e4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o.v[e4 + j] = Elem<T>::from_f32(v[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e)
+                        o.v[e] = Elem<T>::from_f32((ci < L.Cin && co + e < L.Cout) ? src[e] : 0.f);
+                }
+                st_chunk<T>(wd + (size_t)i * EPC, o);
             }
         }
     }
 }
 
-void pack_layer_plan(PackLayer& L, int first_block) {
-    L.wf_bx = (L.Cout_pad + 31) / 32;
-    L.wf_by = (L.Kc + 31) / 32;
+void pack_layer_plan(PackLayer& L, int first_block, int elem_size) {
+    L.wf_bx = (L.Cout_pad + 63) / 64;
+    L.wf_by = (L.Kc + 63) / 64;
     L.wf_blocks = L.wf ? L.wf_bx * L.wf_by * L.taps : 0;
-    const size_t total = (size_t)L.Cin_pad * L.taps * L.Cdy;
+    const size_t total = (size_t)L.Cin_pad * L.taps * L.Cdy / (16 / elem_size);   // 16-byte chunks, 1024 per block
     L.wd_blocks = L.wd ? (int)((total + 1023) / 1024) : 0;
     L.first_block = first_block;
 }
