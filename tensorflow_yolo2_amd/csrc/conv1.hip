@@ -8,12 +8,13 @@
 //   * persistent waves; epilogue repacks through a wave-private LDS patch so the
 //     stores are whole 64-byte pixel rows, 1 KiB contiguous per wave-instruction
 //   * BN statistics as bias-shifted sums per wave, Chan-merged per block.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
 namespace y2 {
 
-template <typename T>
+template <typename T, bool STORE>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
     typedef typename Elem<T>::frag frag_t;
     // a pixel is 4*SZ bytes, so a fragment load is only 8-byte aligned at f16/bf16
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
             Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
             const int pp = tile * 32 + prow;
             if (pp < a.M) {
-                st_chunk<T>((char*)a.y + ((size_t)pp * 32 + ch * EPC) * SZ, c);
+                if (STORE) st_chunk<T>((char*)a.y + ((size_t)pp * 32 + ch * EPC) * SZ, c);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float d = Elem<T>::to_f32(c.v[e]) - bsh[e];
@@ -149,13 +150,269 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
     }
 }
 
+// Statistics-only pass (first pass of the pooled first layer): no output, so no transpose either --
+// every lane keeps bias-shifted sums of its 16 couts (values rounded to T as they WILL be stored by
+// the second pass) over all its tiles; lanes are reduced once, at the end.
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_stats_kernel(Conv1Args a) {
+    typedef typename Elem<T>::frag frag_t;
+    struct __attribute__((packed, aligned(8))) UFrag { frag_t v; };
+    constexpr int SZ = sizeof(T);
+    constexpr int KGC = 16 * SZ / 32;
+    __shared__ float st[4 * 32 * 3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    frag_t fw[3][KGC];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int g = 0; g < KGC; ++g)
+            fw[kh][g] = *(const frag_t*)((const char*)a.w + ((r32 * 3 + kh) * 16) * SZ + 32 * g + 16 * hh);
+    float bq[16], s1[16], s2[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        bq[q] = a.bias[acc_row(q, hh)];
+        s1[q] = s2[q] = 0.f;
+    }
+    const int ntiles = (a.M + 31) / 32;
+    const int nwaves = gridDim.x * 4;
+    const int rowpitch = (a.W + 1) * 4 * SZ;
+    const int hw = a.H * a.W;
+    int my_cnt = 0;
+    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += nwaves) {
+        const int p = tile * 32 + r32;
+        const bool pv = p < a.M;
+        uint32_t base = 0;
+        if (pv) {
+            const int n = p / hw, rem = p - n * hw;
+            const int h = rem / a.W, ww = rem - h * a.W;
+            base = (uint32_t)(bpix(n, h, ww, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(4 * SZ);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        frag_t fx[3][KGC];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int g = 0; g < KGC; ++g)
+                fx[kh][g] = ((const UFrag*)((const char*)a.x4 + base + kh * rowpitch + 32 * g + 16 * hh))->v;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int g = 0; g < KGC; ++g) mma32(acc, fw[kh][g], fx[kh][g]);
+        const float vm = pv ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float d = (Elem<T>::to_f32(Elem<T>::from_f32(acc[q] + bq[q])) - bq[q]) * vm;
+            s1[q] += d;
+            s2[q] = fmaf(d, d, s2[q]);
+        }
+        int tc = a.M - tile * 32;
+        my_cnt += tc > 32 ? 32 : tc;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) {
+            s1[q] = wave_sum_xor(s1[q], msk);
+            s2[q] = wave_sum_xor(s2[q], msk);
+        }
+    if (r32 == 0) {
+        const float n = (float)my_cnt;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int co = acc_row(q, hh);
+            const float md = n > 0 ? s1[q] / n : 0.f;
+            st[(w * 32 + co) * 3 + 0] = n;
+            st[(w * 32 + co) * 3 + 1] = bq[q] + md;
+            st[(w * 32 + co) * 3 + 2] = n > 0 ? fmaxf(s2[q] - s1[q] * md, 0.f) : 0.f;
+        }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float n_acc = 0.f, mean_acc = 0.f, m2_acc = 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const float nk = st[(k * 32 + tid) * 3 + 0];
+            if (nk == 0.f) continue;
+            const float mk = st[(k * 32 + tid) * 3 + 1], vk = st[(k * 32 + tid) * 3 + 2];
+            const float nn = n_acc + nk, dlt = mk - mean_acc;
+            mean_acc += dlt * (nk / nn);
+            m2_acc += vk + dlt * dlt * (n_acc * nk / nn);
+            n_acc = nn;
+        }
+        a.part_mean[blockIdx.x * 32 + tid] = mean_acc;
+        a.part_m2[blockIdx.x * 32 + tid] = m2_acc;
+        if (tid == 0) a.part_cnt[blockIdx.x] = n_acc;
+    }
+}
+
 hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
     dim3 g(a.nblocks), b(256);
-    switch (dtype) {
-        case 0: hipLaunchKernelGGL(conv1_fwd_kernel<float>, g, b, 0, s, a); break;
-        case 1: hipLaunchKernelGGL(conv1_fwd_kernel<half_t>, g, b, 0, s, a); break;
-        case 2: hipLaunchKernelGGL(conv1_fwd_kernel<bf16_t>, g, b, 0, s, a); break;
-        default: return hipErrorInvalidValue;
+    static const bool dev_old = getenv("Y2DEV_C1STATS_OLD") != nullptr;
+    if (a.stats_only && dev_old) {
+        switch (dtype) {
+            case 0: hipLaunchKernelGGL((conv1_fwd_kernel<float, false>), g, b, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((conv1_fwd_kernel<half_t, false>), g, b, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t, false>), g, b, 0, s, a); break;
+        }
+    } else if (a.stats_only) {
+        switch (dtype) {
+            case 0: hipLaunchKernelGGL(conv1_stats_kernel<float>, g, b, 0, s, a); break;
+            case 1: hipLaunchKernelGGL(conv1_stats_kernel<half_t>, g, b, 0, s, a); break;
+            case 2: hipLaunchKernelGGL(conv1_stats_kernel<bf16_t>, g, b, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (dtype) {
+            case 0: hipLaunchKernelGGL((conv1_fwd_kernel<float, true>), g, b, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((conv1_fwd_kernel<half_t, true>), g, b, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t, true>), g, b, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Second pass of the pooled first layer: conv AGAIN (K = 27: recomputing is cheaper than
+// re-reading 64 B/pixel) + batch norm + leaky + 2x2 max pool, writing the conv output (kept
+// for the backward pass) and the pooled activation in one sweep.  Together with the
+// statistics-only first pass this replaces  conv1 (write y) -> finalize -> bn_act (read y):
+// the 709 MB read of y at 416x416x64 disappears.
+// A wave tile is 2 image rows x 32 columns: two accumulators share the four input rows; the
+// wave-private LDS patch [64 px][32 co] feeds both the 1-KiB row stores of y and the 2x2 windows.
+// ---------------------------------------------------------------------------
+template <typename T, bool STOREY>
+__global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
+    typedef typename Elem<T>::frag frag_t;
+    struct __attribute__((packed, aligned(8))) UFrag { frag_t v; };
+    constexpr int SZ = sizeof(T);
+    constexpr int KGC = 16 * SZ / 32;
+    constexpr int EROW = 32 * SZ + 16;
+    constexpr int EPC = 16 / SZ;
+    constexpr int CPR = 32 / EPC;            // chunks per pixel row (4: f16/bf16, 8: f32)
+    constexpr int RPIe = 64 / CPR;           // pixels per wave instruction
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * EROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    char* ew = smem + w * 64 * EROW;
+
+    frag_t fw[3][KGC];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int g = 0; g < KGC; ++g)
+            fw[kh][g] = *(const frag_t*)((const char*)a.w + ((r32 * 3 + kh) * 16) * SZ + 32 * g + 16 * hh);
+    float b4[4][4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[q4][j] = a.bias[8 * q4 + 4 * hh + j];
+    const int ch = lane % CPR, pl = lane / CPR;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = a.scale[ch * EPC + e];
+        sh[e] = a.shift[ch * EPC + e];
+    }
+
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    const int nseg = (a.W + 31) / 32;
+    const int ntiles = a.N * Ho * nseg;
+    const int nwaves = gridDim.x * 4;
+    const int rowpitch = (a.W + 1) * 4 * SZ;
+    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += nwaves) {
+        const int sg = tile % nseg, pr = tile / nseg;
+        const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho, w0 = sg * 32;
+        const int wc = (w0 + r32 < a.W) ? w0 + r32 : a.W - 1;      // clamp (masked at the stores)
+        const uint32_t base = (uint32_t)(bpix(n, h0, wc, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(4 * SZ);
+        frag_t fx[4][KGC];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < KGC; ++g)
+                fx[r][g] = ((const UFrag*)((const char*)a.x4 + base + r * rowpitch + 32 * g + 16 * hh))->v;
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[r][q] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int g = 0; g < KGC; ++g) mma32(acc[r], fw[kh][g], fx[r + kh][g]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                T o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = Elem<T>::from_f32(acc[r][4 * q4 + j] + b4[q4][j]);
+                char* dst = ew + (r * 32 + r32) * EROW + (8 * q4 + 4 * hh) * SZ;
+                if (SZ == 2) *(u32x2*)dst = *(const u32x2*)o;
+                else *(u32x4*)dst = *(const u32x4*)o;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (STOREY) {
+#pragma unroll
+            for (int it = 0; it < 64 / RPIe; ++it) {
+                const int prow = it * RPIe + pl;            // patch row = r*32 + column
+                const int r = prow >> 5, col = prow & 31;
+                if (w0 + col < a.W) {
+                    Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
+                    st_chunk<T>((char*)a.y + (((size_t)(n * a.H + h0 + r) * a.W + w0 + col) * 32 + ch * EPC) * SZ, c);
+                }
+            }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 16 / RPIe; ++ps) {
+            const int j = ps * RPIe + pl;                   // pooled pixel of the tile, 0..15
+            float m[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                Chunk<T> c = ld_chunk<T>(ew + ((d >> 1) * 32 + 2 * j + (d & 1)) * EROW + ch * 16);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], leaky01(fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e])));
+            }
+            const int wo = w0 / 2 + j;
+            if (wo < Wo) {
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(m[e]);
+                st_chunk<T>((char*)a.out + (bpix(n, ho, wo, Ho, Wo) * 32 + ch * EPC) * SZ, o);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+bool conv1_pool_ok(int H, int W, int pool, int cout) { return pool && (H % 2) == 0 && (W % 2) == 0 && cout == 32; }
+
+hipError_t launch_conv1_pool(int dtype, const Conv1PoolArgs& a, hipStream_t s) {
+    dim3 g(a.nblocks), b(256);
+    if (a.store_y) {
+        switch (dtype) {
+            case 0: hipLaunchKernelGGL((conv1_pool_kernel<float, true>), g, b, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((conv1_pool_kernel<half_t, true>), g, b, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv1_pool_kernel<bf16_t, true>), g, b, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (dtype) {
+            case 0: hipLaunchKernelGGL((conv1_pool_kernel<float, false>), g, b, 0, s, a); break;
+            case 1: hipLaunchKernelGGL((conv1_pool_kernel<half_t, false>), g, b, 0, s, a); break;
+            case 2: hipLaunchKernelGGL((conv1_pool_kernel<bf16_t, false>), g, b, 0, s, a); break;
+            default: return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }

@@ -40,8 +40,23 @@ struct Conv1Args {
     float* part_m2;
     int N, H, W, M;
     int nblocks;        // persistent grid size == number of partials
+    int stats_only;     // 1: batch-norm partials only, y is not written (first pass of the pooled form)
 };
 hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s);
+// pooled first layer, second pass: conv again + BN + leaky + 2x2 max pool -> y (optional) and the pooled output
+struct Conv1PoolArgs {
+    const void* x4;
+    const void* w;
+    void* y;            // [M][32] (written when store_y)
+    const float* bias;
+    const float *scale, *shift;
+    void* out;          // zero-bordered [N][Ho+2][Wo+2][32] of T
+    int N, H, W;
+    int nblocks;
+    int store_y;
+};
+bool conv1_pool_ok(int H, int W, int pool, int cout);
+hipError_t launch_conv1_pool(int dtype, const Conv1PoolArgs& a, hipStream_t s);
 struct Conv1WgradArgs {
     const void* x4;     // [N][H+2][W+2][4]
     const void* dy;     // zero-bordered [N][H+2][W+2][32]

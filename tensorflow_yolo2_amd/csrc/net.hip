@@ -436,6 +436,8 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
         float* stat = (float*)(c->ws + y.stat);
         float *scale = stat, *shift = stat + y.ldy, *mean = stat + 2 * y.ldy, *invstd = stat + 3 * y.ldy;
         int P = 0;
+        // pooled first layer: statistics-only conv, then conv again fused with BN + leaky + pool
+        const bool pool1 = y.first3 && l + 1 < nl && y.ldy == 32 && conv1_pool_ok(y.H, y.W, y.pool, y.cout);
         if (y.first3) {
             { PROF(CAT_MISC); HIPCHK(launch_pack_input(c->dtype, images, xin, c->N, y.H, y.W, s)); }
             Conv1Args a{};
@@ -445,7 +447,8 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
             int nb = (y.M + 127) / 128;
             a.nblocks = nb > 2048 ? 2048 : nb;
             P = a.nblocks;
-            { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
+            a.stats_only = pool1 ? 1 : 0;
+            if (!pool1 || training) { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
         } else {
             if (l == 0) HIPCHK(launch_pack_act(c->dtype, images, xin, c->N, y.H, y.W, y.cin, y.cin_s, s));
             ConvArgs a{};
@@ -470,6 +473,18 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
         } else {
             HIPCHK(launch_bn_infer_prepare(c->params + y.pg, c->params + y.pbeta, c->state + y.smm, c->state + y.smv,
                                            scale, shift, mean, invstd, y.cout, kBnEps, s));
+        }
+        if (pool1) {
+            Conv1PoolArgs q{};
+            q.x4 = xin; q.w = c->ws + y.wf; q.y = c->ws + y.y; q.bias = c->params + y.pb;
+            q.scale = scale; q.shift = shift;
+            q.out = c->ws + c->L[l + 1].xin + c->in_geom(l + 1).base_off(sz);
+            q.N = c->N; q.H = y.H; q.W = y.W;
+            const int tiles = c->N * (y.H / 2) * ((y.W + 31) / 32);
+            q.nblocks = (tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4;
+            q.store_y = c->bound_training ? 1 : 0;
+            HIPCHK(launch_conv1_pool(c->dtype, q, s));
+            continue;
         }
         BnActArgs b{};
         b.y = c->ws + y.y; b.scale = scale; b.shift = shift;
@@ -584,6 +599,9 @@ int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
         HIPCHK(launch_unpack_act(c->dtype, c->ws + y.xin + c->in_geom(l).base_off(sz), dst, c->N, y.H, y.W, C,
                                  y.cin_s, s));
     } else if (what == 1) {
+        if (y.first3 && !c->bound_training && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
+            conv1_pool_ok(y.H, y.W, y.pool, y.cout))
+            return fail(Y2_ERR_STATE, "inference binding: the pooled first layer does not store its conv output");
         HIPCHK(launch_cast_to_f32(c->dtype, c->ws + y.y, dst, (size_t)y.M, y.cout, y.ldy, s));
     } else if (what == 2) {
         if (!c->bound_training) return fail(Y2_ERR_STATE, "no gradients in inference binding");
