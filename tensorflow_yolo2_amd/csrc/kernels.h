@@ -25,6 +25,8 @@ struct ConvArgs {
 };
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
+hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels); // + filters via registers
+bool conv_frag_filters(int taps, int W);   // does launch_conv expect fragment-ordered filters for this shape?
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels = nullptr);  // policy
 int conv_block_pixels(int Cout);
 int conv_block_couts(int Cout);
@@ -100,7 +102,7 @@ hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H
 // dgrad: wd[ci][t'][co] = W[8-t'][ci][co]       rows ci >= Cin zero, cols co >= Cout zero (Cdy cols)
 //   Kc = row length per tap of wf (>= Cin, zero beyond Cin)
 hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, int taps, int Cin, int Cout,
-                               int Cout_pad, int Kc, int Cin_pad, int Cdy, hipStream_t s);
+                               int Cout_pad, int Kc, int Cin_pad, int Cdy, int frag, hipStream_t s);
 hipError_t launch_pack_conv1_weights(int dtype, const float* W, void* wp, hipStream_t s);
 // all layers in one launch: table entry per layer (device copy lives in the workspace)
 struct PackLayer {
@@ -109,6 +111,7 @@ struct PackLayer {
     void* wd;           // null: no dgrad copy
     int taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy;
     int wf_bx, wf_by, wf_blocks, wd_blocks, first_block;
+    int frag;           // 1: MFMA-fragment order (conv_haloq.hip) instead of K-contiguous rows
 };
 void pack_layer_plan(PackLayer& L, int first_block, int elem_size);
 hipError_t launch_pack_all(int dtype, const PackLayer* tab_dev, int nlayers, int total_blocks, hipStream_t s);

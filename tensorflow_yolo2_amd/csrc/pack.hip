@@ -143,9 +143,18 @@ hipError_t launch_convert_grad(int dtype, const float* src, void* dst, int M, in
 //   wd[ci][t][co]  = W[taps-1-t][ci][co]  (rows ci in [0,Cin_pad), cols co in [0,Cdy)) dgrad
 // Tiled transpose through LDS so both the fp32 reads and the T writes coalesce.
 // ---------------------------------------------------------------------------
+// MFMA-fragment order (conv_haloq.hip): [row tile of 32][tap][k-group of 32 bytes][lane = hh*32 + row%32][16 B];
+// returns the 16-byte chunk index of element (row, tap, k), k a multiple of EPC
+__host__ __device__ inline size_t frag_chunk(int row, int t, int k, int taps, int krow, int EPC) {
+    const int kgrow = krow / (2 * EPC);
+    const int kg = k / (2 * EPC), hh = (k / EPC) & 1;
+    return ((size_t)(row >> 5) * taps * kgrow + (size_t)t * kgrow + kg) * 64 + hh * 32 + (row & 31);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_wf_kernel(const float* __restrict__ W, T* __restrict__ wf, int taps,
-                                                      int Cin, int Cout, int Cout_pad, int Kc) {
+                                                      int Cin, int Cout, int Cout_pad, int Kc, int frag) {
+    constexpr int EPC = 16 / sizeof(T);
     __shared__ float tile[32][33];
     const int t = blockIdx.z;
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
@@ -157,12 +166,17 @@ __global__ __launch_bounds__(256) void pack_wf_kernel(const float* __restrict__ 
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
-        if (co < Cout_pad && ci < Kc) wf[((size_t)co * taps + t) * Kc + ci] = Elem<T>::from_f32(tile[tx][r]);
+        if (co < Cout_pad && ci < Kc) {
+            const size_t o = frag ? frag_chunk(co, t, ci - ci % EPC, taps, Kc, EPC) * EPC + ci % EPC
+                                  : ((size_t)co * taps + t) * Kc + ci;
+            wf[o] = Elem<T>::from_f32(tile[tx][r]);
+        }
     }
 }
 template <typename T>
 __global__ void pack_wd_kernel(const float* __restrict__ W, T* __restrict__ wd, int taps, int Cin, int Cout,
-                               int Cin_pad, int Cdy) {
+                               int Cin_pad, int Cdy, int frag) {
+    constexpr int EPC = 16 / sizeof(T);
     const size_t total = (size_t)Cin_pad * taps * Cdy;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int co = (int)(i % Cdy);
@@ -170,31 +184,32 @@ __global__ void pack_wd_kernel(const float* __restrict__ W, T* __restrict__ wd, 
         const int ci = (int)(i / ((size_t)Cdy * taps));
         float v = 0.f;
         if (ci < Cin && co < Cout) v = W[((size_t)(taps - 1 - t) * Cin + ci) * Cout + co];
-        wd[i] = Elem<T>::from_f32(v);
+        const size_t o = frag ? frag_chunk(ci, t, co - co % EPC, taps, Cdy, EPC) * EPC + co % EPC : i;
+        wd[o] = Elem<T>::from_f32(v);
     }
 }
 template <typename T>
 static hipError_t pack_weights_T(const float* W, void* wf, void* wd, int taps, int Cin, int Cout, int Cout_pad,
-                                 int Kc, int Cin_pad, int Cdy, hipStream_t s) {
+                                 int Kc, int Cin_pad, int Cdy, int frag, hipStream_t s) {
     if (wf) {
         dim3 g((Cout_pad + 31) / 32, (Kc + 31) / 32, taps);
-        hipLaunchKernelGGL(pack_wf_kernel<T>, g, dim3(256), 0, s, W, (T*)wf, taps, Cin, Cout, Cout_pad, Kc);
+        hipLaunchKernelGGL(pack_wf_kernel<T>, g, dim3(256), 0, s, W, (T*)wf, taps, Cin, Cout, Cout_pad, Kc, frag);
     }
     if (wd) {
         size_t total = (size_t)Cin_pad * taps * Cdy;
         size_t nb = (total + 255) / 256;
         if (nb > 16384) nb = 16384;
         hipLaunchKernelGGL(pack_wd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, W, (T*)wd, taps, Cin, Cout, Cin_pad,
-                           Cdy);
+                           Cdy, frag);
     }
     return hipGetLastError();
 }
 hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, int taps, int Cin, int Cout,
-                               int Cout_pad, int Kc, int Cin_pad, int Cdy, hipStream_t s) {
+                               int Cout_pad, int Kc, int Cin_pad, int Cdy, int frag, hipStream_t s) {
     switch (dtype) {
-        case 0: return pack_weights_T<float>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, s);
-        case 1: return pack_weights_T<half_t>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, s);
-        case 2: return pack_weights_T<bf16_t>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, s);
+        case 0: return pack_weights_T<float>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, frag, s);
+        case 1: return pack_weights_T<half_t>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, frag, s);
+        case 2: return pack_weights_T<bf16_t>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, frag, s);
     }
     return hipErrorInvalidValue;
 }
@@ -236,7 +251,8 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
                 Chunk<T> o;
 #pragma unroll
                 for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[cs * EPC + k][col]);
-                st_chunk<T>(wf + ((size_t)co * L.taps + t) * L.Kc + ci, o);
+                if (L.frag) st_chunk<T>(wf + frag_chunk(co, t, ci, L.taps, L.Kc, EPC) * EPC, o);
+                else st_chunk<T>(wf + ((size_t)co * L.taps + t) * L.Kc + ci, o);
             }
         }
     } else if (L.wd) {
@@ -268,7 +284,8 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
                     for (int e = 0; e < EPC; ++e)
                         o.v[e] = Elem<T>::from_f32((ci < L.Cin && co + e < L.Cout) ? src[e] : 0.f);
                 }
-                st_chunk<T>(wd + (size_t)i * EPC, o);
+                if (L.frag) st_chunk<T>(wd + frag_chunk(ci, tt, co, L.taps, L.Cdy, EPC) * EPC, o);
+                else st_chunk<T>(wd + (size_t)i * EPC, o);
             }
         }
     }
