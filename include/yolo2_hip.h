@@ -107,6 +107,26 @@ int y2_decode_detections(const float* predict, int S, int B, int num_class, int 
 int y2_softmax_cross_entropy(const float* logits, const int* labels, int batch, int classes, float* loss,
                              float* dlogits, void* stream);
 
+/* ---- YOLOv2 pieces named by the north star that the reference does NOT contain (SURVEY §8 a-x1, a-x2):
+ *      no reference interface to cite; specification = oracle/ext_ref.py of this repo. ------------- */
+/* reorg / space-to-depth: forward x [N,H,W,C] -> y [N,H/s,W/s,s*s*C], channel ((h%s)*s + w%s)*C + c;
+ * forward = 0: the inverse permutation (x coarse -> y [N,H,W,C]), i.e. the gradient.  Bit-exact copies. */
+int y2_reorg(const float* x, float* y, int N, int H, int W, int C, int stride, int forward, void* stream);
+/* passthrough: out [N,H,W,4*Cf+Cc] = concat(reorg2(fine [N,2H,2W,Cf]), coarse [N,H,W,Cc]) and its gradient */
+int y2_passthrough_concat(const float* fine, const float* coarse, float* out, int N, int H, int W, int Cf, int Cc,
+                          void* stream);
+int y2_passthrough_concat_backward(const float* dout, float* dfine, float* dcoarse, int N, int H, int W, int Cf,
+                                   int Cc, void* stream);
+/* anchor decode: net [N,S,S,B,5+C] (tx,ty,tw,th,to,classes), anchors [B][2] in cell units ->
+ * boxes [N,S*S*B,4] (cx,cy,w,h relative to the image), scores [N,S*S*B,C] = sigmoid(to)*softmax(classes) */
+int y2_decode_anchors(const float* net, const float* anchors, float* boxes, float* scores, int N, int S, int B, int C,
+                      void* stream);
+/* per-image greedy NMS over K <= 4096 candidates: score descending (ties: lower index first), candidates
+ * below score_thresh dropped, a kept box suppresses later boxes with IoU > iou_thresh (same class id only
+ * when class_aware).  keep [N][max_out] original indices (-1 padded), count [N].  Bit-exact vs the spec. */
+int y2_nms(const float* boxes, const float* scores, const int* classes, int N, int K, float iou_thresh,
+           float score_thresh, int max_out, int class_aware, int* keep, int* count, void* stream);
+
 /* ---- optimizers on flat buffers (pascal_train_darknet.py:51, imagenet_train_darknet.py:58) */
 int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n, int step, float lr,
                  float beta1, float beta2, float eps, float grad_mult, void* stream);

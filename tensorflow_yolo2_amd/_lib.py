@@ -48,6 +48,11 @@ SIGNATURES = {
     "y2_get_iou": (_i, [_vp, _vp, _vp, _i, _vp]),
     "y2_decode_detections": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "y2_softmax_cross_entropy": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "y2_reorg": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "y2_passthrough_concat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "y2_passthrough_concat_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "y2_decode_anchors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "y2_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp]),
     "y2_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
     "y2_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),

@@ -353,8 +353,10 @@ static hipError_t c1wgf_T(const Conv1WgradFusedArgs& a, hipStream_t s) {
     return c1wgf_M<T, 0>(a, s);
 }
 
-bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy) {
-    return pool && (H % 2) == 0 && (W % 2) == 0 && ldy == 32;
+bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy, int elem_size) {
+    const int Wp = (W + 15) & ~15;
+    const size_t lds = 2 * (size_t)Wp * 32 * elem_size + 4 * (size_t)((((Wp + 4) * 4 * elem_size) + 15) & ~15);
+    return pool && (H % 2) == 0 && (W % 2) == 0 && ldy == 32 && lds <= 160 * 1024;   // two dy rows + four x rows in LDS
 }
 
 hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s) {

@@ -78,7 +78,7 @@ struct Conv1WgradFusedArgs {
     int N, H, W;
     float inv_grad_scale;
 };
-bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy);
+bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy, int elem_size);
 hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s);
 
 // ---- weight-gradient GEMM  dW[t][ci][co] += sum_p X[p+t][ci] * dY[p][co]

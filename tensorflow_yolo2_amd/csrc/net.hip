@@ -22,6 +22,12 @@
 using namespace y2;
 
 static thread_local std::string g_err;
+namespace y2 {
+int set_error(int code, const char* msg) {   // shared with ext.hip
+    g_err = msg;
+    return code;
+}
+}
 static int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -547,7 +553,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         b.N = c->N; b.H = y.H; b.W = y.W; b.C = y.cout; b.ldy = y.ldy;
         b.ldd = y.ldy;
         b.pool = y.pool; b.training = c->fwd_training[l]; b.inv_grad_scale = inv_gs;
-        const bool fused1 = y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy);
+        const bool fused1 = y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz());
         {
             PROF(CAT_BN_BWD);
             HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
@@ -606,7 +612,7 @@ int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
         HIPCHK(launch_cast_to_f32(c->dtype, c->ws + y.y, dst, (size_t)y.M, y.cout, y.ldy, s));
     } else if (what == 2) {
         if (!c->bound_training) return fail(Y2_ERR_STATE, "no gradients in inference binding");
-        if (y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy))
+        if (y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz()))
             return fail(Y2_ERR_STATE, "the first layer's dy is fused into its weight gradient and never stored");
         HIPCHK(launch_unpack_act(c->dtype, c->ws + y.dyp + c->dy_geom(l).base_off(sz), dst, c->N, y.H, y.W, y.cout,
                                  y.ldy, s));

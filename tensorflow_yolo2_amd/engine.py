@@ -51,7 +51,7 @@ class Network:
     """One conv-BN-leaky(-pool) stack bound to device buffers."""
 
     def __init__(self, spec, batch, height, width, dtype="f16", core_layers=None, tail=_lib.Y2_TAIL_NONE,
-                 tail_k=7, training=True, device="cuda:0", grad_scale=None, bessel=False):
+                 tail_k=7, training=True, device="cuda:0", grad_scale=None, bessel=False, share_with=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.Y2Error("no MI355X visible: tensorflow_yolo2_amd has no CPU path")
@@ -75,9 +75,16 @@ class Network:
         self.out_shape = tuple(shp)
         if tail == _lib.Y2_TAIL_AVGPOOL:
             self.out_shape = (shp[0], shp[3]) if shp[1] == 1 and shp[2] == 1 else tuple(shp)
-        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device) if training else None
-        self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.device)
+        if share_with is not None:
+            # same layers at another input size (the net is fully convolutional): ONE set of parameters,
+            # gradients and BN state, one workspace per size (multi-scale training, 288 GB of HBM to spend)
+            assert share_with.n_params == self.n_params and share_with.n_state == self.n_state
+            self.params, self.grads, self.state = share_with.params, share_with.grads, share_with.state
+            assert not training or self.grads is not None
+        else:
+            self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+            self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device) if training else None
+            self.state = torch.zeros(self.n_state, dtype=torch.float32, device=self.device)
         self.ws_bytes = self.lib.y2_workspace_bytes(h, int(training))
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
         check(self.lib.y2_bind(h, _ptr(self.params), _ptr(self.grads), _ptr(self.state), _ptr(self.workspace),
@@ -278,6 +285,74 @@ def decode_detections(predict, S, B, num_class, im_w, im_h, object_thresh=0.5):
             out.append((int(det[i, 1]), int(det[i, 2]), int(det[i, 3]), int(det[i, 4]), int(det[i, 5]),
                         float(conf[i]), int(det[i, 6]), int(det[i, 7]), i % B))
     return out
+
+
+# ---- YOLOv2 pieces beyond the reference (SURVEY §8 a-x1/a-x2; specification: oracle/ext_ref.py) ----------
+def reorg(x, stride=2, inverse=False):
+    """space-to-depth [N,H,W,C] -> [N,H/s,W/s,s*s*C]; inverse=True: the gradient (depth-to-space)"""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    s = int(stride)
+    if not inverse:
+        n, h, w, c = x.shape
+        y = torch.empty((n, h // s, w // s, s * s * c), dtype=torch.float32, device=x.device)
+        check(lib.y2_reorg(_ptr(x), _ptr(y), n, h, w, c, s, 1, _stream()))
+    else:
+        n, ho, wo, cc = x.shape
+        c = cc // (s * s)
+        y = torch.empty((n, ho * s, wo * s, c), dtype=torch.float32, device=x.device)
+        check(lib.y2_reorg(_ptr(x), _ptr(y), n, ho * s, wo * s, c, s, 0, _stream()))
+    return y
+
+
+def passthrough_concat(fine, coarse):
+    """concat(reorg2(fine [N,2H,2W,Cf]), coarse [N,H,W,Cc]) -> [N,H,W,4*Cf+Cc]"""
+    lib = _lib.load()
+    n, h, w, cc = coarse.shape
+    cf = fine.shape[3]
+    assert tuple(fine.shape[:3]) == (n, 2 * h, 2 * w) and fine.is_contiguous() and coarse.is_contiguous()
+    out = torch.empty((n, h, w, 4 * cf + cc), dtype=torch.float32, device=coarse.device)
+    check(lib.y2_passthrough_concat(_ptr(fine), _ptr(coarse), _ptr(out), n, h, w, cf, cc, _stream()))
+    return out
+
+
+def passthrough_concat_backward(dout, cf):
+    lib = _lib.load()
+    n, h, w, ct = dout.shape
+    cc = ct - 4 * cf
+    assert dout.is_contiguous()
+    dfine = torch.empty((n, 2 * h, 2 * w, cf), dtype=torch.float32, device=dout.device)
+    dcoarse = torch.empty((n, h, w, cc), dtype=torch.float32, device=dout.device)
+    check(lib.y2_passthrough_concat_backward(_ptr(dout), _ptr(dfine), _ptr(dcoarse), n, h, w, cf, cc, _stream()))
+    return dfine, dcoarse
+
+
+def decode_anchors(net, anchors):
+    """net [N,S,S,B,5+C], anchors [B,2] -> boxes [N,S*S*B,4], scores [N,S*S*B,C]"""
+    lib = _lib.load()
+    n, s, _, b, d = net.shape
+    c = d - 5
+    assert net.is_cuda and net.dtype == torch.float32 and net.is_contiguous()
+    an = torch.as_tensor(np.asarray(anchors, np.float32)).to(net.device).contiguous()
+    boxes = torch.empty((n, s * s * b, 4), dtype=torch.float32, device=net.device)
+    scores = torch.empty((n, s * s * b, c), dtype=torch.float32, device=net.device)
+    check(lib.y2_decode_anchors(_ptr(net), _ptr(an), _ptr(boxes), _ptr(scores), n, s, b, c, _stream()))
+    return boxes, scores
+
+
+def nms(boxes, scores, classes=None, iou_thresh=0.5, score_thresh=0.0, max_out=100, class_aware=False):
+    """boxes [N,K,4], scores [N,K] (, classes [N,K] int32) -> keep [N,max_out] int32 (-1 padded), count [N]"""
+    lib = _lib.load()
+    n, k, _ = boxes.shape
+    assert boxes.is_contiguous() and scores.is_contiguous() and scores.dtype == torch.float32
+    keep = torch.empty((n, max_out), dtype=torch.int32, device=boxes.device)
+    count = torch.empty((n,), dtype=torch.int32, device=boxes.device)
+    cl = None
+    if classes is not None:
+        cl = classes.to(torch.int32).contiguous()
+    check(lib.y2_nms(_ptr(boxes), _ptr(scores), _ptr(cl), n, k, float(iou_thresh), float(score_thresh), int(max_out),
+                     int(bool(class_aware)), _ptr(keep), _ptr(count), _stream()))
+    return keep, count
 
 
 def softmax_cross_entropy(logits, labels, need_grad=True):

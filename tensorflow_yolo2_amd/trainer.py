@@ -10,6 +10,7 @@ layer slices on a side stream as soon as backward has finished them (head first:
 its three 37.7 MB filters are 59 % of the payload), overlapping the remaining
 dgrad/wgrad kernels.
 """
+import numpy as np
 import torch
 
 from . import _lib, engine
@@ -103,6 +104,61 @@ class DetectorTrainer:
         world = self.reducer.backward_and_reduce(dnet)
         self.opt.step(grad_mult=1.0 / world)
         self.last = (loss, ious, mask)
+        return loss, ious, mask
+
+
+MULTI_SCALE_SIZES = tuple(range(320, 609, 32))   # YOLOv2 multi-scale schedule (BASELINE.json configs[4])
+
+
+def multi_scale_size(step, sizes=MULTI_SCALE_SIZES, period=10, seed=0):
+    """input size of training step `step`: redrawn every `period` steps, identical on every rank"""
+    rng = np.random.default_rng([seed, step // period])
+    return int(sizes[int(rng.integers(0, len(sizes)))])
+
+
+class MultiScaleDetectorTrainer:
+    """Detector train step at a size that changes every `period` batches ({320..608}, step 32).
+    NOT in the reference (SURVEY §8 a-x2).  One context + workspace per size, created on first use, all
+    bound to the same flat parameter / gradient / BN-state buffers and one Adam state."""
+
+    def __init__(self, batch, sizes=MULTI_SCALE_SIZES, period=10, B=2, num_class=20, dtype="f16", device="cuda:0",
+                 grad_scale=None, seed=0, core_spec=None, head_spec=None):
+        self.batch, self.sizes, self.period, self.seed = batch, tuple(sizes), period, seed
+        self.B, self.num_class, self.dtype, self.device, self.grad_scale = B, num_class, dtype, device, grad_scale
+        self.core_spec = list(core_spec or CORE_SPEC)
+        self.head_spec = list(head_spec or det_head_spec(5 * B + num_class))
+        self.nets, self.reducers = {}, {}
+        self.opt = None
+        self.steps = 0
+
+    def size_for_step(self, step=None):
+        return multi_scale_size(self.steps if step is None else step, self.sizes, self.period, self.seed)
+
+    def _net(self, size):
+        if size not in self.nets:
+            first = next(iter(self.nets.values())) if self.nets else None
+            net = Network(self.core_spec + self.head_spec, self.batch, size, size, dtype=self.dtype,
+                          core_layers=len(self.core_spec), training=True, device=self.device,
+                          grad_scale=self.grad_scale, share_with=first)
+            if first is None:
+                net.init_params(self.seed)
+                self.opt = AdamOptimizer(net)
+            self.nets[size] = net
+            self.reducers[size] = GradReducer(net)
+        return self.nets[size]
+
+    def step(self, images, labels):
+        size = int(images.shape[1])
+        assert size in self.sizes and size == int(images.shape[2]), images.shape
+        net = self._net(size)
+        net.params_changed()                       # the shared parameters moved since this context last ran
+        S = net.out_shape[1]
+        grid_net = net.forward(images, True, True)
+        loss, ious, mask, dnet = yolo_loss(grid_net, labels, self.num_class, self.batch, size, S, self.B)
+        world = self.reducers[size].backward_and_reduce(dnet)
+        self.opt.net = net                         # same flat buffers; keeps params_changed() on the live context
+        self.opt.step(grad_mult=1.0 / world)
+        self.steps += 1
         return loss, ious, mask
 
 

@@ -75,6 +75,24 @@ def main():
         blob["mm%d" % l] = mv[0].astype(np.float32)
         blob["mv%d" % l] = mv[1].astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "tiny_stack.npz"), **blob)
+    # YOLOv2 extension pieces (no reference code exists: vectors of this repo's own specification)
+    from oracle import ext_ref as X
+    rng = np.random.default_rng(7)
+    fine = rng.standard_normal((2, 8, 12, 6)).astype(np.float32)
+    coarse = rng.standard_normal((2, 4, 6, 5)).astype(np.float32)
+    net5 = rng.standard_normal((2, 5, 5, 3, 5 + 4)).astype(np.float32)
+    anchors = np.array([[1.3221, 1.73145], [3.19275, 4.00944], [5.05587, 8.09892]], np.float32)
+    boxes, scores = X.decode_anchors(net5, anchors)
+    K = 160
+    nb = np.concatenate([rng.uniform(0.2, 0.8, (K, 2)), rng.uniform(0.05, 0.4, (K, 2))], axis=1).astype(np.float32)
+    ns = np.round(rng.uniform(0, 1, K), 2).astype(np.float32)          # rounded: ties on purpose
+    ncls = rng.integers(0, 3, K).astype(np.int32)
+    keep_a = np.array(X.nms(nb, ns, None, 0.45, 0.1, 50, False), np.int32)
+    keep_c = np.array(X.nms(nb, ns, ncls, 0.45, 0.1, 50, True), np.int32)
+    np.savez_compressed(os.path.join(HERE, "yolo2_ext_kat.npz"), fine=fine, coarse=coarse,
+                        concat=X.passthrough_concat(fine, coarse), net5=net5, anchors=anchors, boxes=boxes,
+                        scores=scores, nms_boxes=nb, nms_scores=ns, nms_classes=ncls, keep_agnostic=keep_a,
+                        keep_class_aware=keep_c)
     print("golden vectors written to", HERE)
 
 

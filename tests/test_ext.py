@@ -1,0 +1,160 @@
+"""YOLOv2 pieces beyond the reference (SURVEY §8 a-x1 / a-x2): reorg / passthrough concat, anchor decode,
+per-image NMS.  No reference code exists for them, so the specification is oracle/ext_ref.py; the CPU tests
+pin that specification (golden vectors, round trips, a brute-force NMS property), the GPU tests require the
+HIP kernels to reproduce it: bit-exact for the index work, 1e-5 relative for the exp/sigmoid decode."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ext_ref as X
+
+
+def _kat(golden_dir):
+    return np.load(os.path.join(golden_dir, "yolo2_ext_kat.npz"))
+
+
+# ---------------------------------------------------------------- CPU: the specification itself
+def test_spec_reorg_roundtrip_and_golden(golden_dir):
+    g = _kat(golden_dir)
+    np.testing.assert_array_equal(X.passthrough_concat(g["fine"], g["coarse"]), g["concat"])
+    x = np.arange(2 * 4 * 6 * 3, dtype=np.float32).reshape(2, 4, 6, 3)
+    y = X.reorg(x, 2)
+    assert y.shape == (2, 2, 3, 12)
+    # channel order: (h%2)*2 + w%2 major, original channel minor
+    assert y[0, 0, 0, 0] == x[0, 0, 0, 0] and y[0, 0, 0, 3] == x[0, 0, 1, 0]
+    assert y[0, 0, 0, 6] == x[0, 1, 0, 0] and y[0, 0, 0, 11] == x[0, 1, 1, 2]
+    np.testing.assert_array_equal(X.reorg_backward(y, 2), x)
+    df, dc = X.passthrough_concat_backward(g["concat"], g["fine"].shape[3])
+    np.testing.assert_array_equal(df, g["fine"])
+    np.testing.assert_array_equal(dc, g["coarse"])
+
+
+def test_spec_decode_anchors_golden_and_ranges(golden_dir):
+    g = _kat(golden_dir)
+    boxes, scores = X.decode_anchors(g["net5"], g["anchors"])
+    np.testing.assert_array_equal(boxes, g["boxes"])
+    np.testing.assert_array_equal(scores, g["scores"])
+    assert (boxes[..., :2] > 0).all() and (boxes[..., :2] < 1).all() and (boxes[..., 2:] > 0).all()
+    # per anchor the class scores sum to the objectness
+    so = 1.0 / (1.0 + np.exp(-g["net5"][..., 4].astype(np.float64)))
+    np.testing.assert_allclose(scores.sum(-1).reshape(so.shape), so, rtol=1e-5)
+    # zero logits sit at the cell centre with the anchor's size
+    b0, _ = X.decode_anchors(np.zeros((1, 2, 2, 1, 7), np.float32), [[1.0, 2.0]])
+    np.testing.assert_allclose(b0[0, 3], [0.75, 0.75, 0.5, 1.0], rtol=1e-6)
+
+
+def test_spec_nms_golden_and_bruteforce_property(golden_dir):
+    g = _kat(golden_dir)
+    ka = X.nms(g["nms_boxes"], g["nms_scores"], None, 0.45, 0.1, 50, False)
+    kc = X.nms(g["nms_boxes"], g["nms_scores"], g["nms_classes"], 0.45, 0.1, 50, True)
+    np.testing.assert_array_equal(ka, g["keep_agnostic"])
+    np.testing.assert_array_equal(kc, g["keep_class_aware"])
+    b, s = g["nms_boxes"], g["nms_scores"]
+    # kept boxes: sorted by (score desc, index asc), above the threshold, pairwise IoU <= thresh;
+    # every dropped candidate is suppressed by an earlier kept one
+    assert all((s[i] > s[j]) or (s[i] == s[j] and i < j) for i, j in zip(ka[:-1], ka[1:]))
+    assert all(s[i] >= np.float32(0.1) for i in ka)
+    for x in range(len(ka)):
+        for y in range(x + 1, len(ka)):
+            assert X.nms_iou(b[ka[x]], b[ka[y]]) <= np.float32(0.45)
+    if len(ka) < 50:
+        for j in range(len(s)):
+            if s[j] >= np.float32(0.1) and j not in ka:
+                assert any(X.nms_iou(b[i], b[j]) > np.float32(0.45) and ((s[i] > s[j]) or (s[i] == s[j] and i < j))
+                           for i in ka)
+    assert set(ka) <= set(kc) or len(kc) == 50   # class-aware suppresses less
+
+
+# ---------------------------------------------------------------- GPU: the HIP kernels vs the specification
+def dev(a):
+    import torch
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,stride", [((2, 8, 12, 6), 2), ((3, 6, 6, 5), 2), ((1, 9, 6, 4), 3), ((4, 26, 26, 64), 2)])
+def test_gpu_reorg_bit_exact(shape, stride):
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(shape).astype(np.float32)
+    y = E.reorg(dev(x), stride)
+    np.testing.assert_array_equal(y.cpu().numpy(), X.reorg(x, stride))
+    np.testing.assert_array_equal(E.reorg(y, stride, inverse=True).cpu().numpy(), x)
+
+
+@pytest.mark.gpu
+def test_gpu_passthrough_concat_golden_and_yolo2_shape(golden_dir):
+    from tensorflow_yolo2_amd import engine as E
+    g = _kat(golden_dir)
+    out = E.passthrough_concat(dev(g["fine"]), dev(g["coarse"]))
+    np.testing.assert_array_equal(out.cpu().numpy(), g["concat"])
+    df, dc = E.passthrough_concat_backward(out, g["fine"].shape[3])
+    np.testing.assert_array_equal(df.cpu().numpy(), g["fine"])
+    np.testing.assert_array_equal(dc.cpu().numpy(), g["coarse"])
+    # the YOLOv2 route: 26x26x512 -> 13x13x2048, concatenated with 13x13x1024 (batch 8)
+    rng = np.random.default_rng(2)
+    fine = rng.standard_normal((8, 26, 26, 512)).astype(np.float32)
+    coarse = rng.standard_normal((8, 13, 13, 1024)).astype(np.float32)
+    out = E.passthrough_concat(dev(fine), dev(coarse))
+    assert tuple(out.shape) == (8, 13, 13, 3072)
+    np.testing.assert_array_equal(out.cpu().numpy(), X.passthrough_concat(fine, coarse))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,B,C,N", [(5, 3, 4, 2), (13, 5, 20, 4), (19, 5, 20, 2)])
+def test_gpu_decode_anchors(golden_dir, S, B, C, N):
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(S)
+    net = (rng.standard_normal((N, S, S, B, 5 + C)) * 1.5).astype(np.float32)
+    anchors = rng.uniform(0.5, 9.0, (B, 2)).astype(np.float32)
+    rb, rs = X.decode_anchors(net, anchors)
+    boxes, scores = E.decode_anchors(dev(net), anchors)
+    # tolerance: device expf vs numpy exp differ in the last ulps
+    np.testing.assert_allclose(boxes.cpu().numpy(), rb, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(scores.cpu().numpy(), rs, rtol=1e-5, atol=1e-8)
+
+
+def _random_candidates(rng, K, clustered):
+    if clustered:
+        centres = rng.uniform(0.2, 0.8, (12, 2))
+        c = centres[rng.integers(0, 12, K)] + rng.normal(0, 0.02, (K, 2))
+        wh = rng.uniform(0.15, 0.3, (K, 2))
+    else:
+        c = rng.uniform(0.1, 0.9, (K, 2))
+        wh = rng.uniform(0.03, 0.35, (K, 2))
+    boxes = np.concatenate([c, wh], axis=1).astype(np.float32)
+    scores = np.round(rng.uniform(0, 1, K), 3).astype(np.float32)   # rounded: ties occur
+    return boxes, scores, rng.integers(0, 4, K).astype(np.int32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,clustered,class_aware,max_out", [(160, False, False, 50), (845, True, False, 100),
+                                                               (845, False, True, 200), (1805, True, True, 100),
+                                                               (3000, True, False, 64)])
+def test_gpu_nms_bit_exact(golden_dir, K, clustered, class_aware, max_out):
+    import torch
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(K + 7 * class_aware)
+    N = 3
+    data = [_random_candidates(rng, K, clustered) for _ in range(N)]
+    boxes = np.stack([d[0] for d in data]); scores = np.stack([d[1] for d in data]); cls = np.stack([d[2] for d in data])
+    keep, count = E.nms(dev(boxes), dev(scores), dev(cls), 0.45, 0.25, max_out, class_aware)
+    torch.cuda.synchronize()
+    keep, count = keep.cpu().numpy(), count.cpu().numpy()
+    for n in range(N):
+        ref = X.nms(boxes[n], scores[n], cls[n], 0.45, 0.25, max_out, class_aware)
+        assert count[n] == len(ref)
+        np.testing.assert_array_equal(keep[n, :count[n]], np.array(ref, np.int32))
+        assert (keep[n, count[n]:] == -1).all()
+
+
+@pytest.mark.gpu
+def test_gpu_nms_golden(golden_dir):
+    from tensorflow_yolo2_amd import engine as E
+    g = _kat(golden_dir)
+    b, s, c = dev(g["nms_boxes"][None]), dev(g["nms_scores"][None]), dev(g["nms_classes"][None])
+    keep, count = E.nms(b, s, None, 0.45, 0.1, 50, False)
+    np.testing.assert_array_equal(keep[0, :int(count[0])].cpu().numpy(), g["keep_agnostic"])
+    keep, count = E.nms(b, s, c, 0.45, 0.1, 50, True)
+    np.testing.assert_array_equal(keep[0, :int(count[0])].cpu().numpy(), g["keep_class_aware"])

@@ -261,3 +261,35 @@ def test_full_size_train_steps_bs64_f16():
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
     assert torch.isfinite(tr.net.params).all()
+
+
+def test_multi_scale_trainer_shares_parameters_across_sizes():
+    """BASELINE.json configs[4] (multi-scale {320..608}; not in the reference): one parameter / gradient /
+    Adam state for every input size, one context + workspace per size."""
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from tensorflow_yolo2_amd.trainer import DetectorTrainer, MultiScaleDetectorTrainer
+    core = [(k, ci, co, int(p)) for (k, ci, co, p) in R.scaled_spec(R.CORE_SPEC, 8)]
+    head = [(3, core[-1][2], 128, 0)] * 1 + [(1, 128, 30, 0)]
+    n = 4
+    ms = MultiScaleDetectorTrainer(n, sizes=(320, 352, 608), period=2, dtype="f32", seed=3, core_spec=core,
+                                   head_spec=head)
+    single = DetectorTrainer(n, 320, dtype="f32", seed=3, core_spec=core, head_spec=head)
+    losses = []
+    for step, size in enumerate((320, 352, 608, 320)):
+        S = size // 32
+        x = dev(synthetic.images(n, size, 100 + step))
+        lab = dev(synthetic.det_labels(n, size, S, 200 + step))
+        loss = ms.step(x, lab)[0]
+        losses.append(float(loss[4]))
+        if step == 0:
+            # the first step equals the single-size trainer's first step (same seed, same kernels)
+            ref = single.step(x, lab)[0]
+            np.testing.assert_allclose(loss.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5)
+            np.testing.assert_allclose(ms.nets[320].params.cpu().numpy(), single.net.params.cpu().numpy(),
+                                       rtol=1e-5, atol=1e-7)
+    assert all(np.isfinite(losses)), losses
+    assert set(ms.nets) == {320, 352, 608} and ms.opt.t == 4
+    ptrs = {net.params.data_ptr() for net in ms.nets.values()} | {net.grads.data_ptr() for net in ms.nets.values()}
+    assert len(ptrs) == 2                                   # one parameter buffer, one gradient buffer
+    assert ms.nets[608].out_shape[1] == 19

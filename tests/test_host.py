@@ -97,3 +97,15 @@ def test_layer_slices_cover_the_flat_buffer_in_backward_order():
     ranges = [trainer.slice_range(offs, 1000, 22, lo, hi) for (lo, hi) in sl]
     assert ranges == [(180, 1000), (130, 180), (0, 130)]
     assert trainer.layer_slices(3) == [(0, 3)]
+
+
+def test_multi_scale_schedule_is_deterministic_and_in_range():
+    """{320..608} step 32, redrawn every 10 steps, a pure function of (seed, step): every rank agrees."""
+    from tensorflow_yolo2_amd.trainer import multi_scale_size, MULTI_SCALE_SIZES
+    assert MULTI_SCALE_SIZES == (320, 352, 384, 416, 448, 480, 512, 544, 576, 608)
+    sizes = [multi_scale_size(s, seed=5) for s in range(200)]
+    assert all(s in MULTI_SCALE_SIZES for s in sizes)
+    assert all(len(set(sizes[i:i + 10])) == 1 for i in range(0, 200, 10))
+    assert len(set(sizes)) >= 5
+    assert sizes == [multi_scale_size(s, seed=5) for s in range(200)]
+    assert sizes != [multi_scale_size(s, seed=6) for s in range(200)]
