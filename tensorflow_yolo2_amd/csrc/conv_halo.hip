@@ -333,9 +333,14 @@ static int dev_rule(int W, int Cout) {
     return -1;
 }
 
-// feature maps up to 26x26: filter fragments straight to registers (conv_haloq.hip, 4-8 % faster there;
-// no gain at 52x52) -- the filter pack must match (pack.hip, PackLayer::frag)
-bool conv_frag_filters(int taps, int W) { return taps == 9 && W <= 26; }
+// filter fragments straight to registers (conv_haloq.hip) -- the filter pack must match (pack.hip,
+// PackLayer::wf_frag / wd_frag).
+// Measured (scripts/bench_conv.py, rotating buffers): wins up to 26x26 and again at 104x104 (big 512-pixel
+// tiles); at 52x52 the LDS filter ring is as fast, at 208x208 only the 32-channel dgrad gains.
+bool conv_frag_filters(int taps, int W, int Cout) {
+    if (taps != 9) return false;
+    return W <= 26 || (W > 52 && W <= 104) || (W > 104 && Cout <= 32);
+}
 
 // Kernel policy (measured on MI355X, scripts/bench_conv.py): the halo image wins where the
 // image rows are short (13x13, 26x26: the nine taps share ~85 % of their rows); on the large
@@ -345,7 +350,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_p
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
     const int forced = (a.taps == 9 && dtype == 1) ? dev_rule(a.W, a.Cout) : -1;
-    if (conv_frag_filters(a.taps, a.W)) e = launch_conv_haloq(dtype, a, s, &bp);
+    if (conv_frag_filters(a.taps, a.W, a.Cout)) e = launch_conv_haloq(dtype, a, s, &bp);
     else if (forced >= 0) e = launch_conv_halo_variant(forced, a, s, &bp);
     else if (a.taps == 9 && a.W <= 52) e = launch_conv_halo(dtype, a, s, &bp);
     else e = launch_conv_igemm(dtype, a, s);

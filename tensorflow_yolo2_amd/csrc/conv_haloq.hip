@@ -204,6 +204,22 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
     const int kb = a.C * (int)sizeof(T);
     const bool k128 = (kb % 128) == 0;
     if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
+    if (a.W > 52) {
+        // long rows (104, 208): 512-pixel tiles amortise the two-row halo; one K-chunk per tile where it fits
+        hipError_t e = hipErrorOutOfMemory;
+        if (a.Cout > 64) {
+            *bp = 256;
+            e = haloq_pick<T, 4, 2, 2, 2, 64>(a, s);
+        } else if (a.Cout > 32) {
+            *bp = 512;
+            e = k128 ? haloq_pick<T, 4, 2, 4, 1, 128>(a, s) : haloq_pick<T, 4, 2, 4, 1, 64>(a, s);
+        } else {
+            *bp = 512;
+            e = k128 ? haloq_pick<T, 8, 1, 2, 1, 128>(a, s) : haloq_pick<T, 8, 1, 2, 1, 64>(a, s);
+        }
+        if (e != hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();
+    }
     if (a.Cout > 64) {
         hipError_t e = hipErrorOutOfMemory;
         if (a.M >= 384 * 8) {   // every fragment-filter layer (W <= 26): 384-pixel tiles measured best
@@ -259,6 +275,13 @@ hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t
         HQ(130, 4, 1, 2, 2, 128)
         HQ(131, 4, 1, 3, 2, 128)      // 384 x 64, 4 waves
         HQ(132, 2, 2, 4, 2, 128)      // 256 x 128, 4 waves
+        HQ(133, 4, 2, 4, 1, 128)      // 512 x 64
+        HQ(134, 4, 2, 2, 1, 128)      // 256 x 64
+        HQ(135, 4, 2, 4, 1, 64)
+        HQ(136, 4, 2, 2, 1, 64)
+        HQ(137, 8, 1, 2, 1, 128)      // 512 x 32
+        HQ(138, 8, 1, 2, 1, 64)
+        HQ(139, 4, 2, 4, 2, 64)       // 512 x 128, 64-byte chunks
     }
 #undef HQ
     return hipErrorInvalidValue;

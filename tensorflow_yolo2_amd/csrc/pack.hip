@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
                 Chunk<T> o;
 #pragma unroll
                 for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[cs * EPC + k][col]);
-                if (L.frag) st_chunk<T>(wf + frag_chunk(co, t, ci, L.taps, L.Kc, EPC) * EPC, o);
+                if (L.wf_frag) st_chunk<T>(wf + frag_chunk(co, t, ci, L.taps, L.Kc, EPC) * EPC, o);
                 else st_chunk<T>(wf + ((size_t)co * L.taps + t) * L.Kc + ci, o);
             }
         }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
                     for (int e = 0; e < EPC; ++e)
                         o.v[e] = Elem<T>::from_f32((ci < L.Cin && co + e < L.Cout) ? src[e] : 0.f);
                 }
-                if (L.frag) st_chunk<T>(wd + frag_chunk(ci, tt, co, L.taps, L.Cdy, EPC) * EPC, o);
+                if (L.wd_frag) st_chunk<T>(wd + frag_chunk(ci, tt, co, L.taps, L.Cdy, EPC) * EPC, o);
                 else st_chunk<T>(wd + (size_t)i * EPC, o);
             }
         }
