@@ -175,42 +175,47 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(Conv1Args a) {
         bq[q] = a.bias[acc_row(q, hh)];
         s1[q] = s2[q] = 0.f;
     }
-    const int ntiles = (a.M + 31) / 32;
+    // tiles of 2 image rows x 32 columns (as the second pass): the tile index is wave-uniform, so the
+    // (n, h, w) split costs scalar work only -- per-lane div/mod of a linear pixel index cost more than
+    // the three MFMAs of a tile -- and two accumulators share four input-row loads
+    const int nseg = (a.W + 31) / 32;
+    const int Hp = (a.H + 1) / 2;
+    const int ntiles = a.N * Hp * nseg;
     const int nwaves = gridDim.x * 4;
     const int rowpitch = (a.W + 1) * 4 * SZ;
-    const int hw = a.H * a.W;
     int my_cnt = 0;
     for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += nwaves) {
-        const int p = tile * 32 + r32;
-        const bool pv = p < a.M;
-        uint32_t base = 0;
-        if (pv) {
-            const int n = p / hw, rem = p - n * hw;
-            const int h = rem / a.W, ww = rem - h * a.W;
-            base = (uint32_t)(bpix(n, h, ww, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(4 * SZ);
-        }
-        f32x16 acc;
+        const int sg = tile % nseg, pr = tile / nseg;
+        const int n = pr / Hp, hp = pr - n * Hp, h0 = 2 * hp, w0 = sg * 32;
+        const int wc = (w0 + r32 < a.W) ? w0 + r32 : a.W - 1;
+        const uint32_t base = (uint32_t)(bpix(n, h0, wc, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(4 * SZ);
+        const bool row1 = h0 + 1 < a.H;               // odd H: the last pair has one row (wave-uniform)
+        frag_t fx[4][KGC];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-        frag_t fx[3][KGC];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int g = 0; g < KGC; ++g)
-                fx[kh][g] = ((const UFrag*)((const char*)a.x4 + base + kh * rowpitch + 32 * g + 16 * hh))->v;
+                fx[r][g] = ((const UFrag*)((const char*)a.x4 + base + (r < 3 || row1 ? r : 2) * rowpitch + 32 * g + 16 * hh))->v;
+        const float vm = (w0 + r32 < a.W) ? 1.f : 0.f;
+        const int cols = a.W - w0 < 32 ? a.W - w0 : 32;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && !row1) break;
+            f32x16 acc;
 #pragma unroll
-            for (int g = 0; g < KGC; ++g) mma32(acc, fw[kh][g], fx[kh][g]);
-        const float vm = pv ? 1.f : 0.f;
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float d = (Elem<T>::to_f32(Elem<T>::from_f32(acc[q] + bq[q])) - bq[q]) * vm;
-            s1[q] += d;
-            s2[q] = fmaf(d, d, s2[q]);
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int g = 0; g < KGC; ++g) mma32(acc, fw[kh][g], fx[r + kh][g]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float d = (Elem<T>::to_f32(Elem<T>::from_f32(acc[q] + bq[q])) - bq[q]) * vm;
+                s1[q] += d;
+                s2[q] = fmaf(d, d, s2[q]);
+            }
+            my_cnt += cols;
         }
-        int tc = a.M - tile * 32;
-        my_cnt += tc > 32 ? 32 : tc;
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q)
@@ -413,6 +418,164 @@ hipError_t launch_conv1_pool(int dtype, const Conv1PoolArgs& a, hipStream_t s) {
             case 2: hipLaunchKernelGGL((conv1_pool_kernel<bf16_t, false>), g, b, 0, s, a); break;
             default: return hipErrorInvalidValue;
         }
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Backward reduce pass of the pooled first layer with the conv output RECOMPUTED from the input
+// (same tiles and rounding as conv1_pool_kernel, so the values are bit-identical to the stored y):
+//   g = dA * leaky'(z) at the first arg-max of the 2x2 window;  S1 += g, S2 += g*y   (bn.hip)
+// reads x4 (8 B/pixel) + dA (16 B/pixel at f16) instead of y + dA (80 B/pixel).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_bnbwd_reduce_kernel(Conv1BnBwdArgs a) {
+    typedef typename Elem<T>::frag frag_t;
+    struct __attribute__((packed, aligned(8))) UFrag { frag_t v; };
+    constexpr int SZ = sizeof(T);
+    constexpr int KGC = 16 * SZ / 32;
+    constexpr int EROW = 32 * SZ + 16;
+    constexpr int EPC = 16 / SZ;
+    constexpr int CPR = 32 / EPC;
+    constexpr int RPIe = 64 / CPR;
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * EROW];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, hh = lane >> 5;
+    char* ew = smem + w * 64 * EROW;
+
+    frag_t fw[3][KGC];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int g = 0; g < KGC; ++g)
+            fw[kh][g] = *(const frag_t*)((const char*)a.w + ((r32 * 3 + kh) * 16) * SZ + 32 * g + 16 * hh);
+    float b4[4][4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b4[q4][j] = a.bias[8 * q4 + 4 * hh + j];
+    const int ch = lane % CPR, pl = lane / CPR;
+    float sc[EPC], sh[EPC], s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = a.scale[ch * EPC + e];
+        sh[e] = a.shift[ch * EPC + e];
+        s1[e] = s2[e] = 0.f;
+    }
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    const int nseg = (a.W + 31) / 32;
+    const int ntiles = a.N * Ho * nseg;
+    const int nwaves = gridDim.x * 4;
+    const int rowpitch = (a.W + 1) * 4 * SZ;
+    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += nwaves) {
+        const int sg = tile % nseg, pr = tile / nseg;
+        const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho, w0 = sg * 32;
+        const int wc = (w0 + r32 < a.W) ? w0 + r32 : a.W - 1;
+        const uint32_t base = (uint32_t)(bpix(n, h0, wc, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(4 * SZ);
+        frag_t fx[4][KGC];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < KGC; ++g)
+                fx[r][g] = ((const UFrag*)((const char*)a.x4 + base + r * rowpitch + 32 * g + 16 * hh))->v;
+        // this lane's dA chunks (issued early: they are consumed after the MFMAs and the transpose)
+        Chunk<T> dav[16 / RPIe];
+#pragma unroll
+        for (int ps = 0; ps < 16 / RPIe; ++ps) {
+            const int wo = w0 / 2 + ps * RPIe + pl;
+            const int woc = wo < Wo ? wo : Wo - 1;
+            dav[ps] = ld_chunk<T>((const char*)a.dA + (((size_t)(n * Ho + ho) * Wo + woc) * 32 + ch * EPC) * SZ);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[r][q] = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int g = 0; g < KGC; ++g) mma32(acc[r], fw[kh][g], fx[r + kh][g]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                T o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = Elem<T>::from_f32(acc[r][4 * q4 + j] + b4[q4][j]);
+                char* dst = ew + (r * 32 + r32) * EROW + (8 * q4 + 4 * hh) * SZ;
+                if (SZ == 2) *(u32x2*)dst = *(const u32x2*)o;
+                else *(u32x4*)dst = *(const u32x4*)o;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int ps = 0; ps < 16 / RPIe; ++ps) {
+            const int j = ps * RPIe + pl;
+            float amax[EPC], yb[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                amax[e] = -INFINITY;
+                yb[e] = 0.f;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                Chunk<T> c = ld_chunk<T>(ew + ((d >> 1) * 32 + 2 * j + (d & 1)) * EROW + ch * 16);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float yv = Elem<T>::to_f32(c.v[e]);
+                    const float act = leaky01(fmaf(yv, sc[e], sh[e]));
+                    if (act > amax[e]) {
+                        amax[e] = act;
+                        yb[e] = yv;
+                    }
+                }
+            }
+            const float vm = (w0 / 2 + j < Wo) ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float gz = Elem<T>::to_f32(dav[ps].v[e]) * leaky01_slope(fmaf(yb[e], sc[e], sh[e])) * vm;
+                s1[e] += gz;
+                s2[e] = fmaf(gz, yb[e], s2[e]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- lanes with the same channel chunk, then the 4 waves -> psum[block][2][32]
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+#pragma unroll
+        for (int msk = CPR; msk < 64; msk <<= 1) {
+            s1[e] = wave_sum_xor(s1[e], msk);
+            s2[e] = wave_sum_xor(s2[e], msk);
+        }
+    __syncthreads();
+    float* red = (float*)smem;   // [4 waves][2][32]
+    if (pl == 0) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            red[(w * 2 + 0) * 32 + ch * EPC + e] = s1[e];
+            red[(w * 2 + 1) * 32 + ch * EPC + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int k = tid >> 5, c = tid & 31;
+        a.psum[((size_t)blockIdx.x * 2 + k) * 32 + c] =
+            red[(0 * 2 + k) * 32 + c] + red[(1 * 2 + k) * 32 + c] + red[(2 * 2 + k) * 32 + c] + red[(3 * 2 + k) * 32 + c];
+    }
+}
+
+hipError_t launch_conv1_bnbwd_reduce(int dtype, const Conv1BnBwdArgs& a, hipStream_t s) {
+    dim3 g(a.nblocks), b(256);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(conv1_bnbwd_reduce_kernel<float>, g, b, 0, s, a); break;
+        case 1: hipLaunchKernelGGL(conv1_bnbwd_reduce_kernel<half_t>, g, b, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(conv1_bnbwd_reduce_kernel<bf16_t>, g, b, 0, s, a); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

@@ -57,6 +57,18 @@ struct Conv1PoolArgs {
     int nblocks;
     int store_y;
 };
+// backward reduce pass of the same layer with the conv output recomputed (x4 + dA in, psum out)
+struct Conv1BnBwdArgs {
+    const void* x4;
+    const void* w;
+    const float* bias;
+    const float *scale, *shift;
+    const void* dA;     // grad wrt the pooled output [N*Ho*Wo][32] of T
+    float* psum;        // [nblocks][2][32]
+    int N, H, W;
+    int nblocks;
+};
+hipError_t launch_conv1_bnbwd_reduce(int dtype, const Conv1BnBwdArgs& a, hipStream_t s);
 bool conv1_pool_ok(int H, int W, int pool, int cout);
 hipError_t launch_conv1_pool(int dtype, const Conv1PoolArgs& a, hipStream_t s);
 struct Conv1WgradArgs {

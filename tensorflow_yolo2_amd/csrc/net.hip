@@ -555,9 +555,22 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         b.ldd = y.ldy;
         b.pool = y.pool; b.training = c->fwd_training[l]; b.inv_grad_scale = inv_gs;
         const bool fused1 = y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz());
+        const bool rec1 = y.first3 && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
+                          conv1_pool_ok(y.H, y.W, y.pool, y.cout);
         {
             PROF(CAT_BN_BWD);
-            HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
+            if (rec1) {   // pooled first layer: recompute the conv output instead of reading it (80 -> 24 B/pixel)
+                Conv1BnBwdArgs q{};
+                q.x4 = c->ws + y.xin + c->in_geom(l).base_off(sz); q.w = c->ws + y.wf; q.bias = c->params + y.pb;
+                q.scale = b.scale; q.shift = b.shift; q.dA = b.dA; q.psum = psum;
+                q.N = c->N; q.H = y.H; q.W = y.W;
+                const int tiles = c->N * (y.H / 2) * ((y.W + 31) / 32);
+                q.nblocks = (tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4;
+                b.P = q.nblocks;
+                HIPCHK(launch_conv1_bnbwd_reduce(c->dtype, q, s));
+            } else {
+                HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
+            }
             HIPCHK(launch_bn_bwd_finalize(b, s));
             if (!fused1) HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
         }

@@ -287,8 +287,11 @@ def test_multi_scale_trainer_shares_parameters_across_sizes():
             # the first step equals the single-size trainer's first step (same seed, same kernels)
             ref = single.step(x, lab)[0]
             np.testing.assert_allclose(loss.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5)
-            np.testing.assert_allclose(ms.nets[320].params.cpu().numpy(), single.net.params.cpu().numpy(),
-                                       rtol=1e-5, atol=1e-7)
+            # after Adam: equal in norm, not element-wise -- split-K float atomics reorder the last bits of dW,
+            # and Adam's g / (|g| + eps) turns that into +-lr on the few elements whose gradient is ~eps
+            pa, pb = ms.nets[320].params.cpu().numpy(), single.net.params.cpu().numpy()
+            assert np.linalg.norm(pa - pb) < 1e-4 * np.linalg.norm(pb)
+            assert np.mean(np.abs(pa - pb) > 1e-5) < 1e-3
     assert all(np.isfinite(losses)), losses
     assert set(ms.nets) == {320, 352, 608} and ms.opt.t == 4
     ptrs = {net.params.data_ptr() for net in ms.nets.values()} | {net.grads.data_ptr() for net in ms.nets.values()}
