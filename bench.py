@@ -183,7 +183,7 @@ def main():
         # forward igemm launches: layers 1..L-1; dgrad launches: layers 1..L-1 (layer 0 needs no dgrad)
         igemm_flops = fwd_igemm * (1.0 if args.forward_only else 2.0)
         roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": None, "traffic": None, "kernel": "conv_igemm_kernel (forward + dgrad launches)"}
+                "frac": None, "traffic": None, "kernel": "implicit-GEMM convolution, forward + dgrad launches (conv_haloq / conv_halo / conv_igemm)"}
         kernels = None
         if prof is not None:
             t_igemm = (prof["conv_fwd"][0] + prof["dgrad"][0]) / args.steps * 1e-3
@@ -200,7 +200,7 @@ def main():
         # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction), bytes per launch
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_hbm_traffic.json")))
-            sel = [v for k, v in tj.items() if "conv_halo_kernel" in k or "conv_igemm_kernel" in k]
+            sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k]
             nl = sum(v["launches"] for v in sel)
             if nl and not args.forward_only and bs == 64 and size == 416 and args.dtype == "f16":
                 roof["traffic"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in sel) / nl
