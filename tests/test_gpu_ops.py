@@ -295,3 +295,35 @@ def test_optimizers_vs_oracle():
             else:
                 var, m = O.momentum_step(var, m, g, dtype=np.float64)
         assert relerr(net.params.cpu().numpy(), var) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("shape", [(2, 15, 13, 3), (1, 33, 47, 3), (2, 64, 96, 3)])
+def test_first_layer_paths_odd_and_wide(shape, dtype):
+    """The pooled first layer has a two-pass / recomputing / fused form for even sizes and falls back to
+    conv1 + bn_act + apply + plain weight gradient for odd ones (SAME pooling pads bottom/right): both must
+    match the oracle, forward and backward."""
+    from tensorflow_yolo2_amd import engine as E
+    spec = [(3, 3, 32, 1), (3, 32, 64, 1), (1, 64, 30, 0)]
+    rng = np.random.default_rng(sum(shape))
+    params = _rand_params(spec, rng)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    net = E.Network(spec, shape[0], shape[1], shape[2], dtype=dtype, training=True)
+    net.load_params(params)
+    out = net.forward(dev(x), True, True)
+    q = R.quantizer(dtype)
+    ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q)
+    assert out.shape == ref.shape
+    assert l2err(out.cpu().numpy(), ref) < {"f32": 1e-5, "f16": 1e-3}[dtype]
+    dout = rng.standard_normal(ref.shape).astype(np.float32)
+    net.backward(dev(dout))
+    _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,
+                                     grad_scale=net.grad_scale)
+    grads = net.export_grads()
+    # f16: dy and y are stored / staged in half precision (12 k pixels summed per filter element)
+    tol = {"f32": 2e-4, "f16": 2.5e-2}[dtype]
+    for l in range(len(spec)):
+        for k in ("W", "gamma", "beta"):
+            e = l2err(grads[l][k], rgrads[l][k])
+            assert e < tol, (l, k, e)
