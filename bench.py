@@ -8,8 +8,8 @@ metric is quoted on fwd+bwd at 416x416, which fits one GPU).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the MFMA
-implicit-GEMM convolution: forward + dgrad launches): algorithmic FLOPs of those
-launches / their HIP-event time measured on the launch stream inside the timed region.
+implicit-GEMM convolution: forward, dgrad and wgrad launches): algorithmic FLOPs of those
+launches / the union of their HIP-event intervals, measured on the launch streams inside the timed region.
 `cpu_baseline` is the oracle's PyTorch-CPU restatement of the same train step on a
 bounded sample (rank 0, N=1 only) -- "port", NOT the TF1 reference, which cannot run here.
 """
@@ -108,6 +108,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.all_ranks_on_gpu0:
             local_rank = 0
+            # functional test only: two PROCESSES time-slicing one GPU, each with a side stream, stall on each
+            # other's queue slices (measured 3 s per step); production is one process per GPU
+            os.environ["Y2_NO_WGRAD_OVERLAP"] = "1"
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -145,9 +148,11 @@ def main():
     for _ in range(args.warmup):
         run()
     sync_all()
-    # timed region: HIP events bracket ONLY the dominant kernel's launches (the implicit-GEMM
-    # forward + dgrad convolutions, 42 of ~150 launches per step) so that the measurement does not
-    # cost the step ~6 %; a second, untimed pass brackets every launch for the per-class table
+    # timed region: HIP events bracket ONLY the dominant kernel's launches (the MFMA implicit-GEMM
+    # convolutions: forward, dgrad and weight gradient, 63 of ~150 launches per step) so that the
+    # measurement does not cost the step ~6 %.  The weight gradients run on a side stream beside the
+    # dgrads, so the kernel time is the UNION of the launch intervals (y2_profile_busy), not their sum.
+    # A second, untimed and serialised pass brackets every launch for the per-class table.
     if args.kernel_events == "timed":
         net.profile_enable(2)
     t0 = time.perf_counter()
@@ -155,6 +160,7 @@ def main():
         run()
     sync_all()
     elapsed = time.perf_counter() - t0
+    busy = net.profile_busy() if args.kernel_events == "timed" else None
     prof = net.profile_collect() if args.kernel_events == "timed" else None
     net.profile_enable(0)
     prof_all = None
@@ -180,18 +186,22 @@ def main():
     if rank == 0:
         per = conv_flops(spec, bs, size)
         fwd_igemm = sum(per[1:])
-        # forward igemm launches: layers 1..L-1; dgrad launches: layers 1..L-1 (layer 0 needs no dgrad)
-        igemm_flops = fwd_igemm * (1.0 if args.forward_only else 2.0)
+        # forward, dgrad and wgrad launches of layers 1..L-1 (the 3 -> 32 first layer has its own kernels)
+        igemm_flops = fwd_igemm * (1.0 if args.forward_only else 3.0)
         roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": None, "traffic": None, "kernel": "implicit-GEMM convolution, forward + dgrad launches (conv_haloq / conv_halo / conv_igemm)"}
+                "frac": None, "traffic": None, "kernel": "MFMA implicit-GEMM convolution: forward, dgrad and wgrad launches (conv_haloq / conv_halo / conv_igemm / wgrad9 / wgrad); time = union of the launch intervals"}
         kernels = None
         if prof is not None:
-            t_igemm = (prof["conv_fwd"][0] + prof["dgrad"][0]) / args.steps * 1e-3
+            if busy is not None and busy[1] > 0:
+                t_igemm, n_launch = busy[0] / args.steps * 1e-3, busy[1]
+            else:   # serialised pass: the sum of the durations is the busy time
+                t_igemm = (prof["conv_fwd"][0] + prof["dgrad"][0] + prof["wgrad"][0]) / args.steps * 1e-3
+                n_launch = prof["conv_fwd"][1] + prof["dgrad"][1] + prof["wgrad"][1]
             if t_igemm > 0:
                 roof["achieved"] = igemm_flops / t_igemm / 1e12
                 roof["frac"] = roof["achieved"] / roof["peak"]
-                roof["avg_launch_ms"] = (prof["conv_fwd"][0] + prof["dgrad"][0]) / max(
-                    prof["conv_fwd"][1] + prof["dgrad"][1], 1)
+                roof["avg_launch_ms"] = t_igemm * 1e3 * args.steps / max(n_launch, 1)
+                roof["launches_per_step"] = n_launch / args.steps
             kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
                        for k, v in (prof_all or prof).items()}
             if not args.forward_only and (prof_all or prof)["wgrad"][0] > 0:
@@ -200,7 +210,7 @@ def main():
         # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction), bytes per launch
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_hbm_traffic.json")))
-            sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k]
+            sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k or "wgrad9" in k or "wgrad_kernel" in k]
             nl = sum(v["launches"] for v in sel)
             if nl and not args.forward_only and bs == 64 and size == 416 and args.dtype == "f16":
                 roof["traffic"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in sel) / nl
@@ -208,7 +218,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         if roof.get("avg_launch_ms"):
-            roof["flops_per_launch"] = igemm_flops / max((prof["conv_fwd"][1] + prof["dgrad"][1]) / args.steps, 1)
+            roof["flops_per_launch"] = igemm_flops / max(roof.get("launches_per_step", 1), 1)
         total_flops = sum(per) * flop_mult
         out = {
             "metric": "images/sec fwd+bwd Darknet-19 416x416" if not args.forward_only

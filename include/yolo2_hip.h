@@ -88,10 +88,14 @@ int y2_debug_read(y2_ctx* ctx, int layer, int what, float* dst, void* stream);
 /* Optional measurement aid: bracket every kernel launch of y2_forward / y2_backward with
  * HIP events on the launch stream (the reference only has utils/timer.py wall clocks).
  * Categories: 0 conv fwd (implicit GEMM), 1 conv1 fwd, 2 dgrad, 3 wgrad, 4 conv1 wgrad,
- * 5 BN fwd passes, 6 BN bwd passes, 7 pack/convert.  on = 1: every launch; on = 2: only the
- * dominant kernel (categories 0 and 2).  collect() waits for the events. */
+ * 5 BN fwd passes, 6 BN bwd passes, 7 pack/convert.  on = 1: every launch, serialised
+ * (no side stream); on = 2: only the MFMA convolution launches (categories 0, 2, 3), streams as in production.  collect() waits for the events. */
 int y2_profile_enable(y2_ctx* ctx, int on);
 int y2_profile_collect(y2_ctx* ctx, double* ms_by_category, int* launches_by_category, int ncat);
+/* length of the union of the [start, end] intervals of the launches whose category bit is set in cat_mask
+ * (weight gradients run on a side stream beside the dgrads: summing durations would count shared time twice).
+ * Call before y2_profile_collect (which resets). */
+int y2_profile_busy(y2_ctx* ctx, int cat_mask, double* busy_ms, int* launches);
 
 /* ---- get_loss / get_iou / show_yolo_detection (src/yolo2_nets/net_utils.py:222-439) */
 size_t y2_yolo_loss_workspace_bytes(int batch, int S);

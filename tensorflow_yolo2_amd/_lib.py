@@ -43,6 +43,7 @@ SIGNATURES = {
     "y2_debug_read": (_i, [_vp, _i, _i, _vp, _vp]),
     "y2_profile_enable": (_i, [_vp, _i]),
     "y2_profile_collect": (_i, [_vp, C.POINTER(C.c_double), _pi, _i]),
+    "y2_profile_busy": (_i, [_vp, _i, _vp, _vp]),
     "y2_yolo_loss_workspace_bytes": (_sz, [_i, _i]),
     "y2_yolo_loss": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "y2_get_iou": (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -103,6 +104,10 @@ struct y2_ctx {
     int prof = 0;   // 0 off, 1 every launch, 2 only the dominant kernel (conv forward + dgrad)
     struct ProfRec { int cat, layer; hipEvent_t a, b; };
     int prof_layer = -1;
+    // weight gradients run on a side stream beside the dgrad of the same layer (both only read dY)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap_wgrad = 1;
     std::vector<ProfRec> prof_recs;
     size_t prof_used = 0;
     size_t sz() const { return dtype_size(dtype); }
@@ -117,7 +122,7 @@ struct ProfScope {
     y2_ctx* c; hipStream_t s; int idx = -1;
     ProfScope(y2_ctx* c_, hipStream_t s_, int cat) : c(c_), s(s_) {
         if (!c->prof) return;
-        if (c->prof == 2 && cat != CAT_CONV_FWD && cat != CAT_DGRAD) return;
+        if (c->prof == 2 && cat != CAT_CONV_FWD && cat != CAT_DGRAD && cat != CAT_WGRAD) return;
         if (c->prof_used == c->prof_recs.size()) {
             y2_ctx::ProfRec r; r.cat = cat;
             if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -292,6 +297,9 @@ int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers
 void y2_ctx_destroy(y2_ctx* ctx) {
     if (!ctx) return;
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     delete ctx;
 }
 
@@ -325,6 +333,38 @@ extern "C" int y2dev_profile_layers(y2_ctx* c, double* ms) {
         HIPCHK(hipEventElapsedTime(&t, r.a, r.b));
         if (r.layer >= 0 && r.layer < nl) ms[r.layer * CAT_COUNT + r.cat] += t;
     }
+    return Y2_OK;
+}
+// Busy time of the launches of the categories in `cat_mask`: the length of the UNION of their
+// [start, end] intervals (the weight gradients run on a side stream beside the dgrads, so the sum of
+// the individual durations would count shared machine time twice).  Does not reset.
+int y2_profile_busy(y2_ctx* c, int cat_mask, double* busy_ms, int* launches) {
+    std::vector<std::pair<float, float>> iv;
+    if (c->prof_used == 0) { *busy_ms = 0.0; *launches = 0; return Y2_OK; }
+    const hipEvent_t ref = c->prof_recs[0].a;
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        auto& r = c->prof_recs[i];
+        if (!((cat_mask >> r.cat) & 1)) continue;
+        HIPCHK(hipEventSynchronize(r.b));
+        float t0 = 0.f, t1 = 0.f;
+        HIPCHK(hipEventElapsedTime(&t0, ref, r.a));
+        HIPCHK(hipEventElapsedTime(&t1, ref, r.b));
+        iv.emplace_back(t0, t1);
+    }
+    std::sort(iv.begin(), iv.end());
+    double busy = 0.0;
+    float cur0 = 0.f, cur1 = -1.f;
+    for (auto& p : iv) {
+        if (cur1 < cur0 || p.first > cur1) {
+            if (cur1 >= cur0) busy += cur1 - cur0;
+            cur0 = p.first; cur1 = p.second;
+        } else if (p.second > cur1) {
+            cur1 = p.second;
+        }
+    }
+    if (cur1 >= cur0) busy += cur1 - cur0;
+    *busy_ms = busy;
+    *launches = (int)iv.size();
     return Y2_OK;
 }
 int y2_num_layers(const y2_ctx* c) { return (int)c->L.size(); }
@@ -539,6 +579,16 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         HIPCHK(hipMemsetAsync(c->grads, 0, c->nparams * sizeof(float), s));
     }
     float* psum = (float*)(c->ws + c->o_psum);
+    bool forked = false;
+    if (c->overlap_wgrad && !c->side) {
+        static const bool off = getenv("Y2_NO_WGRAD_OVERLAP") != nullptr;
+        if (off) c->overlap_wgrad = 0;
+        else {
+            HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+    }
     for (int l = layer_hi - 1; l >= layer_lo; --l) {
         c->prof_layer = l;
         const Layer& y = c->L[l];
@@ -593,7 +643,15 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             g.x = xin; g.dy = dyp; g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M;
             g.Cin = y.cin_s; g.Cdy = y.ldy; g.Cout = y.cout; g.taps = y.k * y.k; g.splitk = 0; g.scale = inv_gs;
-            { PROF(CAT_WGRAD); HIPCHK(launch_wgrad_auto(c->dtype, g, s)); }
+            hipStream_t ws_ = s;
+            if (c->overlap_wgrad && l > 0 && c->prof != 1) {
+                // fork: the filter gradient only reads x and dY; it fills the bubbles of the dgrad beside it
+                HIPCHK(hipEventRecord(c->ev_fork, s));
+                HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+                ws_ = c->side;
+                forked = true;
+            }
+            { ProfScope _p(c, ws_, CAT_WGRAD); HIPCHK(launch_wgrad_auto(c->dtype, g, ws_)); }
             if (l > 0) {
                 ConvArgs a{};
                 a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
@@ -603,6 +661,10 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 c->dA_cur ^= 1;
             }
         }
+    }
+    if (forked) {   // join: every gradient is complete when the caller's stream gets past this call
+        HIPCHK(hipEventRecord(c->ev_join, c->side));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
     return Y2_OK;
 }

@@ -173,8 +173,16 @@ class Network:
     PROFILE_CATEGORIES = ("conv_fwd", "conv1_fwd", "dgrad", "wgrad", "conv1_wgrad", "bn_fwd", "bn_bwd", "misc")
 
     def profile_enable(self, on=1):
-        """0 off, 1 bracket every launch with HIP events, 2 only the conv forward + dgrad launches"""
+        """0 off; 1 bracket every launch with HIP events (serialised: no side stream); 2 only the MFMA convolution
+        launches (forward, dgrad, wgrad), streams as in production"""
         check(self.lib.y2_profile_enable(self.h, int(on)))
+
+    def profile_busy(self, categories=("conv_fwd", "dgrad", "wgrad")):
+        """(busy milliseconds, launches): union of the intervals of those launch categories (call before collect)"""
+        mask = sum(1 << self.PROFILE_CATEGORIES.index(k) for k in categories)
+        ms, n = C.c_double(), C.c_int()
+        check(self.lib.y2_profile_busy(self.h, mask, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def profile_collect(self):
         n = len(self.PROFILE_CATEGORIES)
