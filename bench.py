@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--kernel-events", default="timed", choices=["timed", "separate", "off"])
+    ap.add_argument("--event-stride", type=int, default=4, help="bracket the MFMA launches of every n-th timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -153,10 +154,18 @@ def main():
     # measurement does not cost the step ~6 %.  The weight gradients run on a side stream beside the
     # dgrads, so the kernel time is the UNION of the launch intervals (y2_profile_busy), not their sum.
     # A second, untimed and serialised pass brackets every launch for the per-class table.
-    if args.kernel_events == "timed":
-        net.profile_enable(2)
+    # Events cost ~3 us per bracketed launch (they break back-to-back dispatch), so only every
+    # `--event-stride`-th step of the timed region is bracketed; the roofline uses those steps.
+    stride = max(1, args.event_stride)
+    sampled = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if args.kernel_events == "timed":
+            if i % stride == 0:
+                net.profile_enable(2 if sampled == 0 else 3)
+                sampled += 1
+            elif i % stride == 1 or stride == 1:
+                net.profile_enable(0)
         run()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -192,16 +201,19 @@ def main():
                 "frac": None, "traffic": None, "kernel": "MFMA implicit-GEMM convolution: forward, dgrad and wgrad launches (conv_haloq / conv_halo / conv_igemm / wgrad9 / wgrad); time = union of the launch intervals"}
         kernels = None
         if prof is not None:
-            if busy is not None and busy[1] > 0:
-                t_igemm, n_launch = busy[0] / args.steps * 1e-3, busy[1]
+            if busy is not None and busy[1] > 0:      # the bracketed steps of the timed region
+                psteps = max(sampled, 1)
+                t_igemm, n_launch = busy[0] / psteps * 1e-3, busy[1]
             else:   # serialised pass: the sum of the durations is the busy time
-                t_igemm = (prof["conv_fwd"][0] + prof["dgrad"][0] + prof["wgrad"][0]) / args.steps * 1e-3
+                psteps = args.steps
+                t_igemm = (prof["conv_fwd"][0] + prof["dgrad"][0] + prof["wgrad"][0]) / psteps * 1e-3
                 n_launch = prof["conv_fwd"][1] + prof["dgrad"][1] + prof["wgrad"][1]
             if t_igemm > 0:
                 roof["achieved"] = igemm_flops / t_igemm / 1e12
                 roof["frac"] = roof["achieved"] / roof["peak"]
-                roof["avg_launch_ms"] = t_igemm * 1e3 * args.steps / max(n_launch, 1)
-                roof["launches_per_step"] = n_launch / args.steps
+                roof["avg_launch_ms"] = t_igemm * 1e3 * psteps / max(n_launch, 1)
+                roof["launches_per_step"] = n_launch / psteps
+                roof["bracketed_steps"] = psteps
             kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps}
                        for k, v in (prof_all or prof).items()}
             if not args.forward_only and (prof_all or prof)["wgrad"][0] > 0:

@@ -89,7 +89,8 @@ int y2_debug_read(y2_ctx* ctx, int layer, int what, float* dst, void* stream);
  * HIP events on the launch stream (the reference only has utils/timer.py wall clocks).
  * Categories: 0 conv fwd (implicit GEMM), 1 conv1 fwd, 2 dgrad, 3 wgrad, 4 conv1 wgrad,
  * 5 BN fwd passes, 6 BN bwd passes, 7 pack/convert.  on = 1: every launch, serialised
- * (no side stream); on = 2: only the MFMA convolution launches (categories 0, 2, 3), streams as in production.  collect() waits for the events. */
+ * (no side stream); on = 2: only the MFMA convolution launches (categories 0, 2, 3), streams as in production;
+ * on = 0 stops recording but keeps the records, on = 3 resumes mode 2 without clearing (sampling some steps).  collect() waits for the events. */
 int y2_profile_enable(y2_ctx* ctx, int on);
 int y2_profile_collect(y2_ctx* ctx, double* ms_by_category, int* launches_by_category, int ncat);
 /* length of the union of the [start, end] intervals of the launches whose category bit is set in cat_mask

@@ -303,9 +303,11 @@ void y2_ctx_destroy(y2_ctx* ctx) {
     delete ctx;
 }
 
+// on: 0 stop (records are kept until collected), 1 / 2 start afresh, 3 resume mode 2 without clearing
+// (sampling: bracket only some steps of a timed region)
 int y2_profile_enable(y2_ctx* c, int on) {
-    c->prof = on;
-    c->prof_used = 0;
+    if (on == 1 || on == 2) c->prof_used = 0;
+    c->prof = on == 3 ? 2 : on;
     return Y2_OK;
 }
 int y2_profile_collect(y2_ctx* c, double* ms, int* count, int ncat) {
