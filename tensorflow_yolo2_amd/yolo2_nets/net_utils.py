@@ -99,3 +99,77 @@ def show_yolo_detection(image_path, predict_output, imdb, object_thresh=0.5, sho
         except ImportError:
             pass
     return dets
+
+
+# ---------------------------------------------------------------------------
+# snapshots keyed by the reference's TF variable names (the counterpart of
+# get_ordered_ckpts / restore_darknet19_variables, src/yolo2_nets/net_utils.py:14-110).
+# TF checkpoint FILES are out of scope (no TensorFlow here); the name map is what a converter needs,
+# and these .npz snapshots carry exactly the names tf.train.Saver would write.
+# ---------------------------------------------------------------------------
+import glob
+import os
+import re
+
+from . import darknet as _darknet
+
+
+def _kind_of(network):
+    n = network.num_layers
+    return {18: "core", 19: "classifier", 22: "detector"}.get(n, "detector")
+
+
+def save_variables(network, path, kind=None):
+    """write every parameter and BN moving statistic of `network` under its TF variable name"""
+    kind = kind or _kind_of(network)
+    names = _darknet.variable_names("classifier" if kind in ("core", "classifier") else kind,
+                                    network.spec[-1][2])[:network.num_layers]
+    blob = {}
+    for layer, nm in zip(network.export_params(), names):
+        for k, tfname in nm.items():
+            blob[tfname] = layer[k]
+    np.savez(path, **blob)
+    return sorted(blob)
+
+
+def restore_variables(network, path, kind=None):
+    """load the variables whose names are present in the snapshot, leave the others as they are
+    (the reference restores the ImageNet-trained backbone into the detector this way, :83-103).
+    Returns (restored names, names left untouched)."""
+    kind = kind or _kind_of(network)
+    names = _darknet.variable_names("classifier" if kind in ("core", "classifier") else kind,
+                                    network.spec[-1][2])[:network.num_layers]
+    snap = np.load(path)
+    layers = network.export_params()
+    restored, kept = [], []
+    for layer, nm in zip(layers, names):
+        for k, tfname in nm.items():
+            if tfname in snap.files and tuple(snap[tfname].shape) == tuple(layer[k].shape):
+                layer[k] = snap[tfname]
+                restored.append(tfname)
+            else:
+                kept.append(tfname)
+    network.load_params(layers)
+    return restored, kept
+
+
+def get_ordered_ckpts(ckpt_dir, net_name='darknet19', save_epoch=True):
+    """snapshot files of `net_name` in `ckpt_dir`, oldest first (reference :14-38 orders by mtime)"""
+    tag = "epoch" if save_epoch else "iter"
+    files = [f for f in glob.glob(os.path.join(ckpt_dir, "%s_%s_*.npz" % (net_name, tag)))]
+    return sorted(files, key=os.path.getmtime)
+
+
+def restore_darknet19_variables(network, ckpt_dir, net_name='darknet19', save_epoch=True, imagenet_ckpt_dir=None):
+    """Reference :64-110: restore the latest snapshot and return its epoch / iteration number; with no
+    snapshot, restore what an ImageNet-classifier snapshot holds (the backbone) and return 0."""
+    sfiles = get_ordered_ckpts(ckpt_dir, net_name, save_epoch)
+    if not sfiles:
+        if imagenet_ckpt_dir:
+            prior = get_ordered_ckpts(imagenet_ckpt_dir, net_name, True)
+            if prior:
+                restore_variables(network, prior[-1])
+        return 0
+    restore_variables(network, sfiles[-1])
+    m = re.search(r"_(\d+)\.npz$", sfiles[-1])
+    return int(m.group(1)) if m else 0

@@ -297,3 +297,29 @@ def test_multi_scale_trainer_shares_parameters_across_sizes():
     ptrs = {net.params.data_ptr() for net in ms.nets.values()} | {net.grads.data_ptr() for net in ms.nets.values()}
     assert len(ptrs) == 2                                   # one parameter buffer, one gradient buffer
     assert ms.nets[608].out_shape[1] == 19
+
+
+def test_snapshots_by_tf_variable_name(tmp_path):
+    """snapshots keyed by the reference's TF variable names; a classifier snapshot restores the
+    backbone of a detector and leaves the head at its initial values (reference net_utils.py:83-103)."""
+    from tensorflow_yolo2_amd import engine as E
+    from tensorflow_yolo2_amd.yolo2_nets import net_utils as NU, darknet as D
+    cls = E.Network(list(E.CORE_SPEC) + list(E.CLS_HEAD_SPEC), 1, 64, 64, dtype="f32", core_layers=19, training=False)
+    cls.init_params(5)
+    os.makedirs(tmp_path / "imagenet", exist_ok=True)
+    names = NU.save_variables(cls, str(tmp_path / "imagenet" / "darknet19_epoch_3.npz"), "classifier")
+    assert "darknet19/Variable" in names and "darknet19/batch_normalization_18/moving_variance" in names
+    det = E.Network(list(E.CORE_SPEC) + E.det_head_spec(30), 1, 64, 64, dtype="f32", core_layers=18, training=False)
+    det.init_params(9)
+    before = det.export_params()
+    os.makedirs(tmp_path / "voc", exist_ok=True)
+    assert NU.restore_darknet19_variables(det, str(tmp_path / "voc"), imagenet_ckpt_dir=str(tmp_path / "imagenet")) == 0
+    after, src = det.export_params(), cls.export_params()
+    for l in range(18):
+        np.testing.assert_array_equal(after[l]["W"], src[l]["W"])
+    for l in range(18, 22):
+        np.testing.assert_array_equal(after[l]["W"], before[l]["W"])
+    NU.save_variables(det, str(tmp_path / "voc" / "darknet19_epoch_7.npz"))
+    det.init_params(11)
+    assert NU.restore_darknet19_variables(det, str(tmp_path / "voc")) == 7
+    np.testing.assert_array_equal(det.export_params()[20]["W"], after[20]["W"])
