@@ -221,8 +221,8 @@ __global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9_kernel(WgradArgs a, in
 // live in an LDS ring of R = 2^k rows: every step stages only its 64 NEW rows (one aligned
 // group), the nine taps read row-shifted views of the ring, and the wrap is one AND on the
 // byte offset (v_add + v_and_or per address, hidden in the MFMA shadow).
-//   group g = window rows [64g, 64g+64); step st reads groups st .. st+G-1, G = ceil(wrows/64);
-//   group st+G is in flight during step st, so R >= 64*(G+1).
+//   group g = window rows [BKP*g, BKP*(g+1)) (BKP = 64 or 128 pixels per K step); step st reads groups
+//   st .. st+G-1, G = ceil(wrows/BKP); group st+G is in flight during step st, so R >= BKP*(G+1).
 // ---------------------------------------------------------------------------
 template <typename T>
 Y2_DEV typename Elem<T>::frag tr_frag_off(uint32_t o0, uint32_t o1) {
@@ -232,12 +232,12 @@ Y2_DEV typename Elem<T>::frag tr_frag_off(uint32_t o0, uint32_t o1) {
     return __builtin_bit_cast(typename Elem<T>::frag, both);
 }
 
-template <typename T, int WI, int WO, int TG, int T0, int NTAP>
+template <typename T, int WI, int WO, int TG, int T0, int NTAP, int KS = 1>
 Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
-    typedef Wg9Cfg<T, WI, WO, TG> Cfg;
+    typedef Wg9Cfg<T, WI, WO, TG, KS> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
-    static_assert(SZ == 2 && BKP == 64, "ring form: 16-bit elements");
+    static_assert(SZ == 2, "ring form: 16-bit elements");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = w % (WI * WO);
@@ -277,10 +277,10 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
         const int sl = (lane % Cfg::LPRY) ^ wg9_swz<ROWY, SZ>(row);
         voffy[i] = (uint32_t)row * (uint32_t)(a.Cdy * SZ) + sl * 16;
     }
-    auto stage_x = [&](int g) {   // 64 rows: 64 / RPIX pieces of 1 KiB (aligned: a piece never wraps)
+    auto stage_x = [&](int g) {   // BKP rows: BKP / RPIX pieces of 1 KiB (aligned: a piece never wraps)
         const char* xs = xg + (long)g * xstep;
-        char* dst = smem + (((uint32_t)g * 64u * ROWX) & maskB);
-        for (int i = w; i < 64 / Cfg::RPIX; i += NW) {
+        char* dst = smem + (((uint32_t)g * (uint32_t)BKP * ROWX) & maskB);
+        for (int i = w; i < BKP / Cfg::RPIX; i += NW) {
             const int row = i * Cfg::RPIX + lrx;   // row & 3 == LDS row & 3 (groups are 64-row aligned)
             const uint32_t off = (uint32_t)row * (uint32_t)(a.Cin * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
             glds16(xs + off, dst + i * 1024);
@@ -356,7 +356,7 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) rbB[t] = (rbB[t] + 64u * ROWX) & maskB;
+        for (int t = 0; t < NTAP; ++t) rbB[t] = (rbB[t] + (uint32_t)BKP * ROWX) & maskB;
     }
     const int co = co0 + wo * 32 + r32;
     if (co < a.Cout) {
@@ -374,33 +374,33 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
     }
 }
 
-template <typename T, int WI, int WO, int TG>
+template <typename T, int WI, int WO, int TG, int KS = 1>
 __global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9r_kernel(WgradArgs a, int lgR, int G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (TG == 1) {
-        wg9r_body<T, WI, WO, 1, 0, 9>(a, lgR, G, smem);
+        wg9r_body<T, WI, WO, 1, 0, 9, KS>(a, lgR, G, smem);
     } else {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (w < WI * WO) wg9r_body<T, WI, WO, 2, 0, 5>(a, lgR, G, smem);
-        else wg9r_body<T, WI, WO, 2, 5, 4>(a, lgR, G, smem);
+        if (w < WI * WO) wg9r_body<T, WI, WO, 2, 0, 5, KS>(a, lgR, G, smem);
+        else wg9r_body<T, WI, WO, 2, 5, 4, KS>(a, lgR, G, smem);
     }
 }
 
 // blocks_target: split-K so that tiles * splitk ~ blocks_target; 0 = one full wave of resident
 // blocks (256 CUs x blocks per CU by LDS, at most 3: measured best on every long-row shape --
 // 1.5 waves of blocks cost 30 % at 104x104)
-template <typename T, int WI, int WO, int TG>
+template <typename T, int WI, int WO, int TG, int KS = 1>
 static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0) {
-    typedef Wg9Cfg<T, WI, WO, TG> Cfg;
+    typedef Wg9Cfg<T, WI, WO, TG, KS> Cfg;
     static_assert(Cfg::NIY % Cfg::NW == 0, "dY pieces must split evenly over waves");
     const int pitch = a.W + 1;
     const int wrows = Cfg::BKP + 2 * pitch + 2;
-    const int G = (wrows + 63) / 64;
+    const int G = (wrows + Cfg::BKP - 1) / Cfg::BKP;
     int lgR = 7;
-    while ((1 << lgR) < 64 * (G + 1)) ++lgR;
+    while ((1 << lgR) < Cfg::BKP * (G + 1)) ++lgR;
     const size_t lds = ((size_t)Cfg::ROWX << lgR) + 2 * (size_t)Cfg::YS;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    auto kern = wgrad9r_kernel<T, WI, WO, TG>;
+    auto kern = wgrad9r_kernel<T, WI, WO, TG, KS>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
     const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
@@ -486,8 +486,9 @@ static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
         static const int minw = getenv("Y2DEV_WG9R_MINW") ? atoi(getenv("Y2DEV_WG9R_MINW")) : 52;
         if (a.W >= minw) {
             hipError_t e;
-            // 32 ci x 64 co tiles (64-byte X rows: a smaller ring, three blocks per CU) from 104 up
-            if (a.Cin >= 64 && !(a.W >= 104 && a.Cdy >= 64)) e = wg9r_launch<T, 2, 1, 2>(a, s);
+            // 64 ci x 32 co tiles with 128-pixel K steps measured best at 52 and 104 (3-7 % over 64-pixel
+            // steps); 32-channel inputs (208x208): 32 ci x 64 co tiles, 64-pixel steps
+            if (a.Cin >= 64) e = wg9r_launch<T, 2, 1, 2, 2>(a, s);
             else if (a.Cdy >= 64) e = wg9r_launch<T, 1, 2, 2>(a, s);
             else e = wg9r_launch<T, 1, 1, 2>(a, s);
             if (e != hipErrorOutOfMemory) return e;
@@ -557,6 +558,10 @@ hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s)
         case 37: return wg9r_launch<half_t, 2, 1, 2>(a, s, 1024);
         case 38: return wg9r_launch<half_t, 1, 2, 2>(a, s, 1024);
         case 39: return wg9r_launch<half_t, 2, 2, 2>(a, s, 1024);
+        case 44: return wg9r_launch<half_t, 1, 2, 2, 2>(a, s);       // ring, K step 128
+        case 45: return wg9r_launch<half_t, 2, 1, 2, 2>(a, s);
+        case 46: return wg9r_launch<half_t, 1, 2, 2, 2>(a, s, 512);
+        case 47: return wg9r_launch<half_t, 2, 1, 2, 2>(a, s, 512);
         case 40: return wg9r_launch<half_t, 1, 2, 2>(a, s, 384);
         case 41: return wg9r_launch<half_t, 1, 2, 2>(a, s, 256);
         case 42: return wg9r_launch<half_t, 2, 1, 2>(a, s, 384);
