@@ -6,6 +6,7 @@
 // Reference semantics: tf.layers.batch_normalization(center, scale, training)
 // + tf.maximum(0.1*h, h) + tf.nn.max_pool(2,2,'SAME')
 // (src/yolo2_nets/darknet.py:24-25,39-46); momentum 0.99, eps 1e-3 (TF defaults).
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -20,6 +21,7 @@ constexpr int kFinCh = 8, kFinSl = 128;
 
 // sum over the 128 slices of one channel: 3 in-wave shuffle steps (a wave holds 8 channels x 8
 // slices), then 16 per-wave partials through LDS -- two barriers instead of a 7-level tree
+template <int NWV = kFinSl * kFinCh / 64>
 Y2_DEV double fin_block_sum(double v, double (*red)[kFinCh], int sl, int cl) {
     v += __shfl_xor(v, 8, 64);
     v += __shfl_xor(v, 16, 64);
@@ -30,7 +32,7 @@ Y2_DEV double fin_block_sum(double v, double (*red)[kFinCh], int sl, int cl) {
     __syncthreads();
     double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) t += red[w][cl];
+    for (int w = 0; w < NWV; ++w) t += red[w][cl];
     return t;
 }
 
@@ -390,7 +392,13 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
 }
 
 // after the reduce pass: dbeta, dgamma, dbias and the apply-pass constants coef = [ka][kb]
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs a, int P) {
+// 256-thread blocks (32 slices x 8 channels): this kernel sits on the backward critical path while the
+// previous layer's weight gradient fills the CUs from the side stream -- a 16-wave block waits for a whole
+// CU to drain (measured 27 us instead of 8), a 4-wave block is placed at once
+constexpr int kBwdFinSl = 32;
+template <int SLN>
+__global__ __launch_bounds__(SLN * kFinCh) void bn_bwd_finalize_kernel(BnBwdArgs a, int P) {
+    constexpr int kFinSl = SLN;   // shadows the forward kernel's slice count
     __shared__ double red[kFinSl][kFinCh];
     const int cl = threadIdx.x % kFinCh, sl = threadIdx.x / kFinCh;
     const int c = blockIdx.x * kFinCh + cl;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(BnBwdArgs a, int 
             for (int u = 0; u < 4; ++u) v4[u] += (double)a.psum[((size_t)(p + u * kFinSl) * 2 + k) * a.ldy + cc];
         }
         for (; p < P; p += kFinSl) v4[0] += (double)a.psum[((size_t)p * 2 + k) * a.ldy + cc];
-        t[k] = fin_block_sum((v4[0] + v4[1]) + (v4[2] + v4[3]), red, sl, cl);
+        t[k] = fin_block_sum<kFinSl * kFinCh / 64>((v4[0] + v4[1]) + (v4[2] + v4[3]), red, sl, cl);
     }
     if (sl == 0 && cv) {
         const double m = (double)a.N * a.H * a.W;
@@ -448,7 +456,7 @@ hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a, a.P);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<kBwdFinSl>, dim3((a.C + kFinCh - 1) / kFinCh), dim3(kBwdFinSl * kFinCh), 0, s, a, a.P);
     return hipGetLastError();
 }
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s) {
