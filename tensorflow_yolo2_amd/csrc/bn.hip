@@ -36,7 +36,9 @@ Y2_DEV double fin_block_sum(double v, double (*red)[kFinCh], int sl, int cl) {
     return t;
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinalizeArgs a) {
+template <int SLN>
+__global__ __launch_bounds__(SLN * kFinCh) void bn_finalize_kernel(BnFinalizeArgs a) {
+    constexpr int kFinSl = SLN;   // slices of the partial list per block
     __shared__ double red[kFinSl][kFinCh];
     const int cl = threadIdx.x % kFinCh, sl = threadIdx.x / kFinCh;
     const int c = blockIdx.x * kFinCh + cl;
@@ -68,9 +70,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinalizeArgs a) {
         a4[0] += k * d;
         b4[0] += (double)a.part_m2[q] + k * d * d;
     }
-    const double ntot = fin_block_sum((n4[0] + n4[1]) + (n4[2] + n4[3]), red, sl, cl);
-    const double atot = fin_block_sum((a4[0] + a4[1]) + (a4[2] + a4[3]), red, sl, cl);
-    const double btot = fin_block_sum((b4[0] + b4[1]) + (b4[2] + b4[3]), red, sl, cl);
+    const double ntot = fin_block_sum<kFinSl * kFinCh / 64>((n4[0] + n4[1]) + (n4[2] + n4[3]), red, sl, cl);
+    const double atot = fin_block_sum<kFinSl * kFinCh / 64>((a4[0] + a4[1]) + (a4[2] + a4[3]), red, sl, cl);
+    const double btot = fin_block_sum<kFinSl * kFinCh / 64>((b4[0] + b4[1]) + (b4[2] + b4[3]), red, sl, cl);
     const double mean = ntot > 0 ? sft + atot / ntot : 0.0;
     double mt = ntot > 0 ? btot - atot * atot / ntot : 0.0;
     if (mt < 0) mt = 0;
@@ -94,7 +96,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(BnFinalizeArgs a) {
 }
 
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.C + kFinCh - 1) / kFinCh), dim3(1024), 0, s, a);
+    // short partial lists (the 13x13 / 26x26 layers: a few dozen records) finish sooner in 4-wave blocks
+    if (a.P <= 512) hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((a.C + kFinCh - 1) / kFinCh), dim3(32 * kFinCh), 0, s, a);
+    else hipLaunchKernelGGL(bn_finalize_kernel<128>, dim3((a.C + kFinCh - 1) / kFinCh), dim3(128 * kFinCh), 0, s, a);
     return hipGetLastError();
 }
 
