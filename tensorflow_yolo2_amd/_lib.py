@@ -76,6 +76,10 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise Y2Error("HIP extension not built: %s is missing (run __graft_entry__.build())" % LIB_PATH)
+    # torch first: the process must hold ONE HIP runtime.  torch brings its own libamdhip64; loaded after
+    # /opt/rocm's copy (which this library would pull in) the two disagree and every HIP call of this
+    # library fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is absent

@@ -255,14 +255,7 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(Conv1Args a) {
 
 hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
     dim3 g(a.nblocks), b(256);
-    static const bool dev_old = getenv("Y2DEV_C1STATS_OLD") != nullptr;
-    if (a.stats_only && dev_old) {
-        switch (dtype) {
-            case 0: hipLaunchKernelGGL((conv1_fwd_kernel<float, false>), g, b, 0, s, a); break;
-            case 1: hipLaunchKernelGGL((conv1_fwd_kernel<half_t, false>), g, b, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t, false>), g, b, 0, s, a); break;
-        }
-    } else if (a.stats_only) {
+    if (a.stats_only) {
         switch (dtype) {
             case 0: hipLaunchKernelGGL(conv1_stats_kernel<float>, g, b, 0, s, a); break;
             case 1: hipLaunchKernelGGL(conv1_stats_kernel<half_t>, g, b, 0, s, a); break;
