@@ -342,9 +342,10 @@ bool conv_frag_filters(int taps, int W, int Cout) {
     return W <= 26 || (W > 52 && W <= 104) || (W > 104 && Cout <= 32);
 }
 
-// Kernel policy (measured on MI355X, scripts/bench_conv.py): the halo image wins where the
-// image rows are short (13x13, 26x26: the nine taps share ~85 % of their rows); on the large
-// feature maps the image would take a whole CU's LDS, and the per-tap kernel with 8 waves wins.
+// Kernel policy (measured on MI355X, scripts/bench_conv.py and profile_layers.py):
+//   3x3, rows <= 26 / 104 / the 208-wide 32-channel dgrad : conv_haloq (halo image + register filters)
+//   3x3, rows of 52                                        : conv_halo  (halo image + LDS filter ring)
+//   3x3 208-wide forward, and every 1x1                    : conv_igemm (per-tap staging)
 // *block_pixels receives the pixel-tile size used (= rows per BN partial record)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels) {
     int bp = conv_block_pixels(a.Cout);
