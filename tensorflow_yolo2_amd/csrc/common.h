@@ -71,6 +71,20 @@ Y2_DEV void mma32(f32x16& acc, const bf16x8& a, const bf16x8& b) {
 }
 
 // row index inside a 32x32 accumulator tile held by (reg q, lane half h)
+// 16x16 MFMA tiles: D[row 4*(lane>>4) + reg][col lane&15]; A rows / B columns = lane & 15, k-chunk = lane >> 4
+Y2_DEV void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+Y2_DEV void mma16(f32x4& acc, const f16x8& a, const f16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+Y2_DEV void mma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+
 Y2_DEV int acc_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
 // 16-byte vector of T (a "chunk"): load/store + per-element float access

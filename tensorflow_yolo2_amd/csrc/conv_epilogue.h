@@ -24,14 +24,18 @@ struct EpiCfg {
     static constexpr int LDS = NW * EPW + ESTAT;
 };
 
+// phases 2 and 3 (after the wave's patch has been written)
+template <typename T, int WP, int WC, int TP, int TC, int EABL = 0>
+Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane, int m0, int n0, int pt, int ct);
+
 // must be entered by ALL threads of the block, after a barrier that retires every read
 // of the staging buffers (the patch aliases them)
 template <typename T, int WP, int WC, int TP, int TC, int EABL = 0>
 Y2_DEV void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TC][TP], char* smem, int w, int lane, int m0, int n0,
                           int pt, int ct) {
     typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
-    constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BP = Cfg::BP, EROW = Cfg::EROW;
-    const int wp = w / WC, wc = w % WC;
+    constexpr int SZ = Cfg::SZ, EROW = Cfg::EROW;
+    const int wc = w % WC;
     const int r32 = lane & 31, hh = lane >> 5;
     char* ew = smem + w * Cfg::EPW;
     const int cw0 = n0 + wc * TC * 32;  // first cout of this wave
@@ -56,6 +60,48 @@ Y2_DEV void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TC][TP], char* smem, 
             }
         }
     }
+    conv_epilogue_finish<T, WP, WC, TP, TC, EABL>(a, smem, w, lane, m0, n0, pt, ct);
+}
+
+// same, accumulators of 16x16 MFMA tiles: acc[i16][j16][r] = D[cout i16*16 + 4*(lane>>4) + r][pixel j16*16 + (lane&15)]
+// (TP, TC still count 32-wide units: the wave tile and the patch are the same as above)
+template <typename T, int WP, int WC, int TP, int TC>
+Y2_DEV void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[2 * TC][2 * TP], char* smem, int w, int lane, int m0,
+                            int n0, int pt, int ct) {
+    typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
+    constexpr int SZ = Cfg::SZ, EROW = Cfg::EROW;
+    const int wc = w % WC;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    char* ew = smem + w * Cfg::EPW;
+    const int cw0 = n0 + wc * TC * 32;
+#pragma unroll
+    for (int i = 0; i < 2 * TC; ++i) {
+        const int cl = i * 16 + 4 * g4;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b4[j] = (cw0 + cl + j < a.Cout) ? a.bias[cw0 + cl + j] : 0.f;
+        }
+#pragma unroll
+        for (int j2 = 0; j2 < 2 * TP; ++j2) {
+            T o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = Elem<T>::from_f32(acc[i][j2][j] + b4[j]);
+            char* dst = ew + (j2 * 16 + r16) * EROW + cl * SZ;
+            if (SZ == 2) *(u32x2*)dst = *(const u32x2*)o;
+            else *(u32x4*)dst = *(const u32x4*)o;
+        }
+    }
+    conv_epilogue_finish<T, WP, WC, TP, TC, 0>(a, smem, w, lane, m0, n0, pt, ct);
+}
+
+template <typename T, int WP, int WC, int TP, int TC, int EABL>
+Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane, int m0, int n0, int pt, int ct) {
+    typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
+    constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BP = Cfg::BP, EROW = Cfg::EROW;
+    const int wp = w / WC, wc = w % WC;
+    char* ew = smem + w * Cfg::EPW;
+    const int cw0 = n0 + wc * TC * 32;  // first cout of this wave
     if (EABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else __syncthreads();
 

@@ -337,9 +337,15 @@ static int dev_rule(int W, int Cout) {
 // PackLayer::wf_frag / wd_frag).
 // Measured (scripts/bench_conv.py, rotating buffers): wins up to 26x26 and again at 104x104 (big 512-pixel
 // tiles); at 52x52 the LDS filter ring is as fast, at 208x208 only the 32-channel dgrad gains.
-bool conv_frag_filters(int taps, int W, int Cout) {
-    if (taps != 9) return false;
-    return W <= 26 || (W > 52 && W <= 104) || (W > 104 && Cout <= 32);
+// 0: K-contiguous rows (conv_halo / conv_igemm); 1: 32-row MFMA fragments (conv_haloq, 32x32x16 tiles);
+// 2: 16-row fragments (conv_haloq on 16x16x32 tiles: the 384 x 128 tile class up to 26x26, +3-4 %).
+// row_bytes = input channels * element size of the launch (forward: cin_s, dgrad: ldy).
+int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M) {
+    if (taps != 9) return 0;
+    if (!(W <= 26 || (W > 52 && W <= 104) || (W > 104 && Cout <= 32))) return 0;
+    const bool narrow = ((M + 383) / 384) * ((Cout + 127) / 128) < 160;
+    if (W <= 26 && Cout > 64 && M >= 384 * 8 && (row_bytes % 128) == 0 && !narrow) return 2;
+    return 1;
 }
 
 // Kernel policy (measured on MI355X, scripts/bench_conv.py and profile_layers.py):
@@ -351,7 +357,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_p
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
     const int forced = (a.taps == 9 && dtype == 1) ? dev_rule(a.W, a.Cout) : -1;
-    if (conv_frag_filters(a.taps, a.W, a.Cout)) e = launch_conv_haloq(dtype, a, s, &bp);
+    if (conv_filter_layout(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M)) e = launch_conv_haloq(dtype, a, s, &bp);
     else if (forced >= 0) e = launch_conv_halo_variant(forced, a, s, &bp);
     else if (a.taps == 9 && a.W <= 52) e = launch_conv_halo(dtype, a, s, &bp);
     else e = launch_conv_igemm(dtype, a, s);

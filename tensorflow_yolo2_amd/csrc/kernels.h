@@ -26,7 +26,7 @@ struct ConvArgs {
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
 hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels); // + filters via registers
-bool conv_frag_filters(int taps, int W, int Cout);   // does launch_conv expect fragment-ordered filters for this launch?
+int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M);   // filter layout launch_conv expects (0/1/2)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels = nullptr);  // policy
 int conv_block_pixels(int Cout);
 int conv_block_couts(int Cout);
@@ -123,7 +123,7 @@ struct PackLayer {
     void* wd;           // null: no dgrad copy
     int taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy;
     int wf_bx, wf_by, wf_blocks, wd_blocks, first_block;
-    int wf_frag, wd_frag;   // 1: MFMA-fragment order (conv_haloq.hip) instead of K-contiguous rows
+    int wf_frag, wd_frag;   // conv_filter_layout(): 0 K-contiguous rows, 1 / 2 MFMA-fragment order (32 / 16 rows)
 };
 void pack_layer_plan(PackLayer& L, int first_block, int elem_size);
 hipError_t launch_pack_all(int dtype, const PackLayer* tab_dev, int nlayers, int total_blocks, hipStream_t s);

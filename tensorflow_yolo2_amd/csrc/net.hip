@@ -414,8 +414,8 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
         p.wd = (training && l > 0) ? (void*)(c->ws + y.wd) : nullptr;
         p.taps = y.k * y.k; p.Cin = y.cin; p.Cout = y.cout; p.Cout_pad = y.cout_pad; p.Kc = y.cin_s;
         p.Cin_pad = y.cin_pad; p.Cdy = y.ldy;
-        p.wf_frag = conv_frag_filters(p.taps, y.W, y.cout) ? 1 : 0;     // forward launch: Cout = cout
-        p.wd_frag = conv_frag_filters(p.taps, y.W, y.cin) ? 1 : 0;      // dgrad launch: Cout = cin
+        p.wf_frag = conv_filter_layout(p.taps, y.W, y.cin_s * (int)c->sz(), y.cout, y.M);   // forward launch
+        p.wd_frag = conv_filter_layout(p.taps, y.W, y.ldy * (int)c->sz(), y.cin, y.M);      // dgrad launch: Cout = cin
         pack_layer_plan(p, nb, (int)c->sz());
         nb += p.wf_blocks + p.wd_blocks;
         c->packtab.push_back(p);
@@ -794,7 +794,7 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
     char* xp = ws + p.xp + g.base_off(sz);
     HIPCHK(launch_pack_act(dtype, x, xp, N, H, W, Cin, p.Cin_p, s));
     HIPCHK(launch_pack_weights(dtype, w, ws + p.wf, nullptr, k * k, Cin, Cout, p.Cout_pad, p.Cin_p, 0, 0,
-                               conv_frag_filters(k * k, W, Cout) ? 1 : 0, s));
+                               conv_filter_layout(k * k, W, p.Cin_p * (int)sz, Cout, N * H * W), s));
     ConvArgs a{};
     a.x = xp; a.w = ws + p.wf; a.y = ws + p.y; a.bias = bias;
     a.N = N; a.H = H; a.W = W; a.C = p.Cin_p; a.M = N * H * W; a.Cout = Cout; a.ldy = p.ldy; a.taps = k * k;
@@ -819,7 +819,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
     HIPCHK(launch_pack_act(dtype, dy, dyp, N, H, W, Cout, p.Cdy, s));
     if (dx) {
         HIPCHK(launch_pack_weights(dtype, w, nullptr, ws + p.wd, k * k, Cin, Cout, 0, 0, p.Cin_pad, p.Cdy,
-                                   conv_frag_filters(k * k, W, p.Cin_p) ? 1 : 0, s));
+                                   conv_filter_layout(k * k, W, p.Cdy * (int)sz, p.Cin_p, N * H * W), s));
         ConvArgs a{};
         a.x = dyp; a.w = ws + p.wd; a.y = ws + p.dx;
         a.N = N; a.H = H; a.W = W; a.C = p.Cdy; a.M = N * H * W; a.Cout = p.Cin_p; a.ldy = p.Cin_p; a.taps = k * k;

@@ -151,6 +151,16 @@ __host__ __device__ inline size_t frag_chunk(int row, int t, int k, int taps, in
     return ((size_t)(row >> 5) * taps * kgrow + (size_t)t * kgrow + kg) * 64 + hh * 32 + (row & 31);
 }
 
+// 16-row form (conv_haloq16): [row tile of 16][tap][k-group of 64 bytes][lane = (16-byte chunk)*16 + row%16][16 B]
+__host__ __device__ inline size_t frag_chunk16(int row, int t, int k, int taps, int krow, int EPC) {
+    const int kgrow = krow / (4 * EPC);
+    const int kg = k / (4 * EPC), kc = (k / EPC) & 3;
+    return ((size_t)(row >> 4) * taps * kgrow + (size_t)t * kgrow + kg) * 64 + kc * 16 + (row & 15);
+}
+__host__ __device__ inline size_t frag_chunk_any(int layout, int row, int t, int k, int taps, int krow, int EPC) {
+    return layout == 2 ? frag_chunk16(row, t, k, taps, krow, EPC) : frag_chunk(row, t, k, taps, krow, EPC);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_wf_kernel(const float* __restrict__ W, T* __restrict__ wf, int taps,
                                                       int Cin, int Cout, int Cout_pad, int Kc, int frag) {
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(256) void pack_wf_kernel(const float* __restrict__ 
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         if (co < Cout_pad && ci < Kc) {
-            const size_t o = frag ? frag_chunk(co, t, ci - ci % EPC, taps, Kc, EPC) * EPC + ci % EPC
+            const size_t o = frag ? frag_chunk_any(frag, co, t, ci - ci % EPC, taps, Kc, EPC) * EPC + ci % EPC
                                   : ((size_t)co * taps + t) * Kc + ci;
             wf[o] = Elem<T>::from_f32(tile[tx][r]);
         }
@@ -184,7 +194,7 @@ __global__ void pack_wd_kernel(const float* __restrict__ W, T* __restrict__ wd, 
         const int ci = (int)(i / ((size_t)Cdy * taps));
         float v = 0.f;
         if (ci < Cin && co < Cout) v = W[((size_t)(taps - 1 - t) * Cin + ci) * Cout + co];
-        const size_t o = frag ? frag_chunk(ci, t, co - co % EPC, taps, Cdy, EPC) * EPC + co % EPC : i;
+        const size_t o = frag ? frag_chunk_any(frag, ci, t, co - co % EPC, taps, Cdy, EPC) * EPC + co % EPC : i;
         wd[o] = Elem<T>::from_f32(v);
     }
 }
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
                 Chunk<T> o;
 #pragma unroll
                 for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[cs * EPC + k][col]);
-                if (L.wf_frag) st_chunk<T>(wf + frag_chunk(co, t, ci, L.taps, L.Kc, EPC) * EPC, o);
+                if (L.wf_frag) st_chunk<T>(wf + frag_chunk_any(L.wf_frag, co, t, ci, L.taps, L.Kc, EPC) * EPC, o);
                 else st_chunk<T>(wf + ((size_t)co * L.taps + t) * L.Kc + ci, o);
             }
         }
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
                     for (int e = 0; e < EPC; ++e)
                         o.v[e] = Elem<T>::from_f32((ci < L.Cin && co + e < L.Cout) ? src[e] : 0.f);
                 }
-                if (L.wd_frag) st_chunk<T>(wd + frag_chunk(ci, tt, co, L.taps, L.Cdy, EPC) * EPC, o);
+                if (L.wd_frag) st_chunk<T>(wd + frag_chunk_any(L.wd_frag, ci, tt, co, L.taps, L.Cdy, EPC) * EPC, o);
                 else st_chunk<T>(wd + (size_t)i * EPC, o);
             }
         }
