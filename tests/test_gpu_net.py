@@ -323,3 +323,30 @@ def test_snapshots_by_tf_variable_name(tmp_path):
     det.init_params(11)
     assert NU.restore_darknet19_variables(det, str(tmp_path / "voc")) == 7
     np.testing.assert_array_equal(det.export_params()[20]["W"], after[20]["W"])
+
+
+def test_profile_busy_is_union_of_launch_intervals():
+    """y2_profile_busy: the MFMA launches' busy time (union of intervals; the weight gradients run on a side
+    stream beside the dgrads) is positive, covers every bracketed launch and never exceeds the sum of the
+    individual durations."""
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.trainer import DetectorTrainer
+    core = [(k, ci, co, int(p)) for (k, ci, co, p) in R.scaled_spec(R.CORE_SPEC, 4)]
+    head = [(3, core[-1][2], 256, 0), (1, 256, 30, 0)]
+    tr = DetectorTrainer(8, 128, dtype="f16", seed=1, core_spec=core, head_spec=head)
+    x, lab = dev(synthetic.images(8, 128, 1)), dev(synthetic.det_labels(8, 128, 4, 2))
+    tr.step(x, lab)
+    tr.net.profile_enable(2)
+    for _ in range(3):
+        tr.step(x, lab)
+    torch.cuda.synchronize()
+    busy, launches = tr.net.profile_busy()
+    prof = tr.net.profile_collect()
+    tr.net.profile_enable(0)
+    total = sum(prof[k][0] for k in ("conv_fwd", "dgrad", "wgrad"))
+    count = sum(prof[k][1] for k in ("conv_fwd", "dgrad", "wgrad"))
+    nl = len(core) + len(head)
+    assert launches == count == 3 * ((nl - 1) * 3)          # forward, dgrad and wgrad of layers 1..L-1
+    assert 0.0 < busy <= total * 1.0001
+    assert all(prof[k][1] == 0 for k in ("bn_fwd", "bn_bwd", "misc"))   # mode 2 brackets the MFMA launches only
