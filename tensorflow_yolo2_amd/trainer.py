@@ -19,8 +19,12 @@ from .engine import (CORE_SPEC, CLS_HEAD_SPEC, det_head_spec, Network, AdamOptim
 
 
 def _dist():
+    import os
     import torch.distributed as dist
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    # Y2_FORCE_DIST=1: take the sliced all-reduce path even at world size 1 (single-GPU check of the RCCL calls)
+    return dist if (dist.get_world_size() > 1 or os.environ.get("Y2_FORCE_DIST") == "1") else None
 
 
 def layer_slices(num_layers):
