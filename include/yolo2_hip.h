@@ -82,6 +82,11 @@ int y2_forward(y2_ctx* ctx, const float* images, int is_training_core, int is_tr
  * for layers [layer_lo, layer_hi) walking downwards; call with (0, num_layers)
  * for the whole net, or in slices to overlap the all-reduce of finished layers. */
 int y2_backward(y2_ctx* ctx, const float* dout, int layer_lo, int layer_hi, void* stream);
+/* All layers in one pass, with an event pair recorded when every layer >= mark_layers[k] is complete (data
+ * parallelism: the all-reduce of a gradient slice starts behind y2_wait_mark on its own stream while the
+ * pass continues; no join on `stream` until the end, unlike one y2_backward call per slice). */
+int y2_backward_marks(y2_ctx* ctx, const float* dout, int n_marks, const int* mark_layers, void* stream);
+int y2_wait_mark(y2_ctx* ctx, int k, void* stream);
 /* copy a layer's saved activation (post BN+leaky+pool input of `layer`, or conv output) for tests */
 int y2_debug_read(y2_ctx* ctx, int layer, int what, float* dst, void* stream);
 

@@ -40,6 +40,8 @@ SIGNATURES = {
     "y2_params_changed": (_i, [_vp]),
     "y2_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "y2_backward": (_i, [_vp, _vp, _i, _i, _vp]),
+    "y2_backward_marks": (_i, [_vp, _vp, _i, _pi, _vp]),
+    "y2_wait_mark": (_i, [_vp, _i, _vp]),
     "y2_debug_read": (_i, [_vp, _i, _i, _vp, _vp]),
     "y2_profile_enable": (_i, [_vp, _i]),
     "y2_profile_collect": (_i, [_vp, C.POINTER(C.c_double), _pi, _i]),

@@ -108,6 +108,10 @@ struct y2_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap_wgrad = 1;
+    // y2_backward_marks: (main, side) event pairs recorded when every layer >= mark_layers[k] is complete
+    std::vector<hipEvent_t> mark_main, mark_side;
+    int n_marks = 0;
+    const int* cur_marks = nullptr;
     std::vector<ProfRec> prof_recs;
     size_t prof_used = 0;
     size_t sz() const { return dtype_size(dtype); }
@@ -300,6 +304,8 @@ void y2_ctx_destroy(y2_ctx* ctx) {
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (auto e : ctx->mark_main) (void)hipEventDestroy(e);
+    for (auto e : ctx->mark_side) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -663,11 +669,43 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 c->dA_cur ^= 1;
             }
         }
+        for (int k = 0; k < c->n_marks; ++k)
+            if (c->cur_marks[k] == l) {
+                HIPCHK(hipEventRecord(c->mark_main[k], s));
+                HIPCHK(hipEventRecord(c->mark_side[k], forked ? c->side : s));
+            }
     }
     if (forked) {   // join: every gradient is complete when the caller's stream gets past this call
         HIPCHK(hipEventRecord(c->ev_join, c->side));
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
+    return Y2_OK;
+}
+
+// One backward pass over all layers that records, for each mark k, an event pair when every layer
+// >= mark_layers[k] is complete (main-stream chain and side-stream weight gradients).  A consumer stream
+// (the gradient all-reduce of that slice) waits for the pair with y2_wait_mark -- no join on the caller's
+// stream until the end of the pass, unlike one y2_backward call per slice.
+int y2_backward_marks(y2_ctx* c, const float* dout, int n_marks, const int* mark_layers, void* stream) {
+    if (n_marks < 0 || (n_marks > 0 && !mark_layers)) return fail(Y2_ERR_ARG, "bad marks");
+    while ((int)c->mark_main.size() < n_marks) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        c->mark_main.push_back(a);
+        c->mark_side.push_back(b);
+    }
+    c->n_marks = n_marks;
+    c->cur_marks = mark_layers;
+    const int rc = y2_backward(c, dout, 0, (int)c->L.size(), stream);
+    c->n_marks = 0;
+    c->cur_marks = nullptr;
+    return rc;
+}
+int y2_wait_mark(y2_ctx* c, int k, void* stream) {
+    if (k < 0 || k >= (int)c->mark_main.size()) return fail(Y2_ERR_ARG, "no such mark");
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->mark_main[k], 0));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->mark_side[k], 0));
     return Y2_OK;
 }
 

@@ -172,6 +172,16 @@ class Network:
 
     PROFILE_CATEGORIES = ("conv_fwd", "conv1_fwd", "dgrad", "wgrad", "conv1_wgrad", "bn_fwd", "bn_bwd", "misc")
 
+    def backward_marks(self, dout, mark_layers):
+        """full backward; mark k fires when every layer >= mark_layers[k] is complete (see wait_mark)"""
+        assert dout.is_cuda and dout.dtype == torch.float32 and dout.is_contiguous()
+        marks = (C.c_int * len(mark_layers))(*[int(v) for v in mark_layers])
+        check(self.lib.y2_backward_marks(self.h, _ptr(dout), len(mark_layers), marks, _stream()))
+
+    def wait_mark(self, k, stream):
+        """make `stream` (a torch.cuda.Stream) wait until mark k of the last backward_marks has fired"""
+        check(self.lib.y2_wait_mark(self.h, int(k), C.c_void_p(stream.cuda_stream)))
+
     def profile_enable(self, on=1):
         """0 off; 1 bracket every launch with HIP events (serialised: no side stream); 2 only the MFMA convolution
         launches (forward, dgrad, wgrad), streams as in production"""

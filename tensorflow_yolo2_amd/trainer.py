@@ -68,13 +68,13 @@ class GradReducer:
         if dist is None:
             net.backward(dout)
             return 1
-        for (lo, hi) in self.slices:
-            net.backward(dout if hi == net.num_layers else None, lo, hi)
-            s, e = self._range(lo, hi)
-            ready = torch.cuda.Event()
-            ready.record()
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ready)
+        # ONE backward pass; the library records an event pair per slice boundary, the all-reduce of a slice
+        # waits for its pair on the communication stream -- the compute stream never joins in between
+        net.backward_marks(dout, [lo for (lo, hi) in self.slices])
+        with torch.cuda.stream(self.comm_stream):
+            for k, (lo, hi) in enumerate(self.slices):
+                net.wait_mark(k, self.comm_stream)
+                s, e = self._range(lo, hi)
                 reduce_flat(net.grads, [(s, e)], dist)
         torch.cuda.current_stream().wait_stream(self.comm_stream)
         return dist.get_world_size()

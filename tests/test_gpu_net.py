@@ -350,3 +350,35 @@ def test_profile_busy_is_union_of_launch_intervals():
     assert launches == count == 3 * ((nl - 1) * 3)          # forward, dgrad and wgrad of layers 1..L-1
     assert 0.0 < busy <= total * 1.0001
     assert all(prof[k][1] == 0 for k in ("bn_fwd", "bn_bwd", "misc"))   # mode 2 brackets the MFMA launches only
+
+
+def test_backward_marks_equals_backward_and_orders_a_consumer_stream():
+    """y2_backward_marks / y2_wait_mark (the data-parallel hand-off): same gradients as y2_backward, and a
+    consumer stream that waits for mark k sees the finished gradients of every layer >= mark_layers[k]."""
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E
+    spec = [(3, 3, 32, 1), (3, 32, 64, 1), (1, 64, 32, 0), (3, 32, 128, 1), (3, 128, 30, 0)]
+    rng = np.random.default_rng(3)
+    x = dev(rng.uniform(-1, 1, (4, 48, 40, 3)).astype(np.float32))
+    net = E.Network(spec, 4, 48, 40, dtype="f32", training=True)
+    net.init_params(2)
+    out = net.forward(x, True, True)
+    dout = dev(rng.standard_normal(tuple(out.shape)).astype(np.float32))
+    net.backward(dout)
+    ref = net.grads.clone()
+    net.forward(x, True, True)
+    side = torch.cuda.Stream()
+    net.backward_marks(dout, [3, 0])
+    snap = {}
+    with torch.cuda.stream(side):
+        for k, lo in enumerate((3, 0)):
+            net.wait_mark(k, side)
+            start = net._offsets[lo][0]
+            snap[k] = net.grads[start:].clone()          # layers >= lo, read on the consumer stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    atol = 1e-5 * float(ref.abs().max())      # split-K float atomics: the last bits depend on the order
+    np.testing.assert_allclose(net.grads.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=atol)
+    for k, lo in enumerate((3, 0)):
+        start = net._offsets[lo][0]
+        np.testing.assert_allclose(snap[k].cpu().numpy(), ref[start:].cpu().numpy(), rtol=1e-4, atol=atol)
