@@ -93,6 +93,13 @@ def main():
                         concat=X.passthrough_concat(fine, coarse), net5=net5, anchors=anchors, boxes=boxes,
                         scores=scores, nms_boxes=nb, nms_scores=ns, nms_classes=ncls, keep_agnostic=keep_a,
                         keep_class_aware=keep_c)
+    # C1 input: the reference's tests/testImg1.jpg (352x240, a data file) decoded with PIL,
+    # BGR order, cv2-compatible bilinear resize to 224x224 and x/255*2-1 (pascal_detect_darknet.py:31-36)
+    from PIL import Image
+    rgb = np.array(Image.open(os.path.join(HERE, "testImg1.jpg")).convert("RGB"), dtype=np.uint8)
+    bgr = rgb[:, :, ::-1]
+    pre = D.normalise(D.resize_bilinear_u8(bgr, 224, 224)).astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "testImg1_input224.npz"), image=pre, shape=np.array(rgb.shape))
     print("golden vectors written to", HERE)
 
 

@@ -382,3 +382,25 @@ def test_backward_marks_equals_backward_and_orders_a_consumer_stream():
     for k, lo in enumerate((3, 0)):
         start = net._offsets[lo][0]
         np.testing.assert_allclose(snap[k].cpu().numpy(), ref[start:].cpu().numpy(), rtol=1e-4, atol=atol)
+
+
+def test_c1_detect_on_reference_test_image(golden_dir):
+    """BASELINE.json configs[0]: pascal_detect_darknet.py on the reference's tests/testImg1.jpg (plumbing with
+    random weights): core with moving statistics, head with batch statistics, grid [1,7,7,30] and the decode,
+    against the oracle on the same preprocessed input."""
+    from oracle import loss_ref as L
+    from tensorflow_yolo2_amd import engine as E
+    g = np.load(os.path.join(golden_dir, "testImg1_input224.npz"))
+    x = g["image"][None]
+    spec = list(E.CORE_SPEC) + E.det_head_spec(30)
+    params = R.init_params(spec, seed=0)
+    net = E.Network(spec, 1, 224, 224, dtype="f32", core_layers=18, training=False)
+    net.load_params(params)
+    grid = net.forward(dev(x), False, True)                 # pascal_detect_darknet.py:41-42
+    ref, _, _ = R.run_stack(x, params, spec, [False] * 18 + [True] * 4, np.float64)
+    assert tuple(grid.shape) == (1, 7, 7, 30)
+    assert relerr(grid.cpu().numpy(), ref) < 1e-3
+    got = E.decode_detections(grid[0], 7, 2, 20, 352, 240, 0.5)
+    exp = L.decode_detections(grid[0].cpu().numpy(), 352, 240, 20, 7, 2, None, 0.5)
+    assert [d[:5] + d[6:] for d in got] == [e[:5] + e[6:] for e in exp]      # same boxes, bit-exact integers
+    np.testing.assert_array_equal([d[5] for d in got], [np.float32(e[5]) for e in exp])

@@ -109,3 +109,19 @@ def test_multi_scale_schedule_is_deterministic_and_in_range():
     assert len(set(sizes)) >= 5
     assert sizes == [multi_scale_size(s, seed=5) for s in range(200)]
     assert sizes != [multi_scale_size(s, seed=6) for s in range(200)]
+
+
+def test_c1_image_preprocessing_matches_golden(golden_dir):
+    """BASELINE.json configs[0] input: the reference's tests/testImg1.jpg (352x240) -> BGR, cv2-compatible
+    bilinear resize to 224x224, x/255*2-1 (pascal_detect_darknet.py:31-36).  The product's image_read must
+    reproduce the oracle's restatement bit for bit (JPEG-decoder / cv2 bit equality itself is unpinned)."""
+    from PIL import Image
+    from tensorflow_yolo2_amd.img_dataset import pascal_voc
+    g = np.load(os.path.join(golden_dir, "testImg1_input224.npz"))
+    rgb = np.array(Image.open(os.path.join(golden_dir, "testImg1.jpg")).convert("RGB"), dtype=np.uint8)
+    assert tuple(rgb.shape) == tuple(g["shape"]) == (240, 352, 3)
+    img = pascal_voc.image_read(rgb[:, :, ::-1], 224)
+    assert img.shape == (224, 224, 3) and img.dtype == np.float32
+    np.testing.assert_array_equal(img, g["image"])
+    assert -1.0 <= img.min() and img.max() <= 1.0
+    np.testing.assert_array_equal(D.normalise(D.resize_bilinear_u8(rgb[:, :, ::-1], 224, 224)), g["image"])
