@@ -327,3 +327,36 @@ def test_first_layer_paths_odd_and_wide(shape, dtype):
         for k in ("W", "gamma", "beta"):
             e = l2err(grads[l][k], rgrads[l][k])
             assert e < tol, (l, k, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_conv2d_random_shapes_forward_and_backward(dtype):
+    """Seeded sweep over shapes that cross every kernel-policy boundary (rows <= 26 / 52 / 104 / wider, narrow and
+    wide cout tiles, 16- and 32-row MFMA fragment packs, ring and windowed weight gradients, 1x1): forward, dx and
+    dW of the single-op entry points against torch's CPU convolution."""
+    import torch.nn.functional as F
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(2024)
+    cases = [(2, 13, 13, 512, 1024, 3), (3, 26, 26, 256, 128, 3), (1, 52, 52, 128, 64, 3), (1, 104, 104, 64, 128, 3),
+             (1, 104, 60, 128, 64, 3), (1, 40, 208, 32, 64, 3), (1, 30, 208, 64, 32, 3), (2, 19, 19, 160, 96, 3),
+             (4, 7, 7, 1024, 512, 1), (2, 27, 25, 96, 160, 1), (8, 13, 13, 1024, 1024, 3), (1, 5, 37, 32, 32, 3)]
+    for _ in range(6):
+        cases.append((int(rng.integers(1, 4)), int(rng.integers(3, 60)), int(rng.integers(3, 120)),
+                      int(rng.choice([32, 64, 96, 128, 256])), int(rng.choice([30, 32, 64, 128, 200, 256])),
+                      int(rng.choice([1, 3]))))
+    tol = {"f32": (2e-5, 2e-5), "f16": (5e-3, 1e-2)}[dtype]
+    for (n, h, w, ci, co, k) in cases:
+        x = rng.standard_normal((n, h, w, ci)).astype(np.float32)
+        wt = (rng.standard_normal((k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
+        dy = rng.standard_normal((n, h, w, co)).astype(np.float32)
+        xt = torch.as_tensor(x).permute(0, 3, 1, 2).requires_grad_(True)
+        wtt = torch.as_tensor(wt).permute(3, 2, 0, 1).requires_grad_(True)
+        ref = F.conv2d(xt, wtt, padding=k // 2)
+        ref.backward(torch.as_tensor(dy).permute(0, 3, 1, 2))
+        y = E.conv2d(dev(x), dev(wt), None, dtype=dtype).cpu().numpy()
+        dx, dw = E.conv2d_backward(dev(x), dev(wt), dev(dy), dtype=dtype)
+        e_y = l2err(y, ref.detach().permute(0, 2, 3, 1).numpy())
+        e_dx = l2err(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
+        e_dw = l2err(dw.cpu().numpy(), wtt.grad.permute(2, 3, 1, 0).numpy())
+        assert e_y < tol[0] and e_dx < tol[1] and e_dw < tol[1], ((n, h, w, ci, co, k), e_y, e_dx, e_dw)
