@@ -119,6 +119,10 @@ int y2_softmax_cross_entropy(const float* logits, const int* labels, int batch, 
 
 /* ---- YOLOv2 pieces named by the north star that the reference does NOT contain (SURVEY §8 a-x1, a-x2):
  *      no reference interface to cite; specification = oracle/ext_ref.py of this repo. ------------- */
+/* standalone tf.nn.max_pool(2, 2, 'SAME') on fp32 NHWC (reference darknet.py:24-25) and its gradient (first
+ * maximum in row-major window order); the executor pools inside its BN pass, composed graphs use this op */
+int y2_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int y2_maxpool2x2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
 /* reorg / space-to-depth: forward x [N,H,W,C] -> y [N,H/s,W/s,s*s*C], channel ((h%s)*s + w%s)*C + c;
  * forward = 0: the inverse permutation (x coarse -> y [N,H,W,C]), i.e. the gradient.  Bit-exact copies. */
 int y2_reorg(const float* x, float* y, int N, int H, int W, int C, int stride, int forward, void* stream);

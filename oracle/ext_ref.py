@@ -59,7 +59,13 @@ def decode_anchors(net, anchors):
 
 
 def nms_iou(a, b):
-    """a, b: (cx, cy, w, h) float32; the operation order the kernel follows"""
+    """a, b: (cx, cy, w, h) float32; the operation order the kernel follows (inf / nan from absurd boxes
+    propagate exactly as IEEE float32 does on the device)"""
+    with np.errstate(all="ignore"):
+        return _nms_iou(a, b)
+
+
+def _nms_iou(a, b):
     ax1, ax2 = a[0] - a[2] * f32(0.5), a[0] + a[2] * f32(0.5)
     ay1, ay2 = a[1] - a[3] * f32(0.5), a[1] + a[3] * f32(0.5)
     bx1, bx2 = b[0] - b[2] * f32(0.5), b[0] + b[2] * f32(0.5)

@@ -51,6 +51,8 @@ SIGNATURES = {
     "y2_get_iou": (_i, [_vp, _vp, _vp, _i, _vp]),
     "y2_decode_detections": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "y2_softmax_cross_entropy": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "y2_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "y2_maxpool2x2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_reorg": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "y2_passthrough_concat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_passthrough_concat_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

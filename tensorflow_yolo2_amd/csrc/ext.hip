@@ -208,7 +208,68 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ box
     for (int i = s_cnt + tid; i < max_out; i += 1024) keep[(size_t)n * max_out + i] = -1;
 }
 
+// ---------------------------------------------------------------------------
+// standalone 2x2/2 SAME max pool on fp32 NHWC (tf.nn.max_pool, reference darknet.py:24-25) and its gradient
+// (first maximum in row-major window order, like MaxPoolGrad and like the fused pooling of bn.hip).  The
+// network executor pools inside its BN pass; this op exists for composed graphs (the YOLOv2 passthrough
+// needs the UN-pooled 26x26 activation as well as the pooled one).
+// ---------------------------------------------------------------------------
+__global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ dy,
+                               float* __restrict__ dx, int N, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t total = (size_t)N * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t p = i / C;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float best = -INFINITY;
+        int arg = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int h = 2 * ho + (d >> 1), w = 2 * wo + (d & 1);
+            if (h < H && w < W) {
+                const float v = x[(((size_t)n * H + h) * W + w) * C + c];
+                if (v > best) { best = v; arg = d; }
+            }
+        }
+        if (y) y[i] = best;
+        if (dx) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int h = 2 * ho + (d >> 1), w = 2 * wo + (d & 1);
+                if (h < H && w < W) dx[(((size_t)n * H + h) * W + w) * C + c] = (d == arg) ? dy[i] : 0.f;
+            }
+        }
+    }
+}
+
 extern "C" {
+
+int y2_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if (!x || !y) return fail(Y2_ERR_ARG, "null tensor");
+    const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    size_t nb = (total + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, y, nullptr, nullptr, N, H,
+                       W, C);
+    EXTCHK(hipGetLastError());
+    return Y2_OK;
+}
+
+int y2_maxpool2x2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
+    if (!x || !dy || !dx) return fail(Y2_ERR_ARG, "null tensor");
+    const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    size_t nb = (total + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, nullptr, dy, dx, N, H,
+                       W, C);
+    EXTCHK(hipGetLastError());
+    return Y2_OK;
+}
 
 int y2_reorg(const float* x, float* y, int N, int H, int W, int C, int stride, int forward, void* stream) {
     if (!x || !y) return fail(Y2_ERR_ARG, "null tensor");

@@ -306,6 +306,25 @@ def decode_detections(predict, S, B, num_class, im_w, im_h, object_thresh=0.5):
 
 
 # ---- YOLOv2 pieces beyond the reference (SURVEY §8 a-x1/a-x2; specification: oracle/ext_ref.py) ----------
+def max_pool_2x2(x):
+    """tf.nn.max_pool(x, 2, 2, 'SAME') on [N,H,W,C] fp32 (darknet.py:24-25)"""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=torch.float32, device=x.device)
+    check(lib.y2_maxpool2x2(_ptr(x), _ptr(y), n, h, w, c, _stream()))
+    return y
+
+
+def max_pool_2x2_backward(x, dy):
+    lib = _lib.load()
+    n, h, w, c = x.shape
+    assert x.is_contiguous() and dy.is_contiguous() and tuple(dy.shape) == (n, (h + 1) // 2, (w + 1) // 2, c)
+    dx = torch.empty_like(x)
+    check(lib.y2_maxpool2x2_backward(_ptr(x), _ptr(dy), _ptr(dx), n, h, w, c, _stream()))
+    return dx
+
+
 def reorg(x, stride=2, inverse=False):
     """space-to-depth [N,H,W,C] -> [N,H/s,W/s,s*s*C]; inverse=True: the gradient (depth-to-space)"""
     lib = _lib.load()

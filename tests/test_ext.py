@@ -158,3 +158,50 @@ def test_gpu_nms_golden(golden_dir):
     np.testing.assert_array_equal(keep[0, :int(count[0])].cpu().numpy(), g["keep_agnostic"])
     keep, count = E.nms(b, s, c, 0.45, 0.1, 50, True)
     np.testing.assert_array_equal(keep[0, :int(count[0])].cpu().numpy(), g["keep_class_aware"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 8, 12, 6), (1, 7, 9, 5), (3, 26, 26, 64)])
+def test_gpu_maxpool_forward_backward(shape):
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(sum(shape))
+    x = np.round(rng.standard_normal(shape), 1).astype(np.float32)        # rounded: ties inside windows
+    y = E.max_pool_2x2(dev(x))
+    np.testing.assert_array_equal(y.cpu().numpy(), R.max_pool_2x2(x))
+    dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    dx = E.max_pool_2x2_backward(dev(x), dev(dy))
+    np.testing.assert_array_equal(dx.cpu().numpy(), R.max_pool_2x2_backward(x, dy))
+
+
+@pytest.mark.gpu
+def test_gpu_yolov2_composed_detector_matches_composed_oracle():
+    """The north star's model (passthrough + anchors + NMS), composed from three conv-BN-leaky stacks and the
+    ext ops, against the same composition of the oracle's pieces (fp32, inference-mode BN, 160x160 input)."""
+    import torch
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd.yolo2_nets import yolov2
+    n, size = 2, 160
+    det = yolov2.YOLOv2Detector(n, size, dtype="f32", seed=4)
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, (n, size, size, 3)).astype(np.float32)
+    grid = det.forward(dev(x))
+    sa, sb, sc = yolov2.yolov2_specs(20, 5)
+    pa, pb, pc = det.stem.export_params(), det.deep.export_params(), det.head.export_params()
+    fine, _, _ = R.run_stack(x, pa, sa, False, np.float64)
+    coarse, _, _ = R.run_stack(R.max_pool_2x2(fine), pb, sb, False, np.float64)
+    ref, _, _ = R.run_stack(X.passthrough_concat(fine, coarse), pc, sc, False, np.float64)
+    ref = ref.reshape(n, 5, 5, 5, 25)
+    assert tuple(grid.shape) == (n, 5, 5, 5, 25)
+    assert np.abs(grid.cpu().numpy() - ref).max() < 1e-3 * np.abs(ref).max()
+    boxes, best, cls, keep, count = det.detect(dev(x), score_thresh=0.02, iou_thresh=0.45, max_out=50)
+    torch.cuda.synchronize()
+    g = grid.cpu().numpy()
+    rb, rs = X.decode_anchors(g, det.anchors)
+    np.testing.assert_allclose(boxes.cpu().numpy(), rb, rtol=1e-5, atol=1e-7)
+    # NMS on the device's own scores: index work, bit-exact against the specification
+    b, s, c = boxes.cpu().numpy(), best.cpu().numpy(), cls.cpu().numpy()
+    for i in range(n):
+        refk = X.nms(b[i], s[i], c[i], 0.45, 0.02, 50, True)
+        assert int(count[i]) == len(refk) > 0
+        np.testing.assert_array_equal(keep[i, :len(refk)].cpu().numpy(), np.array(refk, np.int32))
