@@ -36,7 +36,13 @@ def passthrough_concat_backward(dout, cf):
 
 
 def decode_anchors(net, anchors):
-    """net [N,S,S,B,5+C] -> boxes [N,S*S*B,4] (cx,cy,w,h relative to the image), scores [N,S*S*B,C]"""
+    """net [N,S,S,B,5+C] -> boxes [N,S*S*B,4] (cx,cy,w,h relative to the image), scores [N,S*S*B,C]
+    (exp overflow of an untrained net's tw/th gives inf, as on the device)"""
+    with np.errstate(over="ignore", invalid="ignore"):
+        return _decode_anchors(net, anchors)
+
+
+def _decode_anchors(net, anchors):
     net = np.asarray(net, f32)
     n, s, _, b, d = net.shape
     c = d - 5
