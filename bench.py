@@ -49,6 +49,45 @@ def usable_cores():
     return n
 
 
+def core_counts():
+    """(physical cores, logical CPUs) of the host, from /proc/cpuinfo"""
+    logical = os.cpu_count() or 1
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+        if pid is not None and cid is not None:
+            phys.add((pid, cid))
+    except OSError:
+        pass
+    return (len(phys) or logical), logical
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves, as a CHILD process tree,
+    before this process has touched the GPU (no HIP call yet; never exec from a GPU-initialised process),
+    and leave with its exit code.  Rank 0 of the children prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(args, spec_core, spec_head):
     """oracle (torch-CPU restatement) timed on the host cores: bounded sample of the same workload."""
     import numpy as np
@@ -72,9 +111,31 @@ def cpu_baseline(args, spec_core, spec_head):
         step(x, lab)
         times.append(time.time() - t0)
     med = sorted(times)[len(times) // 2]
-    return {"value": bs / med, "unit": "images/s", "cores": cores, "kind": "port",
+    phys, logical = core_counts()
+    return {"value": bs / med, "unit": "images/s", "cores": cores, "physical_cores": phys, "logical_cpus": logical,
+            "kind": "port",
             "sample": "oracle/torch_ref.py (PyTorch-CPU fp32 restatement, not TF1): detector fwd+loss+bwd, "
-                      "%dx%d, batch %d, median of %d steps" % (size, size, bs, len(times))}
+                      "%dx%d, batch %d, median of %d steps, %d threads" % (size, size, bs, len(times), cores)}
+
+
+def f32_mode(args, images, labels, device, total_flops):
+    """the parity-grade arithmetic (exact-f32 MFMA, the mode the 1e-3 tests gate) timed on the same
+    workload: a short run, reported beside the headline number"""
+    import torch
+    from tensorflow_yolo2_amd.trainer import DetectorTrainer
+    tr = DetectorTrainer(args.batch, args.image_size, dtype="f32", device=device, seed=0)
+    for _ in range(1):
+        tr.step(images, labels)
+    torch.cuda.synchronize()
+    n = max(1, args.f32_steps)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tr.step(images, labels)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    tf = total_flops / (ms * 1e-3) / 1e12
+    return {"dtype": "f32", "ms_per_step": ms, "images_per_s": args.batch / (ms * 1e-3), "steps": n,
+            "whole_step_tflops": tf, "peak": MFMA_PEAK_TFLOPS["f32"], "whole_step_frac": tf / MFMA_PEAK_TFLOPS["f32"]}
 
 
 def main():
@@ -88,12 +149,17 @@ def main():
     ap.add_argument("--kernel-events", default="timed", choices=["timed", "separate", "off"])
     ap.add_argument("--event-stride", type=int, default=4, help="bracket the MFMA launches of every n-th timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-batch", type=int, default=8)     # bs 8
+    ap.add_argument("--cpu-seconds", type=float, default=25.0)
+    ap.add_argument("--no-f32-mode", action="store_true")
+    ap.add_argument("--f32-steps", type=int, default=3)
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: core forward only (inference BN)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU functional test)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="functional test of the N>1 path on one GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import numpy as np
     import torch
@@ -232,6 +298,9 @@ def main():
         if roof.get("avg_launch_ms"):
             roof["flops_per_launch"] = igemm_flops / max(roof.get("launches_per_step", 1), 1)
         total_flops = sum(per) * flop_mult
+        # SURVEY 8(d)'s own definition (and the north star's 40 % target): ALL algorithmic FLOPs of the step
+        # over the wall time of the whole step, against the dense peak
+        roof["whole_step_frac"] = total_flops / (ms_per_step * 1e-3) / 1e12 / roof["peak"]
         out = {
             "metric": "images/sec fwd+bwd Darknet-19 416x416" if not args.forward_only
                       else "images/sec forward Darknet-19 core 416x416",
@@ -241,12 +310,19 @@ def main():
             "config": {"workload": ("YOLO detector train step: darknet19_core + darknet19_detection(30) + get_loss "
                                     "+ backward + Adam" if not args.forward_only else "darknet19_core forward"),
                        "image_size": size, "batch_per_gpu": bs, "global_batch": bs * world, "S": S, "B": 2,
-                       "parallelism": "dp%d" % world, "grad_allreduce": "rccl sum, 3 overlapped slices"
-                       if world > 1 else "none"},
+                       "parallelism": "dp%d" % world, "grad_allreduce": (tr.reducer.describe() if world > 1 and not args.forward_only
+                                                                            else "none")},
             "whole_step_tflops": total_flops / (ms_per_step * 1e-3) / 1e12 * 1.0,
             "roofline": roof,
             "kernels": kernels,
         }
+        if world == 1 and not args.forward_only and not args.no_f32_mode and args.dtype != "f32":
+            try:
+                del tr, net, run
+                torch.cuda.empty_cache()
+                out["f32_mode"] = f32_mode(args, images, labels, device, total_flops)
+            except Exception as e:
+                out["f32_mode"] = {"dtype": "f32", "ms_per_step": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, spec_core, spec_head)

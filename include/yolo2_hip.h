@@ -22,6 +22,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the declarations below are exported */
+#pragma GCC visibility push(default)
 
 typedef struct y2_ctx y2_ctx;
 
@@ -75,8 +77,13 @@ int y2_params_changed(y2_ctx* ctx);
 
 /* darknet19_core / darknet19_detection / darknet19 forward
  * (darknet.py:61-201): images [N,H,W,3] fp32 -> out (shape: y2_output_shape) */
-int y2_forward(y2_ctx* ctx, const float* images, int is_training_core, int is_training_head, float* out,
-               void* stream);
+/* update_moving: apply the momentum-0.99 moving-statistics update of the training-mode layers inside this
+ * forward (the train step); 0 = leave them alone, as a TF run that does not fetch train_op / UPDATE_OPS does
+ * (pascal_detect_darknet.py:61: the head's default is_training=True normalises with batch statistics at
+ * detect time, but nothing updates).  y2_update_moving_stats applies the skipped update afterwards, once. */
+int y2_forward(y2_ctx* ctx, const float* images, int is_training_core, int is_training_head, int update_moving,
+               float* out, void* stream);
+int y2_update_moving_stats(y2_ctx* ctx, void* stream);
 /* TF autodiff of the stack (tf.train.*Optimizer().minimize, pascal_train_darknet.py:49-51):
  * dout has the output's shape; gradients are written to the bound `grads` buffer
  * for layers [layer_lo, layer_hi) walking downwards; call with (0, num_layers)
@@ -102,6 +109,8 @@ int y2_profile_collect(y2_ctx* ctx, double* ms_by_category, int* launches_by_cat
  * (weight gradients run on a side stream beside the dgrads: summing durations would count shared time twice).
  * Call before y2_profile_collect (which resets). */
 int y2_profile_busy(y2_ctx* ctx, int cat_mask, double* busy_ms, int* launches);
+/* ms[num_layers][8]: the same records per layer and category (does not reset) */
+int y2_profile_layers(y2_ctx* ctx, double* ms);
 
 /* ---- get_loss / get_iou / show_yolo_detection (src/yolo2_nets/net_utils.py:222-439) */
 size_t y2_yolo_loss_workspace_bytes(int batch, int S);
@@ -116,6 +125,10 @@ int y2_decode_detections(const float* predict, int S, int B, int num_class, int 
 /* sparse_softmax_cross_entropy_with_logits + reduce_mean (imagenet_train_darknet.py:51-53) */
 int y2_softmax_cross_entropy(const float* logits, const int* labels, int batch, int classes, float* loss,
                              float* dlogits, void* stream);
+
+/* accuracy = reduce_mean(cast(equal(argmax(logits, 1), labels))) (imagenet_train_darknet.py:60-61; ties: the
+ * smallest index, as tf.argmax) */
+int y2_accuracy(const float* logits, const int* labels, int batch, int classes, float* accuracy, void* stream);
 
 /* ---- YOLOv2 pieces named by the north star that the reference does NOT contain (SURVEY §8 a-x1, a-x2):
  *      no reference interface to cite; specification = oracle/ext_ref.py of this repo. ------------- */
@@ -146,6 +159,15 @@ int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n
                  float beta1, float beta2, float eps, float grad_mult, void* stream);
 int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, float lr, float momentum,
                      float grad_mult, void* stream);
+/* The same updates guarded against half-precision gradient overflow (dynamic loss scaling; the fp32
+ * reference cannot overflow): ctrl = 8 zero-initialised 32-bit device words {found_inf, step, skipped,
+ * ticket, lr_t, ...}.  If `grads` holds any inf / NaN the step is skipped as a whole (params, slots and the
+ * device-side step counter untouched, ctrl.found_inf = 1); otherwise ctrl.step advances and Adam's lr_t is
+ * computed on the device for it.  No host synchronisation. */
+int y2_adam_step_guarded(float* params, float* m, float* v, const float* grads, size_t n, void* ctrl, float lr,
+                         float beta1, float beta2, float eps, float grad_mult, void* stream);
+int y2_momentum_step_guarded(float* params, float* accum, const float* grads, size_t n, void* ctrl, float lr,
+                             float momentum, float grad_mult, void* stream);
 
 /* ---- single-op entry points (tf.nn.conv2d 'SAME' stride 1, darknet.py:20-21) used by the
  *      per-op parity tests; channel counts are padded internally to the kernels' granularity */
@@ -155,6 +177,7 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
 int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int N, int H,
                        int W, int Cin, int Cout, int k, int dtype, void* workspace, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

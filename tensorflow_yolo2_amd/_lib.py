@@ -9,6 +9,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo2_hip.so")
+# development tools (scripts/bench_*.py) opt into the `make dev` library, which adds the kernel variant tables
+if os.environ.get("Y2_DEV_LIB") == "1":
+    LIB_PATH = os.path.join(_HERE, "libyolo2_hip_dev.so")
 
 Y2_F32, Y2_F16, Y2_BF16 = 0, 1, 2
 Y2_TAIL_NONE, Y2_TAIL_AVGPOOL = 0, 1
@@ -38,7 +41,8 @@ SIGNATURES = {
     "y2_set_options": (_i, [_vp, _f, _i]),
     "y2_init_params": (_i, [_vp, _u64, _vp]),
     "y2_params_changed": (_i, [_vp]),
-    "y2_forward": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "y2_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "y2_update_moving_stats": (_i, [_vp, _vp]),
     "y2_backward": (_i, [_vp, _vp, _i, _i, _vp]),
     "y2_backward_marks": (_i, [_vp, _vp, _i, _pi, _vp]),
     "y2_wait_mark": (_i, [_vp, _i, _vp]),
@@ -46,11 +50,13 @@ SIGNATURES = {
     "y2_profile_enable": (_i, [_vp, _i]),
     "y2_profile_collect": (_i, [_vp, C.POINTER(C.c_double), _pi, _i]),
     "y2_profile_busy": (_i, [_vp, _i, _vp, _vp]),
+    "y2_profile_layers": (_i, [_vp, C.POINTER(C.c_double)]),
     "y2_yolo_loss_workspace_bytes": (_sz, [_i, _i]),
     "y2_yolo_loss": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "y2_get_iou": (_i, [_vp, _vp, _vp, _i, _vp]),
     "y2_decode_detections": (_i, [_vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "y2_softmax_cross_entropy": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "y2_accuracy": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "y2_maxpool2x2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_maxpool2x2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_reorg": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -60,6 +66,8 @@ SIGNATURES = {
     "y2_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp]),
     "y2_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
+    "y2_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _vp]),
+    "y2_momentum_step_guarded": (_i, [_vp, _vp, _vp, _sz, _vp, _f, _f, _f, _vp]),
     "y2_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "y2_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "y2_conv2d_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

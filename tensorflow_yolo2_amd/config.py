@@ -20,3 +20,11 @@ def yolo_grid_offset(S=S, B=B):
 
 
 YOLO_GRID_OFFSET = yolo_grid_offset(S, B)
+
+
+def get_ckpts_dir(network_name, imdb_name, root="ckpts"):
+    """config.py:80-90: <root>/<network_name>/<imdb_name>, created on demand"""
+    import os
+    path = os.path.abspath(os.path.join(root, network_name, imdb_name))
+    os.makedirs(path, exist_ok=True)
+    return path

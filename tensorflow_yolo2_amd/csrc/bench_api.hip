@@ -22,7 +22,7 @@ static hipError_t run_variant(int variant, const ConvArgs& a, hipStream_t s, int
 }
 using namespace y2;
 
-extern "C" int y2dev_bench_wgrad(int N, int H, int W, int Cin, int Cout, int k, int variant, int splitk, int iters,
+extern "C" __attribute__((visibility("default"))) int y2dev_bench_wgrad(int N, int H, int W, int Cin, int Cout, int k, int variant, int splitk, int iters,
                                  float* ms_out) {
     const size_t sz = 2;
     const size_t pix = (size_t)N * (H + 1) * (W + 1) + 4 * (W + 3) + 2048;
@@ -59,7 +59,7 @@ extern "C" int y2dev_bench_wgrad(int N, int H, int W, int Cin, int Cout, int k, 
     return 0;
 }
 
-extern "C" int y2dev_bench_conv(int N, int H, int W, int Cin, int Cout, int k, int variant, int iters, float* ms_out) {
+extern "C" __attribute__((visibility("default"))) int y2dev_bench_conv(int N, int H, int W, int Cin, int Cout, int k, int variant, int iters, float* ms_out) {
     const size_t sz = 2;
     const size_t xpix = (size_t)N * (H + 1) * (W + 1) + 4 * (W + 3) + 2048;
     const int taps = k * k;

@@ -85,9 +85,10 @@ __global__ __launch_bounds__(SLN * kFinCh) void bn_finalize_kernel(BnFinalizeArg
         a.shift[c] = a.beta[c] - meanf * sc;
         a.mean[c] = meanf;
         a.invstd[c] = inv;
+        float vu = var;
+        if (a.bessel && ntot > 1.0) vu = (float)(mt / (ntot - 1.0));
+        if (a.var) a.var[c] = vu;
         if (a.update_moving) {
-            float vu = var;
-            if (a.bessel && ntot > 1.0) vu = (float)(mt / (ntot - 1.0));
             const float dec = 1.0f - a.momentum;
             a.moving_mean[c] -= (a.moving_mean[c] - meanf) * dec;
             a.moving_var[c] -= (a.moving_var[c] - vu) * dec;
@@ -99,6 +100,20 @@ hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
     // short partial lists (the 13x13 / 26x26 layers: a few dozen records) finish sooner in 4-wave blocks
     if (a.P <= 512) hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((a.C + kFinCh - 1) / kFinCh), dim3(32 * kFinCh), 0, s, a);
     else hipLaunchKernelGGL(bn_finalize_kernel<128>, dim3((a.C + kFinCh - 1) / kFinCh), dim3(128 * kFinCh), 0, s, a);
+    return hipGetLastError();
+}
+
+// deferred form of the update above (y2_update_moving_stats): same expressions on the saved batch statistics
+__global__ void bn_update_moving_kernel(const float* mean, const float* var, float* mm, float* mv, int C, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float dec = 1.0f - momentum;
+    mm[c] -= (mm[c] - mean[c]) * dec;
+    mv[c] -= (mv[c] - var[c]) * dec;
+}
+hipError_t launch_bn_update_moving(const float* mean, const float* var, float* mm, float* mv, int C, float momentum,
+                                   hipStream_t s) {
+    hipLaunchKernelGGL(bn_update_moving_kernel, dim3((C + 255) / 256), dim3(256), 0, s, mean, var, mm, mv, C, momentum);
     return hipGetLastError();
 }
 

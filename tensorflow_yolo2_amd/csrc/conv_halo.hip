@@ -312,8 +312,9 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* bp
     return hipErrorInvalidValue;
 }
 
+#ifdef Y2_DEV
 hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp);
-// development aid: Y2DEV_CONV="W:Cout:variant,..." forces a halo variant for (W, Cout) (f16 only)
+// development library only (make dev): Y2DEV_CONV="W:Cout:variant,..." forces a halo variant for (W, Cout), f16
 static int dev_rule(int W, int Cout) {
     static int n = -1;
     static int rules[32][3];
@@ -332,6 +333,7 @@ static int dev_rule(int W, int Cout) {
         if (rules[i][0] == W && rules[i][1] == Cout) return rules[i][2];
     return -1;
 }
+#endif
 
 // filter fragments straight to registers (conv_haloq.hip) -- the filter pack must match (pack.hip,
 // PackLayer::wf_frag / wd_frag).
@@ -356,15 +358,18 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M) {
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels) {
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
-    const int forced = (a.taps == 9 && dtype == 1) ? dev_rule(a.W, a.Cout) : -1;
     if (conv_filter_layout(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M)) e = launch_conv_haloq(dtype, a, s, &bp);
-    else if (forced >= 0) e = launch_conv_halo_variant(forced, a, s, &bp);
+#ifdef Y2_DEV
+    else if (a.taps == 9 && dtype == 1 && dev_rule(a.W, a.Cout) >= 0)
+        e = launch_conv_halo_variant(dev_rule(a.W, a.Cout), a, s, &bp);
+#endif
     else if (a.taps == 9 && a.W <= 52) e = launch_conv_halo(dtype, a, s, &bp);
     else e = launch_conv_igemm(dtype, a, s);
     if (block_pixels) *block_pixels = bp;
     return e;
 }
 
+#ifdef Y2_DEV
 // development variants (f16) for scripts/bench_conv.py
 #define HV(id, WP, TPARGS...) \
     case id: if (bp) *bp = halo_bp<WP, TPARGS>(); return halo_pick<T, WP, TPARGS>(a, s);
@@ -444,5 +449,6 @@ hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t 
     }
     return hipErrorInvalidValue;
 }
+#endif  // Y2_DEV
 
 }  // namespace y2

@@ -402,6 +402,7 @@ hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* b
     return hipErrorInvalidValue;
 }
 
+#ifdef Y2_DEV
 // development variants (f16) for scripts/bench_conv.py (timing only: the bench does not care about the
 // filter layout)
 hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp) {
@@ -435,5 +436,6 @@ hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t
 #undef HQ
     return hipErrorInvalidValue;
 }
+#endif  // Y2_DEV
 
 }  // namespace y2

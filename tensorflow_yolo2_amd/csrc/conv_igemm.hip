@@ -256,8 +256,9 @@ hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
 
 }  // namespace y2
 
+#ifdef Y2_DEV
 // ---------------------------------------------------------------------------
-// development aid: explicit tile / pipeline variants (f16 only) for A/B timing
+// development library only: explicit tile / pipeline variants (f16 only) for A/B timing
 // ---------------------------------------------------------------------------
 namespace y2 {
 hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc) {
@@ -303,3 +304,4 @@ hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t
     return hipErrorInvalidValue;
 }
 }  // namespace y2
+#endif  // Y2_DEV

@@ -149,6 +149,7 @@ struct BnFinalizeArgs {
     float* shift;         // out: beta - mean * scale
     float* mean;          // out (saved for backward)
     float* invstd;        // out
+    float* var;           // out: biased (or Bessel) batch variance as the moving update uses it
     float eps, momentum;
     int update_moving;
     int bessel;
@@ -156,6 +157,8 @@ struct BnFinalizeArgs {
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 hipError_t launch_bn_infer_prepare(const float* gamma, const float* beta, const float* mm, const float* mv,
                                    float* scale, float* shift, float* mean, float* invstd, int C, float eps,
+                                   hipStream_t s);
+hipError_t launch_bn_update_moving(const float* mean, const float* var, float* mm, float* mv, int C, float momentum,
                                    hipStream_t s);
 struct BnActArgs {
     const void* y;        // [M][ldy]
@@ -215,11 +218,20 @@ hipError_t launch_avgpool_bwd(const float* dout, float* dh, int N, int H, int W,
 hipError_t launch_softmax_ce(const float* logits, const int* labels, float* loss, float* dlogits, int N, int C,
                              hipStream_t s);
 
+hipError_t launch_accuracy(const float* logits, const int* labels, float* acc, int N, int C, hipStream_t s);
+
 // ---- optimizers (flat buffers)
 hipError_t launch_adam(float* p, float* m, float* v, const float* g, size_t n, float lr_t, float b1, float b2,
                        float eps, float gscale, hipStream_t s);
 hipError_t launch_momentum(float* p, float* acc, const float* g, size_t n, float lr, float mom, float gscale,
                            hipStream_t s);
+// dynamic loss scaling: ctrl = {int found_inf, int step, int skipped, float lr_t}
+hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, float* scratch, float lr, float b1, float b2,
+                             hipStream_t s);
+hipError_t launch_adam_guarded(float* p, float* m, float* v, const float* g, size_t n, const void* ctrl, float b1,
+                               float b2, float eps, float gscale, hipStream_t s);
+hipError_t launch_momentum_guarded(float* p, float* acc, const float* g, size_t n, const void* ctrl, float lr, float mom,
+                                   float gscale, hipStream_t s);
 hipError_t launch_init_trunc_normal(float* p, size_t n, float stddev, uint64_t seed, uint64_t stream_id,
                                     hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);

@@ -306,4 +306,34 @@ hipError_t launch_softmax_ce(const float* logits, const int* labels, float* loss
     return hipGetLastError();
 }
 
+// accuracy = mean(argmax(logits, 1) == labels) (imagenet_train_darknet.py:60-61); tf.argmax returns the
+// smallest index among equal maxima.  One wave per row, one block for the batch: exact integer count.
+__global__ __launch_bounds__(256) void accuracy_kernel(const float* logits, const int* labels, float* acc, int N, int C) {
+    __shared__ int hits[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int mine = 0;
+    for (int n = wave; n < N; n += 4) {
+        const float* z = logits + (size_t)n * C;
+        float best = -INFINITY;
+        int arg = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = z[c];
+            if (v > best || (v == best && c < arg)) { best = v; arg = c; }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64);
+            const int oa = __shfl_xor(arg, off, 64);
+            if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+        }
+        mine += (arg == labels[n]) ? 1 : 0;
+    }
+    if (lane == 0) hits[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) *acc = (float)(hits[0] + hits[1] + hits[2] + hits[3]) / (float)N;
+}
+hipError_t launch_accuracy(const float* logits, const int* labels, float* acc, int N, int C, hipStream_t s) {
+    hipLaunchKernelGGL(accuracy_kernel, dim3(1), dim3(256), 0, s, logits, labels, acc, N, C);
+    return hipGetLastError();
+}
+
 }  // namespace y2

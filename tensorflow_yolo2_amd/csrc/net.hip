@@ -91,6 +91,7 @@ struct y2_ctx {
     int bound_training = 0;
     bool weights_dirty = true;
     bool fwd_saved = false;
+    bool moving_pending = false;   // last forward ran with update_moving = 0
     std::vector<int> fwd_training;  // per layer BN mode of the last forward
     // shared scratch offsets
     size_t o_part_cnt, o_part_mean, o_part_m2, o_psum, o_dA0, o_dA1, o_h32, o_dh32, o_xin_last_end;
@@ -154,7 +155,7 @@ static void plan(y2_ctx* c) {
         Layer& y = c->L[l];
         y.xin = take(c->in_geom((int)l).bytes(sz));
         y.y = take((size_t)y.M * y.ldy * sz + 256);
-        y.stat = take((size_t)6 * y.ldy * sizeof(float));  // scale, shift, mean, invstd, coef[2]
+        y.stat = take((size_t)7 * y.ldy * sizeof(float));  // scale, shift, mean, invstd, coef[2], batch variance
         if (y.first3) {
             y.wf = take((size_t)32 * 3 * 16 * sz);
             y.wd = 0;
@@ -244,6 +245,11 @@ int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers
             delete c;
             return fail(Y2_ERR_ARG, "layer %d: in_chl %d does not match previous out_chl %d", l, y.cin, cprev);
         }
+        if (y.cout > (dtype == 0 ? 1024 : 2048)) {
+            delete c;
+            return fail(Y2_ERR_ARG, "layer %d: out_chl %d exceeds the batch-norm kernels' row width (%d)", l, y.cout,
+                        dtype == 0 ? 1024 : 2048);
+        }
         y.first3 = (l == 0 && y.cin == 3);
         if (y.first3 && !(y.k == 3 && y.cout == 32)) {
             delete c;
@@ -330,8 +336,8 @@ int y2_profile_collect(y2_ctx* c, double* ms, int* count, int ncat) {
     c->prof_used = 0;
     return Y2_OK;
 }
-// dev only (not in the header): per-layer, per-category milliseconds [num_layers][CAT_COUNT]; does not reset
-extern "C" int y2dev_profile_layers(y2_ctx* c, double* ms) {
+// per-layer, per-category milliseconds [num_layers][CAT_COUNT] of the records so far; does not reset
+int y2_profile_layers(y2_ctx* c, double* ms) {
     const int nl = (int)c->L.size();
     for (int i = 0; i < nl * CAT_COUNT; ++i) ms[i] = 0.0;
     for (size_t i = 0; i < c->prof_used; ++i) {
@@ -470,7 +476,8 @@ static int pack_all_weights(y2_ctx* c, hipStream_t s) {
     return Y2_OK;
 }
 
-int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, float* out, void* stream) {
+int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, int update_moving, float* out,
+               void* stream) {
     if (!c->ws) return fail(Y2_ERR_STATE, "bind buffers first");
     if (!images || !out) return fail(Y2_ERR_ARG, "null tensor");
     hipStream_t s = (hipStream_t)stream;
@@ -524,7 +531,8 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
             f.gamma = c->params + y.pg; f.beta = c->params + y.pbeta;
             f.moving_mean = c->state + y.smm; f.moving_var = c->state + y.smv;
             f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
-            f.eps = kBnEps; f.momentum = kBnMomentum; f.update_moving = 1; f.bessel = c->bessel;
+            f.var = stat + 6 * y.ldy;
+            f.eps = kBnEps; f.momentum = kBnMomentum; f.update_moving = update_moving ? 1 : 0; f.bessel = c->bessel;
             HIPCHK(launch_bn_finalize(f, s));
         } else {
             HIPCHK(launch_bn_infer_prepare(c->params + y.pg, c->params + y.pbeta, c->state + y.smm, c->state + y.smv,
@@ -559,6 +567,27 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, f
         HIPCHK(launch_avgpool_fwd((const float*)(c->ws + c->o_h32), out, c->N, y.Ho, y.Wo, y.cout, c->tail_k, s));
     }
     c->fwd_saved = true;
+    c->moving_pending = !update_moving;
+    return Y2_OK;
+}
+
+// The reference updates the moving statistics through UPDATE_OPS attached to train_op
+// (src/pascal/pascal_train_darknet.py:49-51): a forward that only evaluates the loss leaves them alone.
+// y2_forward(update_moving = 0) keeps the batch mean / variance of its training-mode layers; this applies
+// the momentum-0.99 update from them (once), for callers that decide to train after the forward.
+int y2_update_moving_stats(y2_ctx* c, void* stream) {
+    if (!c->ws) return fail(Y2_ERR_STATE, "bind buffers first");
+    if (!c->fwd_saved) return fail(Y2_ERR_STATE, "run y2_forward first");
+    if (!c->moving_pending) return Y2_OK;
+    hipStream_t s = (hipStream_t)stream;
+    for (size_t l = 0; l < c->L.size(); ++l) {
+        if (!c->fwd_training[l]) continue;
+        const Layer& y = c->L[l];
+        const float* stat = (const float*)(c->ws + y.stat);
+        HIPCHK(launch_bn_update_moving(stat + 2 * y.ldy, stat + 6 * y.ldy, c->state + y.smm, c->state + y.smv, y.cout,
+                                       kBnMomentum, s));
+    }
+    c->moving_pending = false;
     return Y2_OK;
 }
 
@@ -688,6 +717,9 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
 // stream until the end of the pass, unlike one y2_backward call per slice.
 int y2_backward_marks(y2_ctx* c, const float* dout, int n_marks, const int* mark_layers, void* stream) {
     if (n_marks < 0 || (n_marks > 0 && !mark_layers)) return fail(Y2_ERR_ARG, "bad marks");
+    for (int k = 0; k < n_marks; ++k)   // an unrecorded event would let y2_wait_mark return at once
+        if (mark_layers[k] < 0 || mark_layers[k] >= (int)c->L.size())
+            return fail(Y2_ERR_ARG, "mark %d: layer %d out of range", k, mark_layers[k]);
     while ((int)c->mark_main.size() < n_marks) {
         hipEvent_t a = nullptr, b = nullptr;
         HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -773,12 +805,35 @@ int y2_softmax_cross_entropy(const float* logits, const int* labels, int batch, 
     return Y2_OK;
 }
 
+int y2_accuracy(const float* logits, const int* labels, int batch, int classes, float* accuracy, void* stream) {
+    if (!logits || !labels || !accuracy || batch < 1 || classes < 1) return fail(Y2_ERR_ARG, "bad arguments");
+    HIPCHK(launch_accuracy(logits, labels, accuracy, batch, classes, (hipStream_t)stream));
+    return Y2_OK;
+}
+
 int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n, int step, float lr, float beta1,
                  float beta2, float eps, float grad_mult, void* stream) {
     if (!params || !m || !v || !grads || step < 1) return fail(Y2_ERR_ARG, "bad arguments");
     // TF: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
     const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
     HIPCHK(launch_adam(params, m, v, grads, n, (float)lr_t, beta1, beta2, eps, grad_mult, (hipStream_t)stream));
+    return Y2_OK;
+}
+// Loss-scale-safe forms of the two optimizers: `ctrl` = 8 caller-owned, zero-initialised 32-bit words on the
+// device {found_inf, step, skipped, ticket, lr_t, -, -, -}.  A gradient buffer with any inf / NaN leaves
+// params, slots and the step counter untouched (ctrl.found_inf = 1, ctrl.skipped += 1).
+int y2_adam_step_guarded(float* params, float* m, float* v, const float* grads, size_t n, void* ctrl, float lr,
+                         float beta1, float beta2, float eps, float grad_mult, void* stream) {
+    if (!params || !m || !v || !grads || !ctrl) return fail(Y2_ERR_ARG, "bad arguments");
+    HIPCHK(launch_grad_check(grads, n, ctrl, nullptr, lr, beta1, beta2, (hipStream_t)stream));
+    HIPCHK(launch_adam_guarded(params, m, v, grads, n, ctrl, beta1, beta2, eps, grad_mult, (hipStream_t)stream));
+    return Y2_OK;
+}
+int y2_momentum_step_guarded(float* params, float* accum, const float* grads, size_t n, void* ctrl, float lr,
+                             float momentum, float grad_mult, void* stream) {
+    if (!params || !accum || !grads || !ctrl) return fail(Y2_ERR_ARG, "bad arguments");
+    HIPCHK(launch_grad_check(grads, n, ctrl, nullptr, lr, 0.9f, 0.999f, (hipStream_t)stream));
+    HIPCHK(launch_momentum_guarded(params, accum, grads, n, ctrl, lr, momentum, grad_mult, (hipStream_t)stream));
     return Y2_OK;
 }
 int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, float lr, float momentum,

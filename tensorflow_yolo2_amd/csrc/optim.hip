@@ -61,6 +61,126 @@ hipError_t launch_momentum(float* p, float* acc, const float* g, size_t n, float
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Dynamic loss scaling for the half-precision modes (the reference runs fp32 and has no such failure
+// mode: an fp16 dY beyond 65504 becomes inf, then NaN in the weight gradient, and an unguarded update
+// would poison params, m and v for good -- and, through the SUM all-reduce, every replica).
+//   grad_check : any non-finite value in the flat gradient buffer -> ctrl.found_inf; the last block to
+//                finish also advances the device-side step counter and computes TF's lr_t for it
+//                (only finite steps count: a skipped step leaves t, m, v and params untouched)
+//   *_guarded  : the optimizer kernels above, skipped as a whole when ctrl.found_inf is set
+// No host synchronisation: the host reads ctrl one step late to adapt grad_scale.
+// ---------------------------------------------------------------------------
+struct OptCtrl { int found_inf, step, skipped, ticket; float lr_t; int pad[3]; };
+
+__global__ __launch_bounds__(256) void grad_check_kernel(const float4* g, size_t n4, const float* gt, size_t tail0,
+                                                         size_t n, OptCtrl* ctrl, float lr, float b1, float b2) {
+    // |x| < inf  <=>  exponent bits != all ones; OR the exponent tests of a whole thread, then of the block
+    unsigned bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = g[i];
+        const unsigned a = __float_as_uint(v.x), b = __float_as_uint(v.y), c = __float_as_uint(v.z), d = __float_as_uint(v.w);
+        bad |= ((a & 0x7F800000u) == 0x7F800000u) | ((b & 0x7F800000u) == 0x7F800000u) |
+               ((c & 0x7F800000u) == 0x7F800000u) | ((d & 0x7F800000u) == 0x7F800000u);
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x)
+            bad |= (__float_as_uint(gt[i]) & 0x7F800000u) == 0x7F800000u;
+    __shared__ int sbad, last;
+    if (threadIdx.x == 0) sbad = 0;
+    __syncthreads();
+    if (bad) atomicOr(&sbad, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sbad) atomicOr(&ctrl->found_inf, 1);
+        __threadfence();
+        last = (atomicAdd(&ctrl->ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const int inf = atomicOr(&ctrl->found_inf, 0);
+        if (inf) {
+            ctrl->skipped += 1;
+        } else {
+            const int t = ctrl->step + 1;
+            ctrl->step = t;
+            // TF: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+            ctrl->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+        }
+        ctrl->ticket = 0;
+    }
+}
+hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, float* scratch, float lr, float b1, float b2,
+                             hipStream_t s) {
+    (void)scratch;
+    hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int), s);   // found_inf of the previous step
+    if (e != hipSuccess) return e;
+    const size_t n4 = n / 4;
+    size_t nb = (n4 + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(grad_check_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float4*)g, n4, g, n4 * 4, n,
+                       (OptCtrl*)ctrl, lr, b1, b2);
+    return hipGetLastError();
+}
+
+__global__ void adam_guarded_kernel(float4* p, float4* m, float4* v, const float4* g, size_t n4, const OptCtrl* ctrl,
+                                    float b1, float b2, float eps, float gscale, float* pt, float* mt, float* vt,
+                                    const float* gt, size_t tail0, size_t n) {
+    if (ctrl->found_inf) return;
+    const float lr_t = ctrl->lr_t;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 pp = p[i], mm = m[i], vv = v[i], gg = g[i];
+        float* P = &pp.x; float* M = &mm.x; float* V = &vv.x; const float* G = &gg.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = G[k] * gscale;
+            M[k] = b1 * M[k] + (1.0f - b1) * gk;
+            V[k] = b2 * V[k] + (1.0f - b2) * gk * gk;
+            P[k] = P[k] - lr_t * M[k] / (sqrtf(V[k]) + eps);
+        }
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) {
+            const float gk = gt[i] * gscale;
+            const float mk = b1 * mt[i] + (1.0f - b1) * gk;
+            const float vk = b2 * vt[i] + (1.0f - b2) * gk * gk;
+            mt[i] = mk; vt[i] = vk;
+            pt[i] = pt[i] - lr_t * mk / (sqrtf(vk) + eps);
+        }
+    }
+}
+hipError_t launch_adam_guarded(float* p, float* m, float* v, const float* g, size_t n, const void* ctrl, float b1,
+                               float b2, float eps, float gscale, hipStream_t s) {
+    const size_t n4 = n / 4;
+    size_t nb = (n4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(adam_guarded_kernel, dim3((unsigned)nb), dim3(256), 0, s, (float4*)p, (float4*)m, (float4*)v,
+                       (const float4*)g, n4, (const OptCtrl*)ctrl, b1, b2, eps, gscale, p, m, v, g, n4 * 4, n);
+    return hipGetLastError();
+}
+__global__ void momentum_guarded_kernel(float* p, float* acc, const float* g, size_t n, const OptCtrl* ctrl, float lr,
+                                        float mom, float gscale) {
+    if (ctrl->found_inf) return;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = mom * acc[i] + g[i] * gscale;
+        acc[i] = a;
+        p[i] = p[i] - lr * a;
+    }
+}
+hipError_t launch_momentum_guarded(float* p, float* acc, const float* g, size_t n, const void* ctrl, float lr, float mom,
+                                   float gscale, hipStream_t s) {
+    size_t nb = (n + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(momentum_guarded_kernel, dim3((unsigned)nb), dim3(256), 0, s, p, acc, g, n, (const OptCtrl*)ctrl,
+                       lr, mom, gscale);
+    return hipGetLastError();
+}
+
 // counter-based generator (splitmix64 finaliser) -> Box-Muller -> reject |z| > 2
 Y2_DEV uint64_t mix64(uint64_t x) {
     x += 0x9E3779B97F4A7C15ull;

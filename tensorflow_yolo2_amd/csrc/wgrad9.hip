@@ -483,7 +483,11 @@ static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
     // many small blocks, two waves per SIMD -- beat 64x64 tiles on every Darknet-19 shape
     if constexpr (sizeof(T) == 2) {
         // long rows: the ring form stages 64 new rows per step instead of the whole window
+#ifdef Y2_DEV
         static const int minw = getenv("Y2DEV_WG9R_MINW") ? atoi(getenv("Y2DEV_WG9R_MINW")) : 52;
+#else
+        constexpr int minw = 52;
+#endif
         if (a.W >= minw) {
             hipError_t e;
             // 64 ci x 32 co tiles with 128-pixel K steps measured best at 52 and 104 (3-7 % over 64-pixel
@@ -527,6 +531,7 @@ hipError_t launch_wgrad9(int dtype, const WgradArgs& a, hipStream_t s) {
 namespace y2 {
 // policy: all-taps kernel where the image rows are short (window ~1.5-2x the K step),
 // per-tap kernel on the large feature maps and for 1x1 filters
+#ifdef Y2_DEV
 // development variants (f16): explicit block shapes
 hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s) {
     switch (variant) {
@@ -569,6 +574,7 @@ hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s)
     }
     return hipErrorInvalidValue;
 }
+#endif  // Y2_DEV
 
 hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a, hipStream_t s) {
     // measured per shape (scripts/bench_wgrad.py): nine-tap blocks win on every 3x3 layer

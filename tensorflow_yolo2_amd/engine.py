@@ -51,7 +51,8 @@ class Network:
     """One conv-BN-leaky(-pool) stack bound to device buffers."""
 
     def __init__(self, spec, batch, height, width, dtype="f16", core_layers=None, tail=_lib.Y2_TAIL_NONE,
-                 tail_k=7, training=True, device="cuda:0", grad_scale=None, bessel=False, share_with=None):
+                 tail_k=7, training=True, device="cuda:0", grad_scale=None, bessel=False, share_with=None,
+                 buffers=None):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.Y2Error("no MI355X visible: tensorflow_yolo2_amd has no CPU path")
@@ -81,6 +82,9 @@ class Network:
             assert share_with.n_params == self.n_params and share_with.n_state == self.n_state
             self.params, self.grads, self.state = share_with.params, share_with.grads, share_with.state
             assert not training or self.grads is not None
+        elif buffers is not None:
+            # caller-owned flat buffers (a variable scope's store, yolo2_nets/darknet.py): exact-size views
+            self.params, self.grads, self.state = self._check_buffers(*buffers)
         else:
             self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
             self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=self.device) if training else None
@@ -89,9 +93,11 @@ class Network:
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
         check(self.lib.y2_bind(h, _ptr(self.params), _ptr(self.grads), _ptr(self.state), _ptr(self.workspace),
                                self.ws_bytes, int(training), _stream()))
+        self.scale_owner = share_with.scale_owner if share_with is not None else self
         if grad_scale is None:
             grad_scale = 1.0 if self.dtype != _lib.Y2_F16 else 1024.0
         self.grad_scale = float(grad_scale)
+        self._bessel = bool(bessel)
         check(self.lib.y2_set_options(h, self.grad_scale, int(bessel)))
         self._offsets = []
         off = (C.c_size_t * 6)()
@@ -99,6 +105,28 @@ class Network:
             check(self.lib.y2_param_offsets(h, l, off))
             self._offsets.append(tuple(off))
         self._out = torch.empty(self.out_shape, dtype=torch.float32, device=self.device)
+        self.store = None          # yolo2_nets.darknet._VarStore when a variable scope owns the buffers
+
+    def _check_buffers(self, params, grads, state):
+        for t, n, need in ((params, self.n_params, True), (grads, self.n_params, self.training),
+                           (state, self.n_state, True)):
+            if t is None:
+                if need:
+                    raise ValueError("missing flat buffer")
+                continue
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n):
+                raise ValueError("flat buffer must be a contiguous float32 device tensor of %d elements" % n)
+        return params, (grads if self.training else None), state
+
+    def rebind(self, params, grads, state):
+        """move this context onto other flat buffers (same sizes); the workspace is re-zeroed"""
+        self.params, self.grads, self.state = self._check_buffers(params, grads, state)
+        check(self.lib.y2_bind(self.h, _ptr(self.params), _ptr(self.grads), _ptr(self.state), _ptr(self.workspace),
+                               self.ws_bytes, int(self.training), _stream()))
+
+    def set_grad_scale(self, grad_scale):
+        self.grad_scale = float(grad_scale)
+        check(self.lib.y2_set_options(self.h, self.grad_scale, int(self._bessel)))
 
     def __del__(self):
         try:
@@ -141,6 +169,8 @@ class Network:
             for k in PARAM_KEYS + STATE_KEYS:
                 v[k].copy_(torch.as_tensor(np.asarray(p[k], np.float32)).to(self.device))
         check(self.lib.y2_params_changed(self.h))
+        if self.store is not None:
+            self.store.version += 1
 
     def export_params(self):
         out = []
@@ -156,13 +186,19 @@ class Network:
         check(self.lib.y2_params_changed(self.h))
 
     # ---- execution -------------------------------------------------------
-    def forward(self, images, is_training_core=True, is_training_head=True, out=None):
+    def forward(self, images, is_training_core=True, is_training_head=True, out=None, update_moving=False):
+        """update_moving: fold the BN moving-statistics update of the training-mode layers into this pass
+        (the train step: UPDATE_OPS under train_op, pascal_train_darknet.py:49-51); False leaves them alone,
+        as a sess.run that fetches only the output or the loss does (update_moving_stats() applies it later)."""
         assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
         assert tuple(images.shape[:3]) == (self.batch, self.height, self.width), images.shape
         out = self._out if out is None else out
         check(self.lib.y2_forward(self.h, _ptr(images), int(bool(is_training_core)), int(bool(is_training_head)),
-                                  _ptr(out), _stream()))
+                                  int(bool(update_moving)), _ptr(out), _stream()))
         return out
+
+    def update_moving_stats(self):
+        check(self.lib.y2_update_moving_stats(self.h, _stream()))
 
     def backward(self, dout, layer_lo=0, layer_hi=None):
         layer_hi = self.num_layers if layer_hi is None else layer_hi
@@ -194,6 +230,12 @@ class Network:
         check(self.lib.y2_profile_busy(self.h, mask, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_layers(self):
+        """[num_layers][8] milliseconds per layer and category of the records so far (call before collect)"""
+        buf = (C.c_double * (self.num_layers * len(self.PROFILE_CATEGORIES)))()
+        check(self.lib.y2_profile_layers(self.h, buf))
+        return np.array(buf).reshape(self.num_layers, len(self.PROFILE_CATEGORIES))
+
     def profile_collect(self):
         n = len(self.PROFILE_CATEGORIES)
         ms = (C.c_double * n)()
@@ -214,35 +256,132 @@ class Network:
 # ---------------------------------------------------------------------------
 # flat-buffer optimizers
 # ---------------------------------------------------------------------------
-class AdamOptimizer:
-    """tf.train.AdamOptimizer defaults (src/pascal/pascal_train_darknet.py:51)."""
+class LossScaler:
+    """Dynamic loss scale for the half-precision modes (the fp32 reference has no counterpart).
 
-    def __init__(self, net, learning_rate=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8):
+    The guarded optimizer kernels skip a step whose gradient buffer holds an inf / NaN on the device, without a
+    host synchronisation; this object reads the control words ONE STEP LATE (asynchronous copy into pinned
+    memory) and halves grad_scale after an overflow, doubling it again after `growth_interval` clean steps up
+    to the initial scale's ceiling.  ctrl words: found_inf, step, skipped, ticket, lr_t."""
+
+    def __init__(self, net, growth_interval=2000, max_scale=65536.0, min_scale=1.0):
+        self.net = net.scale_owner
+        self.nets = [net]
+        self.ctrl = torch.zeros(8, dtype=torch.int32, device=net.device)
+        self._host = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self._event = None
+        self.growth_interval, self.max_scale, self.min_scale = growth_interval, max_scale, min_scale
+        self.enabled = net.dtype == _lib.Y2_F16
+        self._clean = 0
+        self.overflows = 0
+
+    @property
+    def scale(self):
+        return self.net.grad_scale
+
+    def _apply(self, scale):
+        seen = set()
+        for n in [self.net] + self.nets:
+            if id(n) not in seen:
+                seen.add(id(n))
+                n.set_grad_scale(scale)
+
+    def attach(self, net):
+        """another context on the same flat buffers (multi-scale): keep its scale in step"""
+        if all(n is not net for n in self.nets):
+            self.nets.append(net)
+            net.set_grad_scale(self.scale)
+
+    def after_step(self):
+        """call right after the guarded optimizer launch of a step"""
+        if self._event is not None:          # the copy issued after the PREVIOUS step has long finished
+            self._event.synchronize()
+            if int(self._host[0]) != 0:
+                self.overflows += 1
+                self._clean = 0
+                if self.enabled:
+                    self._apply(max(self.scale * 0.5, self.min_scale))
+            else:
+                self._clean += 1
+                if self.enabled and self._clean >= self.growth_interval and self.scale < self.max_scale:
+                    self._clean = 0
+                    self._apply(min(self.scale * 2.0, self.max_scale))
+        self._host.copy_(self.ctrl, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+
+    def state(self):
+        """(found_inf, device step counter, skipped steps) -- synchronises"""
+        c = self.ctrl.cpu().numpy()
+        return int(c[0]), int(c[1]), int(c[2])
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer defaults (src/pascal/pascal_train_darknet.py:51).
+    guard=True (default for the f16 mode): the overflow-safe kernels + LossScaler; the step counter then lives
+    on the device (`t` mirrors it assuming no skipped step; `scaler.state()` is authoritative)."""
+
+    def __init__(self, net, learning_rate=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8, guard=None):
         self.net, self.lr, self.b1, self.b2, self.eps = net, learning_rate, beta1, beta2, epsilon
         self.m = torch.zeros_like(net.params)
         self.v = torch.zeros_like(net.params)
         self.t = 0
+        self.guard = (net.dtype == _lib.Y2_F16) if guard is None else bool(guard)
+        self.scaler = LossScaler(net) if self.guard else None
 
     def step(self, grad_mult=1.0):
         self.t += 1
         n = self.net
-        check(n.lib.y2_adam_step(_ptr(n.params), _ptr(self.m), _ptr(self.v), _ptr(n.grads), n.n_params, self.t,
-                                 self.lr, self.b1, self.b2, self.eps, grad_mult, _stream()))
+        if self.guard:
+            check(n.lib.y2_adam_step_guarded(_ptr(n.params), _ptr(self.m), _ptr(self.v), _ptr(n.grads), n.n_params,
+                                             _ptr(self.scaler.ctrl), self.lr, self.b1, self.b2, self.eps,
+                                             grad_mult, _stream()))
+            self.scaler.after_step()
+        else:
+            check(n.lib.y2_adam_step(_ptr(n.params), _ptr(self.m), _ptr(self.v), _ptr(n.grads), n.n_params, self.t,
+                                     self.lr, self.b1, self.b2, self.eps, grad_mult, _stream()))
         n.params_changed()
+
+    # ---- tf.train.Saver slots (ADVICE r1: a resumed run must not restart Adam at t = 0)
+    def export_state(self):
+        t = self.scaler.state()[1] if self.guard else self.t
+        return {"m": self.m.detach().cpu().numpy().copy(), "v": self.v.detach().cpu().numpy().copy(), "t": int(t)}
+
+    def load_state(self, st):
+        self.m.copy_(torch.as_tensor(np.asarray(st["m"], np.float32)).to(self.m.device))
+        self.v.copy_(torch.as_tensor(np.asarray(st["v"], np.float32)).to(self.v.device))
+        self.t = int(st["t"])
+        if self.guard:
+            c = self.scaler.ctrl.cpu()
+            c[1] = self.t
+            self.scaler.ctrl.copy_(c)
 
 
 class MomentumOptimizer:
     """tf.train.MomentumOptimizer(0.001, 0.9) (src/imagenet/imagenet_train_darknet.py:58)."""
 
-    def __init__(self, net, learning_rate=1e-3, momentum=0.9):
+    def __init__(self, net, learning_rate=1e-3, momentum=0.9, guard=None):
         self.net, self.lr, self.mom = net, learning_rate, momentum
         self.accum = torch.zeros_like(net.params)
+        self.guard = (net.dtype == _lib.Y2_F16) if guard is None else bool(guard)
+        self.scaler = LossScaler(net) if self.guard else None
 
     def step(self, grad_mult=1.0):
         n = self.net
-        check(n.lib.y2_momentum_step(_ptr(n.params), _ptr(self.accum), _ptr(n.grads), n.n_params, self.lr,
-                                     self.mom, grad_mult, _stream()))
+        if self.guard:
+            check(n.lib.y2_momentum_step_guarded(_ptr(n.params), _ptr(self.accum), _ptr(n.grads), n.n_params,
+                                                 _ptr(self.scaler.ctrl), self.lr, self.mom, grad_mult, _stream()))
+            self.scaler.after_step()
+        else:
+            check(n.lib.y2_momentum_step(_ptr(n.params), _ptr(self.accum), _ptr(n.grads), n.n_params, self.lr,
+                                         self.mom, grad_mult, _stream()))
         n.params_changed()
+
+    def export_state(self):
+        return {"accum": self.accum.detach().cpu().numpy().copy()}
+
+    def load_state(self, st):
+        self.accum.copy_(torch.as_tensor(np.asarray(st["accum"], np.float32)).to(self.accum.device))
 
 
 # ---------------------------------------------------------------------------
@@ -402,6 +541,17 @@ def softmax_cross_entropy(logits, labels, need_grad=True):
     dl = torch.empty_like(logits) if need_grad else None
     check(lib.y2_softmax_cross_entropy(_ptr(logits), _ptr(labels), n, c, _ptr(loss), _ptr(dl), _stream()))
     return loss, dl
+
+
+def accuracy(logits, labels):
+    """reduce_mean(cast(equal(argmax(logits, 1), labels))) (imagenet_train_darknet.py:60-61) -> 0-d tensor"""
+    lib = _lib.load()
+    logits = logits.contiguous().float()
+    labels = labels.contiguous().to(torch.int32)
+    n, c = logits.shape
+    acc = torch.empty(1, dtype=torch.float32, device=logits.device)
+    check(lib.y2_accuracy(_ptr(logits), _ptr(labels), n, c, _ptr(acc), _stream()))
+    return acc[0]
 
 
 def conv2d(x, w, bias=None, dtype="f32"):

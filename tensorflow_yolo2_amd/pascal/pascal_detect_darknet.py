@@ -1,8 +1,11 @@
 """Counterpart of src/pascal/pascal_detect_darknet.py: single-image detection.
-    python -m tensorflow_yolo2_amd.pascal.pascal_detect_darknet IMAGE [--size 224]
+    python -m tensorflow_yolo2_amd.pascal.pascal_detect_darknet IMAGE [--ckpt-dir DIR | --weights FILE]
 Same sequence as the reference (:23-63): read + bilinear resize + x/255*2-1 on BGR pixels, core
-with is_training=False, head with its default is_training=True, reshape to [-1,S,S,30], decode."""
+with is_training=False, head with its default is_training=True, reshape to [-1,S,S,30], restore the
+variables (a weight file if given, else the latest snapshot of the checkpoint directory, :54-60),
+run, decode."""
 import argparse
+import os
 import sys
 
 import numpy as np
@@ -24,6 +27,9 @@ def main(argv=None):
     ap.add_argument("image")
     ap.add_argument("--size", type=int, default=cfg.IMAGE_SIZE)
     ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--weights", default=None, help="snapshot file (cfg.darknet_pascal_weight_path of the reference)")
+    ap.add_argument("--ckpt-dir", default=None, help="directory of train_iter_*.npz snapshots (cfg.get_ckpts_dir)")
+    ap.add_argument("--no-show", action="store_true")
     args = ap.parse_args(argv)
     from PIL import Image
     imdb = _Imdb()
@@ -36,9 +42,21 @@ def main(argv=None):
     core_net = darknet.darknet19_core(input_data, is_training=False)
     final_conv_layer = darknet.darknet19_detection(core_net, 5 * B + imdb.num_class)
     grid_net = final_conv_layer.reshape([-1, S, S, 5 * B + imdb.num_class])
-    predicts = grid_net.eval()                              # random weights unless a checkpoint was loaded
+    network = grid_net.build(training=False)                # the variables exist from here on (tf.Session + init)
+    # Load from weight file or checkpoint (:54-60); with neither, the initial values stay (plumbing run)
+    restored = 0
+    if args.weights and os.path.isfile(args.weights):
+        print('Restorining model from weight file {:s}'.format(args.weights))
+        names, _ = net_utils.restore_variables(network, args.weights)
+        restored = len(names)
+        print('Restored.')
+    elif args.ckpt_dir:
+        it = net_utils.restore_darknet19_variables(network, args.ckpt_dir, net_name='darknet19', save_epoch=False)
+        restored = it
+    predicts = grid_net.eval()
     cfg.S = S
-    return net_utils.show_yolo_detection(args.image, predicts, imdb)
+    dets = net_utils.show_yolo_detection(args.image, predicts, imdb, show=not args.no_show)
+    return {"detections": dets, "predicts": predicts, "restored": restored, "network": network}
 
 
 if __name__ == "__main__":

@@ -1,7 +1,10 @@
 """Counterpart of src/pascal/pascal_train_darknet.py's training loop on synthetic VOC-shaped data
 (no dataset ships here):  python -m tensorflow_yolo2_amd.pascal.pascal_train_darknet --iters 20
-Graph as the reference (:34-51): core(is_training) -> detection(30) -> reshape -> get_loss -> Adam."""
+Graph as the reference (:34-51): core(is_training) -> detection(30) -> reshape -> get_loss -> Adam;
+loop as the reference (:83-114): resume from the latest `train_iter_<i>.npz` snapshot of --ckpt-dir
+(variables AND Adam slots), run ADD_ITER more iterations, print every 10, save every --save-every."""
 import argparse
+import os
 
 import numpy as np
 import torch
@@ -13,10 +16,13 @@ from ..yolo2_nets import darknet, net_utils
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--iters", type=int, default=20, help="ADD_ITER (:24; 80000 in the reference)")
     ap.add_argument("--batch", type=int, default=24)        # BATCH_SIZE = 24 (:28)
     ap.add_argument("--size", type=int, default=cfg.IMAGE_SIZE)
     ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--ckpt-dir", default=None, help="snapshot directory (cfg.get_ckpts_dir('darknet19', imdb.name))")
+    ap.add_argument("--imagenet-ckpt-dir", default=None, help="classifier snapshots to take the backbone from")
+    ap.add_argument("--save-every", type=int, default=40000)   # :111
     args = ap.parse_args(argv)
     S, B, NUM_CLASS = args.size // 32, cfg.B, 20
     darknet.set_default_dtype(args.dtype)
@@ -25,10 +31,18 @@ def main(argv=None):
     final_conv_layer = darknet.darknet19_detection(core_net, 5 * B + NUM_CLASS)
     grid_net = final_conv_layer.reshape([-1, S, S, 5 * B + NUM_CLASS])
     optimizer = net_utils.AdamOptimizer()
+    network = grid_net.build(training=True)
+    last_iter_num = 0
+    if args.ckpt_dir:
+        os.makedirs(args.ckpt_dir, exist_ok=True)
+        last_iter_num = net_utils.restore_darknet19_variables(
+            network, args.ckpt_dir, net_name='darknet19', save_epoch=False,
+            imagenet_ckpt_dir=args.imagenet_ckpt_dir, optimizer=optimizer.slots(network))
+    TOTAL_ITER = args.iters + last_iter_num
     T = Timer()
     T.tic()
     losses = []
-    for i in range(1, args.iters + 1):
+    for i in range(last_iter_num + 1, TOTAL_ITER + 1):
         input_data.copy_(torch.as_tensor(synthetic.images(args.batch, args.size, i)))
         gt_labels = synthetic.det_labels(args.batch, args.size, S, 1000 + i)
         loss, ious, object_mask = net_utils.get_loss(grid_net, gt_labels, num_class=NUM_CLASS,
@@ -38,9 +52,13 @@ def main(argv=None):
         losses.append(float(loss))
         if i % 10 == 0:
             _time = T.toc(average=False)
-            print('iter {:d}/{:d}, total loss: {:.3}, take {:.2}s'.format(i, args.iters, losses[-1], _time))
+            print('iter {:d}/{:d}, total loss: {:.3}, take {:.2}s'.format(i, TOTAL_ITER, losses[-1], _time))
             T.tic()
-    return losses
+        if args.ckpt_dir and (i % args.save_every == 0 or i == TOTAL_ITER):
+            save_path = os.path.join(args.ckpt_dir, cfg.TRAIN_SNAPSHOT_PREFIX + '_iter_' + str(i) + '.npz')
+            net_utils.save_variables(network, save_path, optimizer=optimizer.slots(network))
+            print("Model saved in file: %s" % save_path)
+    return {"losses": losses, "last_iter": TOTAL_ITER, "first_iter": last_iter_num + 1, "network": network}
 
 
 if __name__ == "__main__":

@@ -26,8 +26,9 @@ from ..engine import CORE_SPEC, CLS_HEAD_SPEC, det_head_spec, Network
 alpha = 0.1   # darknet.py:5 (leaky slope, fixed in the kernels)
 
 _DEFAULT_DTYPE = "f16"
-_SCOPES = {}      # scope name -> {"spec": [...], "layers": list of dict(name -> torch tensor) or None}
-_NETWORKS = {}    # (scope chain, shape, dtype, training) -> Network
+_SCOPES = {}      # scope name -> {"spec": [...]}
+_STORES = []      # variable stores: one flat parameter / state (/ gradient) buffer per chain of scopes
+_NETWORKS = {}    # (scope chain, shape, dtype, training, tail) -> Network
 
 
 def set_default_dtype(dtype):
@@ -41,6 +42,7 @@ def reset_default_graph():
     """tf.reset_default_graph() counterpart: drops every scope, variable and cached network."""
     _SCOPES.clear()
     _NETWORKS.clear()
+    del _STORES[:]
 
 
 def _declare(scope, spec, reuse):
@@ -53,6 +55,88 @@ def _declare(scope, spec, reuse):
         if reuse:
             raise ValueError("reuse=True but variable scope %r does not exist" % scope)
         _SCOPES[scope] = {"spec": spec, "seed": len(_SCOPES)}
+
+
+class _VarStore:
+    """The variables of a chain of scopes (darknet19 [+ darknet19_detection]) in ONE flat buffer, in the
+    reference's creation order.  Every Network over that chain -- or over a leading part of it (the
+    backbone alone), at any batch / input size, training or not -- is bound to views of these tensors,
+    which is what tf.variable_scope(..., reuse=True) gives the reference (darknet.py:144,187): a train
+    step is visible to every graph that shares the scope at once."""
+
+    def __init__(self, chain, counts, device):
+        self.chain = tuple(chain)
+        self.counts = list(counts)            # per scope: (n_params, n_state)
+        n_p = sum(c[0] for c in counts)
+        n_s = sum(c[1] for c in counts)
+        self.params = torch.zeros(n_p, dtype=torch.float32, device=device)
+        self.state = torch.zeros(n_s, dtype=torch.float32, device=device)
+        self.grads = None
+        self.nets = []                        # (Network, number of leading scopes it covers)
+        self.optimizers = {}                  # optimizer slots live with the variables (net_utils)
+        self.version = 0                      # bumped whenever the variables change (optimizer step, restore)
+
+    def sizes(self, nscopes):
+        return (sum(c[0] for c in self.counts[:nscopes]), sum(c[1] for c in self.counts[:nscopes]))
+
+    def views(self, nscopes, training):
+        n_p, n_s = self.sizes(nscopes)
+        if training and self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+        return self.params[:n_p], (self.grads[:n_p] if training else None), self.state[:n_s]
+
+
+def _find_store(chain):
+    """(store, nscopes) whose chain starts with `chain`; None if `chain` is new or extends a store"""
+    for st in _STORES:
+        if st.chain[:len(chain)] == tuple(chain):
+            return st
+    return None
+
+
+def _store_for(chain, net_factory):
+    """Return the store holding `chain`'s variables, creating or extending one.
+    net_factory(buffers) builds the Network for the full `chain` (needed to learn the sizes and to draw
+    the initial values of new scopes on the device)."""
+    chain = tuple(chain)
+    st = _find_store(chain)
+    if st is not None:
+        return st, None
+    # a store whose chain is a leading part of the requested one: extend it (the head joins the backbone)
+    base = None
+    for cand in _STORES:
+        if chain[:len(cand.chain)] == cand.chain:
+            base = cand
+    for cand in _STORES:
+        if cand is not base and set(cand.chain) & set(chain):
+            raise NotImplementedError("scope(s) %s already live in the chain %s; one scope cannot be the prefix "
+                                      "of two different stacks" % (sorted(set(cand.chain) & set(chain)), cand.chain))
+    probe = net_factory(None)                 # own buffers: sizes + initial values for every scope of the chain
+    probe.init_params(seed=0)
+    counts, lo = [], 0
+    for scope in chain:
+        nl = len(_SCOPES[scope]["spec"])
+        o0 = probe._offsets[lo]
+        end_p = probe.n_params if lo + nl == probe.num_layers else probe._offsets[lo + nl][0]
+        end_s = probe.n_state if lo + nl == probe.num_layers else probe._offsets[lo + nl][4]
+        counts.append((end_p - o0[0], end_s - o0[4]))
+        lo += nl
+    st = _VarStore(chain, counts, probe.device)
+    st.params.copy_(probe.params)
+    st.state.copy_(probe.state)
+    if base is not None:
+        n_p, n_s = base.sizes(len(base.chain))
+        st.params[:n_p].copy_(base.params)
+        st.state[:n_s].copy_(base.state)
+        if base.grads is not None:
+            st.grads = torch.zeros_like(st.params)
+        for (net, k) in base.nets:            # move the existing graphs onto the longer buffer
+            net.rebind(*st.views(k, net.training))
+            st.nets.append((net, k))
+        _STORES.remove(base)
+    _STORES.append(st)
+    probe.rebind(*st.views(len(chain), probe.training))
+    return st, probe
 
 
 class NetTensor:
@@ -77,32 +161,40 @@ class NetTensor:
         if net is None:
             spec = [l for (_s, sp, _t) in self.segments for l in sp]
             n_core = len(self.segments[0][1])
-            net = Network(spec, x.shape[0], x.shape[1], x.shape[2], dtype=_DEFAULT_DTYPE, core_layers=n_core,
-                          tail=self.tail, tail_k=self.tail_k, training=training, device=str(x.device))
-            net.init_params(seed=0)
-            # share variables with networks that already hold one of these scopes
-            lo = 0
-            for (scope, sp, _t) in self.segments:
-                src = _SCOPES[scope].get("owner")
-                if src is not None and src[0] is not net:
-                    onet, olo = src
-                    for i in range(len(sp)):
-                        dst, srcv = net.layer_views(lo + i), onet.layer_views(olo + i)
-                        for k in dst:
-                            dst[k].copy_(srcv[k])
-                    net.params_changed()
-                else:
-                    _SCOPES[scope]["owner"] = (net, lo)
-                lo += len(sp)
+
+            def factory(buffers):
+                return Network(spec, x.shape[0], x.shape[1], x.shape[2], dtype=_DEFAULT_DTYPE, core_layers=n_core,
+                               tail=self.tail, tail_k=self.tail_k, training=training, device=str(x.device),
+                               buffers=buffers)
+            store, net = _store_for(chain, factory)
+            if net is None:
+                net = factory(store.views(len(chain), training))
+                owner = store.nets[0][0].scale_owner if store.nets else None
+                if owner is not None:
+                    net.scale_owner = owner
+                    net.set_grad_scale(owner.grad_scale)
+            store.nets.append((net, len(chain)))
+            net.store = store
             _NETWORKS[key] = net
         return net
 
-    def run(self, training=False):
+    def build(self, training=False):
+        """create (or find) the Network behind this tensor without running it -- the point at which the
+        reference's variables exist (tf.Session + initializer), so that a checkpoint can be restored into
+        them before the first run (pascal_detect_darknet.py:54-60)"""
+        self.network = self._network(training)
+        return self.network
+
+    def run(self, training=False, update_moving=False):
         """Evaluate (the `sess.run(tensor, feed)` of the reference scripts)."""
         net = self._network(training)
         self.network = net
         flags = [bool(t) for (_s, _sp, t) in self.segments]
-        out = net.forward(self.inputs.contiguous(), flags[0], flags[-1] if len(flags) > 1 else flags[0])
+        if getattr(net, "_seen_version", None) != net.store.version:
+            net.params_changed()             # the scope's variables moved under another graph: re-pack the filters
+            net._seen_version = net.store.version
+        out = net.forward(self.inputs.contiguous(), flags[0], flags[-1] if len(flags) > 1 else flags[0],
+                          update_moving=update_moving)
         if self.shape_override is not None:
             out = out.view(self.shape_override)
         self._value = out

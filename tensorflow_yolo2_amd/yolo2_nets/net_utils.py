@@ -30,7 +30,9 @@ def get_loss(net, labels, num_class, batch_size, image_size, S, B, OFFSET, scope
     if np.asarray(OFFSET).shape != expect.shape or not (np.asarray(OFFSET) == expect).all():
         raise ValueError("OFFSET must be the [S,S,B] column-index grid of config.py:40-42")
     source = net if isinstance(net, NetTensor) else None
-    value = net.run(training=True) if source is not None else net
+    # batch statistics, no moving-statistics update yet: the reference's UPDATE_OPS hang off train_op
+    # (pascal_train_darknet.py:49-51), so a loss that is only evaluated leaves them alone
+    value = net.run(training=True, update_moving=False) if source is not None else net
     if not torch.is_tensor(labels):
         labels = torch.as_tensor(np.asarray(labels, np.float32))
     labels = labels.to(value.device, torch.float32)
@@ -44,13 +46,34 @@ def get_loss(net, labels, num_class, batch_size, image_size, S, B, OFFSET, scope
     return loss, ious, mask
 
 
-class AdamOptimizer:
-    """tf.train.AdamOptimizer().minimize(loss) (pascal_train_darknet.py:51): returns a train op;
-    calling it applies one update (backward through the stack that produced `loss`, then Adam)."""
+class _Optimizer:
+    """tf.train.*Optimizer().minimize(loss): returns a train op; calling it applies one update (the BN
+    moving-statistics update of the forward that produced `loss`, backward through that stack, then the
+    optimizer).  Slots live with the variable store, so every graph sharing the scopes trains ONE state."""
+    _engine_cls = None
 
-    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-08):
-        self.args = (learning_rate, beta1, beta2, epsilon)
+    def __init__(self, *args):
+        self.args = args
         self._opt = {}
+
+    def slots(self, net):
+        """the engine optimizer (slot tensors) that train ops of this object apply to `net`'s variables"""
+        return self._slots(net)
+
+    def _slots(self, net):
+        store = getattr(net, "store", None)
+        key = id(store) if store is not None else id(net)
+        opt = self._opt.get(key)
+        if opt is None:
+            opt = self._opt[key] = self._engine_cls(net, *self.args)
+            if store is not None:
+                store.optimizers[type(self).__name__] = opt
+        if opt.net is not net:                 # same flat buffers, another context (batch / size)
+            assert opt.net.n_params == net.n_params, "one optimizer per variable chain"
+            opt.net = net
+            if opt.scaler is not None:
+                opt.scaler.attach(net)
+        return opt
 
     def minimize(self, loss):
         def train_op(loss=loss):
@@ -58,12 +81,29 @@ class AdamOptimizer:
             if src is None or src.network is None or not src.network.training:
                 raise RuntimeError("loss was not produced by a training-mode NetTensor")
             net = src.network
+            net.update_moving_stats()          # tf.control_dependencies(update_ops)
             net.backward(loss.dnet.contiguous())
-            opt = self._opt.get(id(net))
-            if opt is None:
-                opt = self._opt[id(net)] = engine.AdamOptimizer(net, *self.args)
-            opt.step()
+            self._slots(net).step()
+            store = getattr(net, "store", None)
+            if store is not None:
+                store.version += 1
         return train_op
+
+
+class AdamOptimizer(_Optimizer):
+    """tf.train.AdamOptimizer().minimize(loss) (pascal_train_darknet.py:51)"""
+    _engine_cls = engine.AdamOptimizer
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-08):
+        _Optimizer.__init__(self, learning_rate, beta1, beta2, epsilon)
+
+
+class MomentumOptimizer(_Optimizer):
+    """tf.train.MomentumOptimizer(0.001, 0.9).minimize(loss) (imagenet_train_darknet.py:58)"""
+    _engine_cls = engine.MomentumOptimizer
+
+    def __init__(self, learning_rate, momentum):
+        _Optimizer.__init__(self, learning_rate, momentum)
 
 
 def decode_yolo_detection(predict_output, im_w, im_h, num_class, S=cfg.S, B=cfg.B, object_thresh=0.5):
@@ -119,48 +159,119 @@ def _kind_of(network):
     return {18: "core", 19: "classifier", 22: "detector"}.get(n, "detector")
 
 
-def save_variables(network, path, kind=None):
-    """write every parameter and BN moving statistic of `network` under its TF variable name"""
+def _names(network, kind):
     kind = kind or _kind_of(network)
-    names = _darknet.variable_names("classifier" if kind in ("core", "classifier") else kind,
-                                    network.spec[-1][2])[:network.num_layers]
+    return _darknet.variable_names("classifier" if kind in ("core", "classifier") else kind,
+                                   network.spec[-1][2])[:network.num_layers]
+
+
+def _slot_views(network, flat):
+    """per-layer dict of numpy copies of a flat optimizer slot laid out like the parameters"""
+    host = flat.detach().cpu().numpy()
+    out = []
+    for l in range(network.num_layers):
+        o = network._offsets[l]
+        shp = network._shapes(l)
+        d = {}
+        for i, k in enumerate(engine.PARAM_KEYS):
+            n = int(np.prod(shp[k]))
+            d[k] = host[o[i]:o[i] + n].reshape(shp[k]).copy()
+        out.append(d)
+    return out
+
+
+def save_variables(network, path, kind=None, optimizer=None):
+    """write what tf.train.Saver() writes for the reference graph, under the TF variable names: every
+    parameter and BN moving statistic and -- with `optimizer` (an engine Adam/Momentum optimizer) -- its slots
+    (`<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power`; `<var>/Momentum`), so that a resumed run
+    does not restart Adam at t = 0 with empty moments (pascal_train_darknet.py:83,88,111-114)."""
+    names = _names(network, kind)
     blob = {}
     for layer, nm in zip(network.export_params(), names):
         for k, tfname in nm.items():
             blob[tfname] = layer[k]
+    if optimizer is not None:
+        st = optimizer.export_state()
+        if "m" in st:
+            flat_m = torch.as_tensor(st["m"])
+            flat_v = torch.as_tensor(st["v"])
+            for lm, lv, nm in zip(_slot_views(network, flat_m), _slot_views(network, flat_v), names):
+                for k in engine.PARAM_KEYS:
+                    blob[nm[k] + "/Adam"] = lm[k]
+                    blob[nm[k] + "/Adam_1"] = lv[k]
+            blob["beta1_power"] = np.float64(optimizer.b1) ** st["t"]
+            blob["beta2_power"] = np.float64(optimizer.b2) ** st["t"]
+            blob["adam_step"] = np.int64(st["t"])
+        else:
+            for la, nm in zip(_slot_views(network, torch.as_tensor(st["accum"])), names):
+                for k in engine.PARAM_KEYS:
+                    blob[nm[k] + "/Momentum"] = la[k]
     np.savez(path, **blob)
     return sorted(blob)
 
 
-def restore_variables(network, path, kind=None):
+def restore_variables(network, path, kind=None, optimizer=None):
     """load the variables whose names are present in the snapshot, leave the others as they are
     (the reference restores the ImageNet-trained backbone into the detector this way, :83-103).
-    Returns (restored names, names left untouched)."""
-    kind = kind or _kind_of(network)
-    names = _darknet.variable_names("classifier" if kind in ("core", "classifier") else kind,
-                                    network.spec[-1][2])[:network.num_layers]
+    A variable present with another shape raises (tf.train.Saver does too).  With `optimizer`, its slots
+    are restored when the snapshot holds them.  Returns (restored names, names left untouched)."""
+    names = _names(network, kind)
     snap = np.load(path)
     layers = network.export_params()
     restored, kept = [], []
     for layer, nm in zip(layers, names):
         for k, tfname in nm.items():
-            if tfname in snap.files and tuple(snap[tfname].shape) == tuple(layer[k].shape):
+            if tfname in snap.files:
+                if tuple(snap[tfname].shape) != tuple(layer[k].shape):
+                    raise ValueError("snapshot %s: %s has shape %s, the graph expects %s" %
+                                     (path, tfname, tuple(snap[tfname].shape), tuple(layer[k].shape)))
                 layer[k] = snap[tfname]
                 restored.append(tfname)
             else:
                 kept.append(tfname)
     network.load_params(layers)
+    if optimizer is not None:
+        st = optimizer.export_state()
+        if "m" in st and all((nm["W"] + "/Adam") in snap.files for nm in names):
+            for slot, suffix in (("m", "/Adam"), ("v", "/Adam_1")):
+                flat = st[slot]
+                for l, nm in enumerate(names):
+                    o = network._offsets[l]
+                    for i, k in enumerate(engine.PARAM_KEYS):
+                        a = snap[nm[k] + suffix]
+                        flat[o[i]:o[i] + a.size] = a.reshape(-1)
+            if "adam_step" in snap.files:
+                st["t"] = int(snap["adam_step"])
+            else:   # a converter from a TF checkpoint only has the beta powers
+                st["t"] = int(round(np.log(float(snap["beta1_power"])) / np.log(optimizer.b1)))
+            optimizer.load_state(st)
+        elif "accum" in st and all((nm["W"] + "/Momentum") in snap.files for nm in names):
+            flat = st["accum"]
+            for l, nm in enumerate(names):
+                o = network._offsets[l]
+                for i, k in enumerate(engine.PARAM_KEYS):
+                    a = snap[nm[k] + "/Momentum"]
+                    flat[o[i]:o[i] + a.size] = a.reshape(-1)
+            optimizer.load_state(st)
     return restored, kept
 
 
 def get_ordered_ckpts(ckpt_dir, net_name='darknet19', save_epoch=True):
-    """snapshot files of `net_name` in `ckpt_dir`, oldest first (reference :14-38 orders by mtime)"""
+    """snapshot files of `net_name` in `ckpt_dir`, oldest first (reference :14-38 orders by mtime;
+    the number in the name breaks ties of files written within one clock tick)"""
     tag = "epoch" if save_epoch else "iter"
-    files = [f for f in glob.glob(os.path.join(ckpt_dir, "%s_%s_*.npz" % (net_name, tag)))]
-    return sorted(files, key=os.path.getmtime)
+    # reference :27-28: cfg.TRAIN_SNAPSHOT_PREFIX + '_' + save_interval + '_*.ckpt.meta' inside
+    # cfg.get_ckpts_dir(net_name, imdb.name); here the caller passes that directory
+    files = [f for f in glob.glob(os.path.join(ckpt_dir, "%s_%s_*.npz" % (cfg.TRAIN_SNAPSHOT_PREFIX, tag)))]
+
+    def key(f):
+        m = re.search(r"_(\d+)\.npz$", f)
+        return (os.path.getmtime(f), int(m.group(1)) if m else 0)
+    return sorted(files, key=key)
 
 
-def restore_darknet19_variables(network, ckpt_dir, net_name='darknet19', save_epoch=True, imagenet_ckpt_dir=None):
+def restore_darknet19_variables(network, ckpt_dir, net_name='darknet19', save_epoch=True, imagenet_ckpt_dir=None,
+                                optimizer=None):
     """Reference :64-110: restore the latest snapshot and return its epoch / iteration number; with no
     snapshot, restore what an ImageNet-classifier snapshot holds (the backbone) and return 0."""
     sfiles = get_ordered_ckpts(ckpt_dir, net_name, save_epoch)
@@ -170,6 +281,6 @@ def restore_darknet19_variables(network, ckpt_dir, net_name='darknet19', save_ep
             if prior:
                 restore_variables(network, prior[-1])
         return 0
-    restore_variables(network, sfiles[-1])
+    restore_variables(network, sfiles[-1], optimizer=optimizer)
     m = re.search(r"_(\d+)\.npz$", sfiles[-1])
     return int(m.group(1)) if m else 0

@@ -34,6 +34,32 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.skipif(not _built(), reason="libyolo2_hip.so not built")
+def test_library_exports_nothing_but_the_header():
+    """the product library must not ship development entry points (y2dev_* timing
+    calls that allocate their own buffers) or any other undeclared function: the exported FUNCTIONS of
+    the .so are exactly the header's (kernel handle objects are data symbols, not part of the ABI)."""
+    import subprocess
+    from tensorflow_yolo2_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    funcs = sorted(ln.split()[2] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in ("T", "W"))
+    funcs = [f for f in funcs if not f.startswith("_Z")]          # C++ kernel stubs carry no C name
+    assert funcs == header_symbols()
+    assert not any("y2dev" in ln for ln in out.splitlines())
+
+
+@pytest.mark.skipif(not _built(), reason="libyolo2_hip.so not built")
+def test_context_rejects_widths_the_kernels_cannot_run():
+    """out_chl beyond the BN kernels' row width must be an argument error, not a divide by zero"""
+    import ctypes as C
+    from tensorflow_yolo2_amd import _lib
+    lib = _lib.load()
+    spec = (C.c_int * 8)(3, 3, 32, 0, 3, 32, 4096, 0)
+    h = C.c_void_p()
+    assert lib.y2_ctx_create(C.byref(h), spec, 2, 2, 0, 0, 1, 8, 8, 1) < 0
+    assert b"row width" in lib.y2_last_error()
+
+
+@pytest.mark.skipif(not _built(), reason="libyolo2_hip.so not built")
 def test_spec_and_context_planning_without_gpu():
     """context creation / planning is host-only arithmetic: the reference counts must come out."""
     import ctypes as C

@@ -37,7 +37,7 @@ def _rank_grads(rank):
     return params, _flat(grads)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, strategy="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
         offs.append(o)
         o += k * k * ci * co + 3 * co
     ranges = [trainer.slice_range(offs, flat.numel(), len(SPEC), lo, hi) for (lo, hi) in [(2, 3), (0, 2)]]
-    trainer.reduce_flat(flat, ranges, dist)
+    trainer.reduce_flat(flat, ranges, dist, strategy)
     p0 = _flat([{k: p[k] for k in ("W", "b", "gamma", "beta")} for p in params])
     var, m, v = O.adam_step(p0, np.zeros_like(p0), np.zeros_like(p0), flat.numpy() * (1.0 / world), 1)
     q.put((rank, flat.numpy().copy(), var))
@@ -58,11 +58,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sliced_allreduce_equals_mean_of_replica_gradients():
+import pytest
+
+
+@pytest.mark.parametrize("strategy", ["allreduce", "rs_ag"])
+def test_sliced_allreduce_equals_mean_of_replica_gradients(strategy):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, strategy)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict()

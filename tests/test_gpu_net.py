@@ -39,7 +39,7 @@ def test_golden_tiny_stack(golden_dir):
     x = g["x"]
     net = E.Network(spec, x.shape[0], x.shape[1], x.shape[2], dtype="f32", training=True)
     net.load_params(params)
-    out = net.forward(dev(x), True, True)
+    out = net.forward(dev(x), True, True, update_moving=True)
     assert relerr(out.cpu().numpy(), g["out"]) < 1e-3          # north_star: 1e-3 relative (observed ~1e-6)
     net.backward(dev(g["dout"]))
     grads, state = net.export_grads(), net.export_params()
@@ -307,7 +307,7 @@ def test_snapshots_by_tf_variable_name(tmp_path):
     cls = E.Network(list(E.CORE_SPEC) + list(E.CLS_HEAD_SPEC), 1, 64, 64, dtype="f32", core_layers=19, training=False)
     cls.init_params(5)
     os.makedirs(tmp_path / "imagenet", exist_ok=True)
-    names = NU.save_variables(cls, str(tmp_path / "imagenet" / "darknet19_epoch_3.npz"), "classifier")
+    names = NU.save_variables(cls, str(tmp_path / "imagenet" / "train_epoch_3.npz"), "classifier")
     assert "darknet19/Variable" in names and "darknet19/batch_normalization_18/moving_variance" in names
     det = E.Network(list(E.CORE_SPEC) + E.det_head_spec(30), 1, 64, 64, dtype="f32", core_layers=18, training=False)
     det.init_params(9)
@@ -319,7 +319,7 @@ def test_snapshots_by_tf_variable_name(tmp_path):
         np.testing.assert_array_equal(after[l]["W"], src[l]["W"])
     for l in range(18, 22):
         np.testing.assert_array_equal(after[l]["W"], before[l]["W"])
-    NU.save_variables(det, str(tmp_path / "voc" / "darknet19_epoch_7.npz"))
+    NU.save_variables(det, str(tmp_path / "voc" / "train_epoch_7.npz"))
     det.init_params(11)
     assert NU.restore_darknet19_variables(det, str(tmp_path / "voc")) == 7
     np.testing.assert_array_equal(det.export_params()[20]["W"], after[20]["W"])

@@ -132,7 +132,7 @@ def test_stack_forward(first3, training, dtype):
     x = rng.uniform(-1, 1, shape).astype(np.float32)
     net = E.Network(spec, shape[0], shape[1], shape[2], dtype=dtype, training=False)
     net.load_params(params)
-    out = net.forward(dev(x), training, training).cpu().numpy()
+    out = net.forward(dev(x), training, training, update_moving=True).cpu().numpy()
     ref, caches, movings = R.run_stack(x, params, spec, training, np.float64)
     tol = {"f32": 2e-5, "f16": 1e-2, "bf16": 8e-2}[dtype]
     assert out.shape == ref.shape

@@ -91,12 +91,17 @@ def test_synthetic_inputs_are_deterministic_and_encoded_like_the_reference():
 
 def test_layer_slices_cover_the_flat_buffer_in_backward_order():
     from tensorflow_yolo2_amd import trainer
-    sl = trainer.layer_slices(22)
+    sl = trainer.layer_slices(22, cuts=(0, 13, 18))
     assert sl == [(18, 22), (13, 18), (0, 13)]
     offs = list(range(0, 220, 10))
     ranges = [trainer.slice_range(offs, 1000, 22, lo, hi) for (lo, hi) in sl]
     assert ranges == [(180, 1000), (130, 180), (0, 130)]
-    assert trainer.layer_slices(3) == [(0, 3)]
+    assert trainer.layer_slices(3, cuts=(0, 13, 18)) == [(0, 3)]
+    # default: head filters one by one, a 3.4 MB tail; contiguous cover of [0, n) in backward order
+    d = trainer.layer_slices(22)
+    assert d[0] == (20, 22) and d[-1] == (0, 8)
+    assert [lo for (lo, hi) in d] == [hi for (lo, hi) in d[1:]] + [0] and d[0][1] == 22
+    assert trainer.layer_slices(19)[0][1] == 19 and trainer.layer_slices(19)[-1][0] == 0
 
 
 def test_multi_scale_schedule_is_deterministic_and_in_range():
