@@ -160,14 +160,31 @@ int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n
 int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, float lr, float momentum,
                      float grad_mult, void* stream);
 /* The same updates guarded against half-precision gradient overflow (dynamic loss scaling; the fp32
- * reference cannot overflow): ctrl = 8 zero-initialised 32-bit device words {found_inf, step, skipped,
- * ticket, lr_t, ...}.  If `grads` holds any inf / NaN the step is skipped as a whole (params, slots and the
- * device-side step counter untouched, ctrl.found_inf = 1); otherwise ctrl.step advances and Adam's lr_t is
- * computed on the device for it.  No host synchronisation. */
+ * reference cannot overflow): ctrl = 8 zero-initialised 32-bit device words {found_inf, step, skipped, -,
+ * lr_t, ...}.  A scan sets ctrl.found_inf: y2_grad_check reads the context's SENTINEL ranges of its bound gradient
+ * buffer (b / gamma / beta of every layer and the first filter, ~30 k floats: every non-finite value of the
+ * backward pass reaches them -- an inf / NaN in a layer's incoming gradient makes the channel sums dbeta
+ * non-finite, a dy that overflows at its own f16 store is an operand of the dgrad below it, and the first layer's
+ * dy feeds its filter gradient directly); y2_grad_check_full reads every element of any buffer.
+ * The guarded step then skips as a whole when found_inf is set (params, slots and the device-side step
+ * counter untouched, ctrl.skipped += 1); otherwise ctrl.step advances and Adam's lr_t is computed on the
+ * device for it.  No host synchronisation. */
+int y2_grad_check(y2_ctx* ctx, void* ctrl, void* stream);
+int y2_grad_check_full(const float* grads, size_t n, void* ctrl, void* stream);
 int y2_adam_step_guarded(float* params, float* m, float* v, const float* grads, size_t n, void* ctrl, float lr,
                          float beta1, float beta2, float eps, float grad_mult, void* stream);
 int y2_momentum_step_guarded(float* params, float* accum, const float* grads, size_t n, void* ctrl, float lr,
                              float momentum, float grad_mult, void* stream);
+
+/* The optimizer step of a context's bound parameters / gradients FUSED with the re-pack of its filters into the
+ * MFMA operand layouts (the update reads and writes every filter anyway; y2_forward then finds the packed copies
+ * current and skips its own re-pack pass).  Same arithmetic as y2_adam_step / y2_momentum_step.  ctrl: NULL for
+ * the plain step number `step`, or the guard words of the *_guarded forms (run y2_grad_check first).  Other
+ * contexts bound to the same parameter buffer must still call y2_params_changed. */
+int y2_adam_step_packed(y2_ctx* ctx, float* m, float* v, void* ctrl, int step, float lr, float beta1, float beta2,
+                        float eps, float grad_mult, void* stream);
+int y2_momentum_step_packed(y2_ctx* ctx, float* accum, void* ctrl, float lr, float momentum, float grad_mult,
+                            void* stream);
 
 /* ---- single-op entry points (tf.nn.conv2d 'SAME' stride 1, darknet.py:20-21) used by the
  *      per-op parity tests; channel counts are padded internally to the kernels' granularity */

@@ -15,12 +15,8 @@ tr.net.profile_enable(1)
 for _ in range(steps):
     tr.step(x, lab)
 torch.cuda.synchronize()
-lib = tr.net.lib
-nl = lib.y2_num_layers(tr.net.h)
-buf = (C.c_double * (nl * 8))()
-lib.y2dev_profile_layers.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-lib.y2dev_profile_layers(tr.net.h, buf)
-a = np.array(buf).reshape(nl, 8) / steps * 1e3
+nl = tr.net.num_layers
+a = tr.net.profile_layers() / steps * 1e3
 spec = list(E.CORE_SPEC) + E.det_head_spec(30)
 h = size
 print("layer  k  cin->cout   hw   | fwd us (TF) | dgrad us (TF) | wgrad us (TF) | bn_fwd  bn_bwd")

@@ -8,6 +8,14 @@
         `--pmc WRITE_SIZE` passes of the same command.  Per kernel: launches, average counter values (KB)
         and HBM bytes per launch, with FETCH_SIZE doubled (the gfx950 correction of
         /opt/skills/guides/MI355X_MICROARCH.md: wide coalesced reads are tallied at half their size).
+    python scripts/summarize_profiles.py trace <dir> <out.csv> <steps>
+        <dir> holds *_kernel_trace.csv of `rocprofv3 --kernel-trace -- python3 bench.py --steps N ...`; writes the
+        per-dispatch timeline (start, end relative to the step's first launch, in us) of the LAST step and, in
+        the header comment, what bench.py's roofline uses: the length of the UNION of the MFMA convolution
+        launches' intervals, their summed durations and the step's span.
+    python scripts/summarize_profiles.py sq <dir> <out.csv>
+        <dir> holds *_counter_collection.csv of one `--pmc SQ_...` pass; per kernel: launches and the average of
+        every counter, plus MFMA busy / CU busy and LDS conflict ratios where the inputs are present.
 """
 import csv
 import glob
@@ -64,8 +72,101 @@ def pmc(fd, wd, out):
     print("wrote", out, len(res), "kernels")
 
 
+MFMA_KERNELS = ("conv_haloq", "conv_halo_kernel", "conv_igemm_kernel", "wgrad9", "wgrad_kernel", "gemm1x1",
+                "conv_big", "wgrad1x1")
+
+
+def is_mfma_conv(name):
+    return any(k in name for k in MFMA_KERNELS)
+
+
+def trace(d, out, steps):
+    rows = [r for r in csv.DictReader(open(find(d, "*_kernel_trace.csv"))) if r["Kind"] == "KERNEL_DISPATCH"]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # a step starts at the image pack of the first layer (pack_input_kernel); keep the last complete one
+    starts = [i for i, r in enumerate(rows) if "pack_input" in r["Kernel_Name"]]
+    if len(starts) < 2:
+        raise SystemExit("no step boundaries found")
+    # the last step ends where the optimizer kernel of that step ends
+    lo = starts[-1]
+    hi = len(rows)
+    step = rows[lo:hi]
+    for j, r in enumerate(step):
+        if "adam" in r["Kernel_Name"] or "momentum" in r["Kernel_Name"]:
+            hi = lo + j + 1
+            break
+    step = rows[lo:hi]
+    t0 = int(step[0]["Start_Timestamp"])
+    iv = sorted((int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0) for r in step
+                if is_mfma_conv(r["Kernel_Name"]))
+    union, cur0, cur1 = 0, None, None
+    for a, b in iv:
+        if cur1 is None or a > cur1:
+            if cur1 is not None:
+                union += cur1 - cur0
+            cur0, cur1 = a, b
+        elif b > cur1:
+            cur1 = b
+    if cur1 is not None:
+        union += cur1 - cur0
+    span = int(step[-1]["End_Timestamp"]) - t0
+    with open(out, "w", newline="") as f:
+        f.write("# last step of %s: %d dispatches, span %.1f us; MFMA convolution launches: %d, union of intervals "
+                "%.1f us, sum of durations %.1f us\n" % (os.path.basename(d.rstrip("/")), len(step), span / 1e3, len(iv),
+                                                         union / 1e3, sum(b - a for a, b in iv) / 1e3))
+        w = csv.writer(f)
+        w.writerow(["start_us", "end_us", "dur_us", "stream", "mfma_conv", "grid", "wg", "lds", "vgpr", "kernel"])
+        for r in step:
+            a, b = int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0
+            w.writerow(["%.2f" % (a / 1e3), "%.2f" % (b / 1e3), "%.2f" % ((b - a) / 1e3), r.get("Stream_Id", ""),
+                        int(is_mfma_conv(r["Kernel_Name"])), r["Grid_Size_X"], r["Workgroup_Size_X"],
+                        r["LDS_Block_Size"], r["VGPR_Count"], short(r["Kernel_Name"])])
+    print("wrote", out, "union %.1f us over %d launches, span %.1f us" % (union / 1e3, len(iv), span / 1e3))
+
+
+def sq(d, out):
+    acc = {}
+    names = []
+    for r in csv.DictReader(open(find(d, "*_counter_collection.csv"))):
+        k = short(r["Kernel_Name"])
+        c = r["Counter_Name"]
+        if c not in names:
+            names.append(c)
+        a = acc.setdefault(k, {})
+        v = a.setdefault(c, [0, 0.0])
+        v[0] += 1
+        v[1] += float(r["Counter_Value"])
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        extra = []
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in names and "SQ_BUSY_CU_CYCLES" in names:
+            extra.append("mfma_busy_per_cu_busy")
+        if "SQ_LDS_BANK_CONFLICT" in names and "SQ_LDS_IDX_ACTIVE" in names:
+            extra.append("lds_conflict_frac")
+        if "SQ_WAIT_ANY" in names and "SQ_WAVE_CYCLES" in names:
+            extra.append("wait_any_frac")
+        w.writerow(["kernel", "launches"] + names + extra)
+        for k, a in sorted(acc.items(), key=lambda kv: -kv[1].get(names[0], [0, 0])[1]):
+            n = max(v[0] for v in a.values())
+            avg = {c: (a[c][1] / a[c][0] if c in a else 0.0) for c in names}
+            row = [k, n] + ["%.0f" % avg[c] for c in names]
+            for e in extra:
+                if e == "mfma_busy_per_cu_busy":
+                    row.append("%.3f" % (avg["SQ_VALU_MFMA_BUSY_CYCLES"] / max(avg["SQ_BUSY_CU_CYCLES"], 1)))
+                elif e == "lds_conflict_frac":
+                    row.append("%.3f" % (avg["SQ_LDS_BANK_CONFLICT"] / max(avg["SQ_LDS_IDX_ACTIVE"], 1)))
+                else:
+                    row.append("%.3f" % (avg["SQ_WAIT_ANY"] / max(avg["SQ_WAVE_CYCLES"], 1)))
+            w.writerow(row)
+    print("wrote", out, len(acc), "kernels")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else None)
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4])

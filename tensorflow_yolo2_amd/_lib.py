@@ -66,8 +66,12 @@ SIGNATURES = {
     "y2_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp]),
     "y2_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
+    "y2_grad_check": (_i, [_vp, _vp, _vp]),
+    "y2_grad_check_full": (_i, [_vp, _sz, _vp, _vp]),
     "y2_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step_guarded": (_i, [_vp, _vp, _vp, _sz, _vp, _f, _f, _f, _vp]),
+    "y2_adam_step_packed": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp]),
+    "y2_momentum_step_packed": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp]),
     "y2_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "y2_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "y2_conv2d_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
         while (ho >= Ho) { ho -= Ho; ++n; }
         float r[EPC];
         if (POOL) {
+            Chunk<T> ys;   // conv output at the first arg-max of the window (backward: BnActArgs::ysel)
 #pragma unroll
             for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
 #pragma unroll
@@ -186,10 +187,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
                     Chunk<T> v = ld_chunk<T>((const char*)a.y +
                                              (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e)
-                        r[e] = fmaxf(r[e], leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]));
+                    for (int e = 0; e < EPC; ++e) {
+                        const float act = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+                        if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
+                    }
                 }
             }
+            if (a.ysel) st_chunk<T>((char*)a.ysel + ((size_t)po * a.ldy + c0) * sizeof(T), ys);
         } else {
             Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
 #pragma unroll

@@ -114,6 +114,7 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
     const int mw0 = m0 + wp * TP * 32;  // first pixel of this wave
     const int cch = cw0 + ch * EPC;     // first cout of this lane's chunk
     const bool stats = a.part_mean != nullptr;
+    const bool bw = a.bw_psum != nullptr;    // dgrad launch: BN-backward reduce of the layer below (kernels.h)
     // Statistics of the values AS STORED, as sums of d = y - bias and of d^2: one pass, no value
     // buffer; the bias is a free pivot (it removes the offset the filter response rides on).
     float piv[EPC], s1[EPC], s2[EPC];
@@ -123,28 +124,68 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
         s1[e] = 0.f;
         s2[e] = 0.f;
     }
-    auto sweep = [&](auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    if (!bw) {
+        auto sweep = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int prow = it * RPIe + prow0;
+                Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
+                const bool pv = FULL || (mw0 + prow) < a.M;
+                if (!(EABL & 1) && pv && cch < a.ldy) st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
+                if (stats) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        float d = Elem<T>::to_f32(c.v[e]) - piv[e];
+                        if (!FULL) d = pv ? d : 0.f;
+                        s1[e] += d;
+                        s2[e] = fmaf(d, d, s2[e]);
+                    }
+                }
+            }
+        };
+        if (mw0 + TP * 32 <= a.M) sweep(std::true_type{});   // wave-uniform
+        else sweep(std::false_type{});
+    } else {
+        // ---- dgrad: store dA and reduce S1 = sum g, S2 = sum g * y_sel of the layer below on the fly
+        const bool cv = cch < a.ldy;
+        float sc[EPC], sh[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = cv ? a.bw_scale[cch + e] : 0.f;
+            sh[e] = cv ? a.bw_shift[cch + e] : 0.f;
+        }
+        const char* yb = (const char*)a.bw_y + (size_t)cch * SZ;
+        const size_t rowB = (size_t)a.ldy * SZ;
+        // every y chunk of the sweep is requested before the first one is used (the accumulators are dead: the
+        // registers are free, and one HBM latency is paid per tile instead of one per row group)
+        Chunk<T> yv[NIT];
+        if (cv) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                int p = mw0 + it * RPIe + prow0;
+                if (p > a.M - 1) p = a.M - 1;
+                yv[it] = ld_chunk<T>(yb + (size_t)p * rowB);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int prow = it * RPIe + prow0;
             Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
-            const bool pv = FULL || (mw0 + prow) < a.M;
-            if (!(EABL & 1) && pv && cch < a.ldy) st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
-            if (stats) {
+            const bool pv = (mw0 + prow) < a.M;
+            if (pv && cv) {
+                st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    float d = Elem<T>::to_f32(c.v[e]) - piv[e];
-                    if (!FULL) d = pv ? d : 0.f;
-                    s1[e] += d;
-                    s2[e] = fmaf(d, d, s2[e]);
+                    const float yf = Elem<T>::to_f32(yv[it].v[e]);
+                    const float g = Elem<T>::to_f32(c.v[e]) * leaky01_slope(fmaf(yf, sc[e], sh[e]));
+                    s1[e] += g;
+                    s2[e] = fmaf(g, yf, s2[e]);
                 }
             }
         }
-    };
-    if (mw0 + TP * 32 <= a.M) sweep(std::true_type{});   // wave-uniform
-    else sweep(std::false_type{});
-    if (stats) {
+    }
+    if (stats || bw) {
         // lane partials -> the wave's own patch (dead now: a wave's LDS operations retire in order),
         // then one thread per block channel adds the RPIe row groups of the WP waves
         float* sw = (float*)ew;   // [2][64][EPC]
@@ -172,13 +213,18 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
             }
             const int co = n0 + c;
             if (co < a.ldy) {
-                const float md = S1 * inv;
-                const float pb = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-                a.part_mean[(size_t)pt * a.ldy + co] = pb + md;
-                a.part_m2[(size_t)pt * a.ldy + co] = fmaxf(S2 - S1 * md, 0.f);
+                if (bw) {
+                    a.bw_psum[((size_t)pt * 2 + 0) * a.ldy + co] = S1;
+                    a.bw_psum[((size_t)pt * 2 + 1) * a.ldy + co] = S2;
+                } else {
+                    const float md = S1 * inv;
+                    const float pb = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+                    a.part_mean[(size_t)pt * a.ldy + co] = pb + md;
+                    a.part_m2[(size_t)pt * a.ldy + co] = fmaxf(S2 - S1 * md, 0.f);
+                }
             }
         }
-        if (threadIdx.x == 0 && ct == 0) a.part_cnt[pt] = (float)cb;
+        if (stats && threadIdx.x == 0 && ct == 0) a.part_cnt[pt] = (float)cb;
     }
 }
 

@@ -22,6 +22,15 @@ struct ConvArgs {
     int Cout;
     int ldy;
     int taps;           // 9 (3x3) or 1 (1x1)
+    // dgrad launches only: the batch-norm backward REDUCE pass of the layer below, fused into this epilogue.
+    // y (this launch's output) is dA of that layer; with bw_y = its conv output at the same pixels (a pooled
+    // layer: at the window's arg-max, BnActArgs::ysel) and its scale / shift the epilogue accumulates
+    // S1 = sum g and S2 = sum g * y, g = dA * leaky'(y * scale + shift), per pixel tile:
+    // bw_psum[tile][2][ldy] -- what bn_bwd_kernel<.., APPLY = false> would write.
+    const void* bw_y = nullptr;       // [M][ldy]
+    const float* bw_scale = nullptr;
+    const float* bw_shift = nullptr;
+    float* bw_psum = nullptr;
 };
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
@@ -119,14 +128,30 @@ hipError_t launch_pack_conv1_weights(int dtype, const float* W, void* wp, hipStr
 // all layers in one launch: table entry per layer (device copy lives in the workspace)
 struct PackLayer {
     const float* W;
+    size_t w_off;       // offset of W in the flat parameter buffer (adam_pack: the same offset into m, v, grads)
     void* wf;
     void* wd;           // null: no dgrad copy
     int taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy;
     int wf_bx, wf_by, wf_blocks, wd_blocks, first_block;
+    int opt_first;      // first tile block of this layer in launch_opt_pack's grid (tiles only)
     int wf_frag, wd_frag;   // conv_filter_layout(): 0 K-contiguous rows, 1 / 2 MFMA-fragment order (32 / 16 rows)
 };
 void pack_layer_plan(PackLayer& L, int first_block, int elem_size);
 hipError_t launch_pack_all(int dtype, const PackLayer* tab_dev, int nlayers, int total_blocks, hipStream_t s);
+// Optimizer step + filter re-pack in ONE pass over the parameters (the update reads and writes every filter
+// anyway: the packed f16 / bf16 copies leave from the same registers instead of a second 193 MB read).
+// kind 0: Adam (slot0 = m, slot1 = v), 1: Momentum (slot0 = accum).  ctrl != null: guarded (optim.hip), lr_t from
+// ctrl; else lr_t = hyper[0].  hyper = {lr_t or lr, b1 or momentum, b2, eps, grad_mult}.
+// small: [offset, count] ranges of the parameters that are not filter tiles (b, gamma, beta; a 3-channel first filter)
+struct OptPackArgs {
+    float* p; float* slot0; float* slot1; const float* g;
+    const void* ctrl;
+    float lr_t, b1, b2, eps, gmult;
+    int kind;
+    const PackLayer* tab; int nlayers; int tile_blocks;
+    const unsigned* small; int nsmall;
+};
+hipError_t launch_opt_pack(int dtype, const OptPackArgs& a, hipStream_t s);
 hipError_t launch_convert_grad(int dtype, const float* src, void* dst, int M, int C, int ldd, float scale,
                                hipStream_t s);
 hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H, int W, int C, int Cs,
@@ -168,6 +193,8 @@ struct BnActArgs {
     int N, H, W, C, ldy;
     int pool;             // 2x2/2 SAME max pool after the activation
     int out_f32;
+    void* ysel = nullptr; // pooled layers, training: the conv output at the window's (first) arg-max, [Mout][ldy] of T --
+                          // what the BN-backward reduce needs of y (fused into the dgrad epilogue above this layer)
 };
 hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t s);
 
@@ -226,8 +253,9 @@ hipError_t launch_adam(float* p, float* m, float* v, const float* g, size_t n, f
 hipError_t launch_momentum(float* p, float* acc, const float* g, size_t n, float lr, float mom, float gscale,
                            hipStream_t s);
 // dynamic loss scaling: ctrl = {int found_inf, int step, int skipped, float lr_t}
-hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, float* scratch, float lr, float b1, float b2,
-                             hipStream_t s);
+hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, hipStream_t s);
+hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s);
+hipError_t launch_opt_ctrl_advance(void* ctrl, float lr, float b1, float b2, hipStream_t s);
 hipError_t launch_adam_guarded(float* p, float* m, float* v, const float* g, size_t n, const void* ctrl, float b1,
                                float b2, float eps, float gscale, hipStream_t s);
 hipError_t launch_momentum_guarded(float* p, float* acc, const float* g, size_t n, const void* ctrl, float lr, float mom,

@@ -72,7 +72,7 @@ struct Layer {
     size_t pW, pb, pg, pbeta;  // float offsets into params / grads
     size_t smm, smv;           // float offsets into state
     // byte offsets into the workspace
-    size_t xin, y, stat, wf, wd, dyp;
+    size_t xin, y, stat, wf, wd, dyp, ysel;
 };
 
 struct y2_ctx {
@@ -98,7 +98,8 @@ struct y2_ctx {
     size_t part_rows, part_ld;
     size_t total_infer = 0, total_train = 0;
     int dA_cur = 0;
-    size_t o_packtab = 0;
+    size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0;
+    int n_chkranges = 0, n_smallranges = 0, opt_tile_blocks = 0;
     std::vector<PackLayer> packtab;
     int pack_blocks = 0;
     // optional per-launch HIP-event bracketing (bench.py roofline leg)
@@ -185,10 +186,23 @@ static void plan(y2_ctx* c) {
     c->o_part_m2 = take(max_slab * sizeof(float));
     c->o_h32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
     c->o_packtab = take(c->L.size() * sizeof(PackLayer));
+    c->o_chkranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
+    c->o_smallranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
     c->total_infer = off;
     // ---- training-only buffers
     for (size_t l = 0; l < c->L.size(); ++l) c->L[l].dyp = take(c->dy_geom((int)l).bytes(sz));
-    c->o_psum = take((size_t)2048 * 2 * max_ld * sizeof(float));
+    for (size_t l = 0; l < c->L.size(); ++l) {   // pooled layers: conv output at the arg-max (BnActArgs::ysel)
+        Layer& y = c->L[l];
+        y.ysel = (y.pool && !y.first3) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
+    }
+    // BN-backward partial sums [P][2][ldy]: P <= 2048 from the reduce kernel, or one record per 128+ pixel tile
+    // of the dgrad above when the reduce is fused into that dgrad's epilogue
+    size_t psum_floats = (size_t)2048 * 2 * max_ld;
+    for (size_t l = 1; l < c->L.size(); ++l) {
+        const size_t rows = ((size_t)c->L[l].M + 127) / 128;
+        psum_floats = std::max(psum_floats, rows * 2 * (size_t)c->L[l - 1].ldy);
+    }
+    c->o_psum = take(psum_floats * sizeof(float));
     c->o_dA0 = take(max_dA * sz + 256);
     c->o_dA1 = take(max_dA * sz + 256);
     c->o_dh32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
@@ -416,12 +430,13 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
     HIPCHK(hipMemsetAsync(workspace, 0, need, (hipStream_t)stream));
     // filter re-pack job table (one launch per step for all layers)
     c->packtab.clear();
-    int nb = 0;
+    int nb = 0, ntile = 0;
     for (size_t l = 0; l < c->L.size(); ++l) {
         const Layer& y = c->L[l];
         if (y.first3) continue;
         PackLayer p{};
         p.W = params + y.pW;
+        p.w_off = y.pW;
         p.wf = c->ws + y.wf;
         p.wd = (training && l > 0) ? (void*)(c->ws + y.wd) : nullptr;
         p.taps = y.k * y.k; p.Cin = y.cin; p.Cout = y.cout; p.Cout_pad = y.cout_pad; p.Kc = y.cin_s;
@@ -430,9 +445,38 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
         p.wd_frag = conv_filter_layout(p.taps, y.W, y.ldy * (int)c->sz(), y.cin, y.M);      // dgrad launch: Cout = cin
         pack_layer_plan(p, nb, (int)c->sz());
         nb += p.wf_blocks + p.wd_blocks;
+        p.opt_first = ntile;
+        ntile += p.wf_blocks;
         c->packtab.push_back(p);
     }
     c->pack_blocks = nb;
+    c->opt_tile_blocks = ntile;
+    {   // parameters outside the filter tiles of the fused optimizer + re-pack pass
+        std::vector<unsigned> rg;
+        for (size_t l = 0; l < c->L.size(); ++l) {
+            rg.push_back((unsigned)c->L[l].pb);
+            rg.push_back((unsigned)(3 * c->L[l].cout));
+        }
+        if (c->L[0].first3) {
+            rg.push_back((unsigned)c->L[0].pW);
+            rg.push_back((unsigned)(27 * c->L[0].cout));
+        }
+        c->n_smallranges = (int)(rg.size() / 2);
+        HIPCHK(hipMemcpyAsync(c->ws + c->o_smallranges, rg.data(), rg.size() * sizeof(unsigned), hipMemcpyHostToDevice,
+                              (hipStream_t)stream));
+    }
+    {   // sentinel ranges of y2_grad_check: b, gamma, beta of every layer (contiguous) + the first filter
+        std::vector<unsigned> rg;
+        for (size_t l = 0; l < c->L.size(); ++l) {
+            rg.push_back((unsigned)c->L[l].pb);
+            rg.push_back((unsigned)(3 * c->L[l].cout));
+        }
+        rg.push_back((unsigned)c->L[0].pW);
+        rg.push_back((unsigned)((size_t)c->L[0].k * c->L[0].k * c->L[0].cin * c->L[0].cout));
+        c->n_chkranges = (int)(rg.size() / 2);
+        HIPCHK(hipMemcpyAsync(c->ws + c->o_chkranges, rg.data(), rg.size() * sizeof(unsigned), hipMemcpyHostToDevice,
+                              (hipStream_t)stream));
+    }
     if (!c->packtab.empty())
         HIPCHK(hipMemcpyAsync(c->ws + c->o_packtab, c->packtab.data(), c->packtab.size() * sizeof(PackLayer),
                               hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -560,6 +604,7 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             b.out = (c->tail == Y2_TAIL_AVGPOOL) ? (void*)(c->ws + c->o_h32) : (void*)out;
             b.out_f32 = 1;
         }
+        if (y.pool && c->bound_training && y.ysel) b.ysel = c->ws + y.ysel;
         HIPCHK(launch_bn_act(c->dtype, b, s));
     }
     if (c->tail == Y2_TAIL_AVGPOOL) {
@@ -617,6 +662,8 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
     }
     float* psum = (float*)(c->ws + c->o_psum);
     bool forked = false;
+    int fused_P = 0;          // > 0: the dgrad of the layer above already reduced this layer's BN-backward sums
+    static const bool no_fuse = getenv("Y2_NO_BNBWD_FUSE") != nullptr;
     if (c->overlap_wgrad && !c->side) {
         static const bool off = getenv("Y2_NO_WGRAD_OVERLAP") != nullptr;
         if (off) c->overlap_wgrad = 0;
@@ -655,9 +702,12 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 q.nblocks = (tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4;
                 b.P = q.nblocks;
                 HIPCHK(launch_conv1_bnbwd_reduce(c->dtype, q, s));
+            } else if (fused_P > 0) {
+                b.P = fused_P;
             } else {
                 HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
             }
+            fused_P = 0;
             HIPCHK(launch_bn_bwd_finalize(b, s));
             if (!fused1) HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
         }
@@ -694,7 +744,19 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
                 a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.ldy; a.M = y.M; a.Cout = y.cin; a.ldy = y.cin;
                 a.taps = y.k * y.k;
-                { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s)); }
+                int bp = 0;
+                const Layer& z = c->L[l - 1];
+                // the BN-backward reduce of the layer below rides in this dgrad's epilogue (it needs that layer's
+                // conv output, scale and shift beside the dA tile the epilogue holds anyway); the first layer
+                // keeps its own recomputing reduce
+                const bool fuse = !no_fuse && l - 1 >= layer_lo && !z.first3 && z.ldy == y.cin;
+                if (fuse) {
+                    float* zs = (float*)(c->ws + z.stat);
+                    a.bw_y = c->ws + (z.pool ? z.ysel : z.y);   // same pixel grid as this launch's output either way
+                    a.bw_scale = zs; a.bw_shift = zs + z.ldy; a.bw_psum = psum;
+                }
+                { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s, &bp)); }
+                if (fuse) fused_P = (y.M + bp - 1) / bp;
                 c->dA_cur ^= 1;
             }
         }
@@ -820,21 +882,66 @@ int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n
     return Y2_OK;
 }
 // Loss-scale-safe forms of the two optimizers: `ctrl` = 8 caller-owned, zero-initialised 32-bit words on the
-// device {found_inf, step, skipped, ticket, lr_t, -, -, -}.  A gradient buffer with any inf / NaN leaves
-// params, slots and the step counter untouched (ctrl.found_inf = 1, ctrl.skipped += 1).
+// device {found_inf, step, skipped, -, lr_t, -, -, -}.  First one of the two scans sets ctrl.found_inf
+// (y2_grad_check: the context's sentinel ranges, ~30 k floats; y2_grad_check_full: every element of any buffer),
+// then the guarded step: a gradient buffer flagged non-finite leaves params, slots and the step counter
+// untouched (ctrl.skipped += 1).
+int y2_grad_check(y2_ctx* c, void* ctrl, void* stream) {
+    if (!c->grads || !ctrl) return fail(Y2_ERR_ARG, "bind with a gradient buffer first");
+    HIPCHK(launch_grad_check_ranges(c->grads, c->ws + c->o_chkranges, c->n_chkranges, ctrl, (hipStream_t)stream));
+    return Y2_OK;
+}
+int y2_grad_check_full(const float* grads, size_t n, void* ctrl, void* stream) {
+    if (!grads || !ctrl) return fail(Y2_ERR_ARG, "bad arguments");
+    HIPCHK(launch_grad_check(grads, n, ctrl, (hipStream_t)stream));
+    return Y2_OK;
+}
 int y2_adam_step_guarded(float* params, float* m, float* v, const float* grads, size_t n, void* ctrl, float lr,
                          float beta1, float beta2, float eps, float grad_mult, void* stream) {
     if (!params || !m || !v || !grads || !ctrl) return fail(Y2_ERR_ARG, "bad arguments");
-    HIPCHK(launch_grad_check(grads, n, ctrl, nullptr, lr, beta1, beta2, (hipStream_t)stream));
+    HIPCHK(launch_opt_ctrl_advance(ctrl, lr, beta1, beta2, (hipStream_t)stream));
     HIPCHK(launch_adam_guarded(params, m, v, grads, n, ctrl, beta1, beta2, eps, grad_mult, (hipStream_t)stream));
     return Y2_OK;
 }
 int y2_momentum_step_guarded(float* params, float* accum, const float* grads, size_t n, void* ctrl, float lr,
                              float momentum, float grad_mult, void* stream) {
     if (!params || !accum || !grads || !ctrl) return fail(Y2_ERR_ARG, "bad arguments");
-    HIPCHK(launch_grad_check(grads, n, ctrl, nullptr, lr, 0.9f, 0.999f, (hipStream_t)stream));
+    HIPCHK(launch_opt_ctrl_advance(ctrl, lr, 0.9f, 0.999f, (hipStream_t)stream));
     HIPCHK(launch_momentum_guarded(params, accum, grads, n, ctrl, lr, momentum, grad_mult, (hipStream_t)stream));
     return Y2_OK;
+}
+// Optimizer step of the context's bound params / grads fused with the filter re-pack (pack.hip opt_pack_kernel):
+// every filter is read and written by the update anyway, so its MFMA-operand copies (forward and dgrad layouts)
+// leave in the same pass -- the separate re-pack of the next y2_forward (193 MB read again) is not needed.
+// ctrl (nullable): the overflow guard of y2_adam_step_guarded (run y2_grad_check first); NULL: plain step `step`.
+static int opt_step_packed(y2_ctx* c, int kind, float* slot0, float* slot1, void* ctrl, float lr_t_or_lr, float b1,
+                           float b2, float eps, float grad_mult, hipStream_t s) {
+    if (!c->ws || !c->grads || !c->bound_training) return fail(Y2_ERR_STATE, "bind with training=1 first");
+    OptPackArgs a{};
+    a.p = c->params; a.slot0 = slot0; a.slot1 = slot1; a.g = c->grads; a.ctrl = ctrl;
+    a.lr_t = lr_t_or_lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.gmult = grad_mult; a.kind = kind;
+    a.tab = (const PackLayer*)(c->ws + c->o_packtab); a.nlayers = (int)c->packtab.size();
+    a.tile_blocks = c->opt_tile_blocks;
+    a.small = (const unsigned*)(c->ws + c->o_smallranges); a.nsmall = c->n_smallranges;
+    HIPCHK(launch_opt_pack(c->dtype, a, s));
+    if (!c->L.empty() && c->L[0].first3)
+        HIPCHK(launch_pack_conv1_weights(c->dtype, c->params + c->L[0].pW, c->ws + c->L[0].wf, s));
+    c->weights_dirty = false;
+    return Y2_OK;
+}
+int y2_adam_step_packed(y2_ctx* c, float* m, float* v, void* ctrl, int step, float lr, float beta1, float beta2,
+                        float eps, float grad_mult, void* stream) {
+    if (!m || !v || (!ctrl && step < 1)) return fail(Y2_ERR_ARG, "bad arguments");
+    double lr_t = lr;
+    if (ctrl) HIPCHK(launch_opt_ctrl_advance(ctrl, lr, beta1, beta2, (hipStream_t)stream));
+    else lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    return opt_step_packed(c, 0, m, v, ctrl, (float)lr_t, beta1, beta2, eps, grad_mult, (hipStream_t)stream);
+}
+int y2_momentum_step_packed(y2_ctx* c, float* accum, void* ctrl, float lr, float momentum, float grad_mult,
+                            void* stream) {
+    if (!accum) return fail(Y2_ERR_ARG, "bad arguments");
+    if (ctrl) HIPCHK(launch_opt_ctrl_advance(ctrl, lr, 0.9f, 0.999f, (hipStream_t)stream));
+    return opt_step_packed(c, 1, accum, nullptr, ctrl, lr, momentum, 0.f, 0.f, grad_mult, (hipStream_t)stream);
 }
 int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, float lr, float momentum,
                      float grad_mult, void* stream) {

@@ -6,6 +6,7 @@
 // tf.truncated_normal(stddev=0.1) / tf.constant(0.1) (src/yolo2_nets/darknet.py:10-17).
 #include "common.h"
 #include "kernels.h"
+#include "optim_math.h"
 
 namespace y2 {
 
@@ -16,21 +17,14 @@ __global__ void adam_kernel(float4* p, float4* m, float4* v, const float4* g, si
         float4 pp = p[i], mm = m[i], vv = v[i], gg = g[i];
         float* P = &pp.x; float* M = &mm.x; float* V = &vv.x; const float* G = &gg.x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = G[k] * gscale;
-            M[k] = b1 * M[k] + (1.0f - b1) * gk;
-            V[k] = b2 * V[k] + (1.0f - b2) * gk * gk;
-            P[k] = P[k] - lr_t * M[k] / (sqrtf(V[k]) + eps);
-        }
+        for (int k = 0; k < 4; ++k) adam_update(P[k], M[k], V[k], G[k] * gscale, lr_t, b1, b2, eps);
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
     if (blockIdx.x == 0) {
         for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) {
-            const float gk = gt[i] * gscale;
-            const float mk = b1 * mt[i] + (1.0f - b1) * gk;
-            const float vk = b2 * vt[i] + (1.0f - b2) * gk * gk;
-            mt[i] = mk; vt[i] = vk;
-            pt[i] = pt[i] - lr_t * mk / (sqrtf(vk) + eps);
+            float pk = pt[i], mk = mt[i], vk = vt[i];
+            adam_update(pk, mk, vk, gt[i] * gscale, lr_t, b1, b2, eps);
+            mt[i] = mk; vt[i] = vk; pt[i] = pk;
         }
     }
 }
@@ -47,9 +41,10 @@ hipError_t launch_adam(float* p, float* m, float* v, const float* g, size_t n, f
 
 __global__ void momentum_kernel(float* p, float* acc, const float* g, size_t n, float lr, float mom, float gscale) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float a = mom * acc[i] + g[i] * gscale;
+        float pk = p[i], a = acc[i];
+        momentum_update(pk, a, g[i] * gscale, lr, mom);
         acc[i] = a;
-        p[i] = p[i] - lr * a;
+        p[i] = pk;
     }
 }
 hipError_t launch_momentum(float* p, float* acc, const float* g, size_t n, float lr, float mom, float gscale,
@@ -71,10 +66,11 @@ hipError_t launch_momentum(float* p, float* acc, const float* g, size_t n, float
 //   *_guarded  : the optimizer kernels above, skipped as a whole when ctrl.found_inf is set
 // No host synchronisation: the host reads ctrl one step late to adapt grad_scale.
 // ---------------------------------------------------------------------------
-struct OptCtrl { int found_inf, step, skipped, ticket; float lr_t; int pad[3]; };
+struct OptCtrl { int found_inf, step, skipped, reserved; float lr_t; int pad[3]; };
 
+// full scan (y2_grad_check_full: any flat buffer)
 __global__ __launch_bounds__(256) void grad_check_kernel(const float4* g, size_t n4, const float* gt, size_t tail0,
-                                                         size_t n, OptCtrl* ctrl, float lr, float b1, float b2) {
+                                                         size_t n, OptCtrl* ctrl) {
     // |x| < inf  <=>  exponent bits != all ones; OR the exponent tests of a whole thread, then of the block
     unsigned bad = 0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -86,42 +82,57 @@ __global__ __launch_bounds__(256) void grad_check_kernel(const float4* g, size_t
     if (blockIdx.x == 0)
         for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x)
             bad |= (__float_as_uint(gt[i]) & 0x7F800000u) == 0x7F800000u;
-    __shared__ int sbad, last;
-    if (threadIdx.x == 0) sbad = 0;
-    __syncthreads();
-    if (bad) atomicOr(&sbad, 1);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (sbad) atomicOr(&ctrl->found_inf, 1);
-        __threadfence();
-        last = (atomicAdd(&ctrl->ticket, 1) == (int)gridDim.x - 1);
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
-        const int inf = atomicOr(&ctrl->found_inf, 0);
-        if (inf) {
-            ctrl->skipped += 1;
-        } else {
-            const int t = ctrl->step + 1;
-            ctrl->step = t;
-            // TF: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
-            ctrl->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
-        }
-        ctrl->ticket = 0;
-    }
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ctrl->found_inf, 1);
 }
-hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, float* scratch, float lr, float b1, float b2,
-                             hipStream_t s) {
-    (void)scratch;
+hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, hipStream_t s) {
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int), s);   // found_inf of the previous step
     if (e != hipSuccess) return e;
     const size_t n4 = n / 4;
-    size_t nb = (n4 + 255) / 256;
+    size_t nb = (n4 + 1023) / 1024;
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(grad_check_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float4*)g, n4, g, n4 * 4, n,
-                       (OptCtrl*)ctrl, lr, b1, b2);
+                       (OptCtrl*)ctrl);
+    return hipGetLastError();
+}
+
+// Sentinel scan (y2_grad_check): a non-finite value anywhere in the backward pass reaches the checked ranges.
+//   * an inf / NaN in dA of layer l makes S1 = sum(dz) of its channel non-finite -> dbeta_l (checked), and through
+//     ka = f(S1) every dy of that channel -> dW_l, and through the dgrad every layer below;
+//   * a dy that overflows only at its own f16 store (finite sums) is an inf operand of dgrad_l -> dA_{l-1} -> dbeta_{l-1};
+//     in the first layer (no dgrad below it) dy feeds the filter gradient directly -> dW_0 (checked whole).
+// ranges: [offset, count] pairs of the flat gradient buffer: b / gamma / beta of every layer + the first filter.
+__global__ __launch_bounds__(256) void grad_check_ranges_kernel(const float* g, const unsigned* ranges, int nranges,
+                                                                OptCtrl* ctrl) {
+    unsigned bad = 0;
+    for (int r = blockIdx.x; r < nranges; r += gridDim.x) {
+        const float* p = g + ranges[2 * r];
+        const unsigned cnt = ranges[2 * r + 1];
+        for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x)
+            bad |= (__float_as_uint(p[i]) & 0x7F800000u) == 0x7F800000u;
+    }
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ctrl->found_inf, 1);
+}
+hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(grad_check_ranges_kernel, dim3(nranges < 64 ? nranges : 64), dim3(256), 0, s, g,
+                       (const unsigned*)ranges_dev, nranges, (OptCtrl*)ctrl);
+    return hipGetLastError();
+}
+
+// after either scan: finite -> step += 1 and TF's lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) for it; else skipped += 1
+__global__ void opt_ctrl_advance_kernel(OptCtrl* ctrl, float lr, float b1, float b2) {
+    if (ctrl->found_inf) {
+        ctrl->skipped += 1;
+    } else {
+        const int t = ctrl->step + 1;
+        ctrl->step = t;
+        ctrl->lr_t = (float)((double)lr * sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+    }
+}
+hipError_t launch_opt_ctrl_advance(void* ctrl, float lr, float b1, float b2, hipStream_t s) {
+    hipLaunchKernelGGL(opt_ctrl_advance_kernel, dim3(1), dim3(1), 0, s, (OptCtrl*)ctrl, lr, b1, b2);
     return hipGetLastError();
 }
 
@@ -134,21 +145,14 @@ __global__ void adam_guarded_kernel(float4* p, float4* m, float4* v, const float
         float4 pp = p[i], mm = m[i], vv = v[i], gg = g[i];
         float* P = &pp.x; float* M = &mm.x; float* V = &vv.x; const float* G = &gg.x;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = G[k] * gscale;
-            M[k] = b1 * M[k] + (1.0f - b1) * gk;
-            V[k] = b2 * V[k] + (1.0f - b2) * gk * gk;
-            P[k] = P[k] - lr_t * M[k] / (sqrtf(V[k]) + eps);
-        }
+        for (int k = 0; k < 4; ++k) adam_update(P[k], M[k], V[k], G[k] * gscale, lr_t, b1, b2, eps);
         p[i] = pp; m[i] = mm; v[i] = vv;
     }
     if (blockIdx.x == 0) {
         for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) {
-            const float gk = gt[i] * gscale;
-            const float mk = b1 * mt[i] + (1.0f - b1) * gk;
-            const float vk = b2 * vt[i] + (1.0f - b2) * gk * gk;
-            mt[i] = mk; vt[i] = vk;
-            pt[i] = pt[i] - lr_t * mk / (sqrtf(vk) + eps);
+            float pk = pt[i], mk = mt[i], vk = vt[i];
+            adam_update(pk, mk, vk, gt[i] * gscale, lr_t, b1, b2, eps);
+            mt[i] = mk; vt[i] = vk; pt[i] = pk;
         }
     }
 }
@@ -166,9 +170,10 @@ __global__ void momentum_guarded_kernel(float* p, float* acc, const float* g, si
                                         float mom, float gscale) {
     if (ctrl->found_inf) return;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float a = mom * acc[i] + g[i] * gscale;
+        float pk = p[i], a = acc[i];
+        momentum_update(pk, a, g[i] * gscale, lr, mom);
         acc[i] = a;
-        p[i] = p[i] - lr * a;
+        p[i] = pk;
     }
 }
 hipError_t launch_momentum_guarded(float* p, float* acc, const float* g, size_t n, const void* ctrl, float lr, float mom,

@@ -3,6 +3,7 @@
 // MI355X-side layouts (zero-bordered NHWC of T, K-contiguous packed filters).
 #include "common.h"
 #include "kernels.h"
+#include "optim_math.h"
 
 namespace y2 {
 
@@ -299,6 +300,147 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// Optimizer update fused with the filter re-pack (kernels.h: OptPackArgs).  One block = one 64 (ci) x 64 (co)
+// tile of one tap of one layer: p, slot(s), g in (16-byte loads, 256-byte rows), update, p / slots out, and the
+// updated tile leaves a second and third time in the MFMA operand type: co-contiguous rows to the dgrad copy
+// (tap-flipped), and through a 64 x 64 LDS transpose to the forward copy.  Blocks past the tiles update the
+// small ranges (b, gamma, beta, a 3-channel first filter) with the plain flat form.
+// ---------------------------------------------------------------------------
+struct OptCtrlView { int found_inf, step, skipped, reserved; float lr_t; };
+
+template <int KIND>
+Y2_DEV void opt_update(float& p, float& s0, float& s1, float g, float lr_t, float b1, float b2, float eps) {
+    if (KIND == 0) adam_update(p, s0, s1, g, lr_t, b1, b2, eps);
+    else momentum_update(p, s0, g, lr_t, b1);
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void opt_pack_kernel(OptPackArgs a) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int CPR = 64 / EPC;
+    constexpr int RPP = 256 / CPR;
+    float lr_t = a.lr_t;
+    if (a.ctrl) {
+        const OptCtrlView* c = (const OptCtrlView*)a.ctrl;
+        if (c->found_inf) return;          // overflowed gradients: nothing moves, the packed copies stay valid
+        if (KIND == 0) lr_t = c->lr_t;
+    }
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b >= a.tile_blocks) {
+        // small ranges: grid-stride over the concatenation of the ranges
+        const int nb = gridDim.x - a.tile_blocks, bi = b - a.tile_blocks;
+        for (int r = 0; r < a.nsmall; ++r) {
+            const unsigned off = a.small[2 * r], cnt = a.small[2 * r + 1];
+            for (unsigned i = bi * 256 + tid; i < cnt; i += nb * 256) {
+                float p = a.p[off + i], s0 = a.slot0[off + i], s1 = KIND == 0 ? a.slot1[off + i] : 0.f;
+                opt_update<KIND>(p, s0, s1, a.g[off + i] * a.gmult, lr_t, a.b1, a.b2, a.eps);
+                a.p[off + i] = p; a.slot0[off + i] = s0;
+                if (KIND == 0) a.slot1[off + i] = s1;
+            }
+        }
+        return;
+    }
+    __shared__ float tile[64][65];
+    int l = 0;
+    while (l + 1 < a.nlayers && b >= a.tab[l + 1].opt_first) ++l;
+    const PackLayer L = a.tab[l];
+    const int local = b - L.opt_first;
+    const int bx = local % L.wf_bx, by = (local / L.wf_bx) % L.wf_by, t = local / (L.wf_bx * L.wf_by);
+    const int ci0 = by * 64, co0 = bx * 64;
+    // ---- update: thread = 4 consecutive co of one ci row per pass (16 lanes per 256-byte row, 16 rows per pass)
+    const int c4 = (tid & 15) * 4, r0 = tid >> 4;
+    const bool vec = (L.Cout & 3) == 0;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int r = pass * 16 + r0;
+        const int ci = ci0 + r, co = co0 + c4;
+        float pv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ci < L.Cin && co < L.Cout) {
+            const size_t o = L.w_off + ((size_t)t * L.Cin + ci) * L.Cout + co;
+            if (vec) {
+                f32x4 p = *(const f32x4*)(a.p + o), s0 = *(const f32x4*)(a.slot0 + o), g = *(const f32x4*)(a.g + o);
+                f32x4 s1 = KIND == 0 ? *(const f32x4*)(a.slot1 + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float pk = p[k], ak = s0[k], bk = s1[k];
+                    opt_update<KIND>(pk, ak, bk, g[k] * a.gmult, lr_t, a.b1, a.b2, a.eps);
+                    p[k] = pk; s0[k] = ak; s1[k] = bk; pv[k] = pk;
+                }
+                *(f32x4*)(a.p + o) = p; *(f32x4*)(a.slot0 + o) = s0;
+                if (KIND == 0) *(f32x4*)(a.slot1 + o) = s1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (co + k < L.Cout) {
+                        float pk = a.p[o + k], ak = a.slot0[o + k], bk = KIND == 0 ? a.slot1[o + k] : 0.f;
+                        opt_update<KIND>(pk, ak, bk, a.g[o + k] * a.gmult, lr_t, a.b1, a.b2, a.eps);
+                        a.p[o + k] = pk; a.slot0[o + k] = ak;
+                        if (KIND == 0) a.slot1[o + k] = bk;
+                        pv[k] = pk;
+                    }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[r][c4 + k] = pv[k];
+    }
+    __syncthreads();
+    // ---- dgrad copy wd[ci][taps-1-t][co]: rows stay co-contiguous (16-byte chunks of EPC couts)
+    if (L.wd) {
+        T* __restrict__ wd = (T*)L.wd;
+        const int tt = L.taps - 1 - t;
+        const int cs = tid % CPR, cr = tid / CPR;
+#pragma unroll
+        for (int p = 0; p < 64 / RPP; ++p) {
+            const int r = p * RPP + cr;
+            const int ci = ci0 + r, co = co0 + cs * EPC;
+            if (ci < L.Cin_pad && co < L.Cdy) {
+                Chunk<T> o;
+#pragma unroll
+                for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[r][cs * EPC + k]);
+                if (L.wd_frag) st_chunk<T>(wd + frag_chunk_any(L.wd_frag, ci, tt, co, L.taps, L.Cdy, EPC) * EPC, o);
+                else st_chunk<T>(wd + ((size_t)ci * L.taps + tt) * L.Cdy + co, o);
+            }
+        }
+    }
+    // ---- forward copy wf[co][t][ci]: the transpose
+    {
+        T* __restrict__ wf = (T*)L.wf;
+        const int cs = tid % CPR, cr = tid / CPR;
+#pragma unroll
+        for (int p = 0; p < 64 / RPP; ++p) {
+            const int col = p * RPP + cr;
+            const int co = co0 + col, ci = ci0 + cs * EPC;
+            if (co < L.Cout_pad && ci < L.Kc) {
+                Chunk<T> o;
+#pragma unroll
+                for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[cs * EPC + k][col]);
+                if (L.wf_frag) st_chunk<T>(wf + frag_chunk_any(L.wf_frag, co, t, ci, L.taps, L.Kc, EPC) * EPC, o);
+                else st_chunk<T>(wf + ((size_t)co * L.taps + t) * L.Kc + ci, o);
+            }
+        }
+    }
+}
+
+hipError_t launch_opt_pack(int dtype, const OptPackArgs& a, hipStream_t s) {
+    const int small_blocks = a.nsmall > 0 ? 64 : 0;
+    dim3 g(a.tile_blocks + small_blocks), b(256);
+    if (g.x == 0) return hipSuccess;
+#define Y2_OP(T, K) hipLaunchKernelGGL((opt_pack_kernel<T, K>), g, b, 0, s, a)
+    switch (dtype * 2 + a.kind) {
+        case 0: Y2_OP(float, 0); break;
+        case 1: Y2_OP(float, 1); break;
+        case 2: Y2_OP(half_t, 0); break;
+        case 3: Y2_OP(half_t, 1); break;
+        case 4: Y2_OP(bf16_t, 0); break;
+        case 5: Y2_OP(bf16_t, 1); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef Y2_OP
+    return hipGetLastError();
 }
 
 void pack_layer_plan(PackLayer& L, int first_block, int elem_size) {

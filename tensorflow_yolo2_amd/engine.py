@@ -292,6 +292,13 @@ class LossScaler:
             self.nets.append(net)
             net.set_grad_scale(self.scale)
 
+    def scan(self, net, full=False):
+        """set ctrl.found_inf from net's gradient buffer: sentinel ranges (default) or every element"""
+        if full:
+            check(net.lib.y2_grad_check_full(_ptr(net.grads), net.n_params, _ptr(self.ctrl), _stream()))
+        else:
+            check(net.lib.y2_grad_check(net.h, _ptr(self.ctrl), _stream()))
+
     def after_step(self):
         """call right after the guarded optimizer launch of a step"""
         if self._event is not None:          # the copy issued after the PREVIOUS step has long finished
@@ -321,26 +328,37 @@ class AdamOptimizer:
     guard=True (default for the f16 mode): the overflow-safe kernels + LossScaler; the step counter then lives
     on the device (`t` mirrors it assuming no skipped step; `scaler.state()` is authoritative)."""
 
-    def __init__(self, net, learning_rate=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8, guard=None):
+    def __init__(self, net, learning_rate=1e-3, beta1=0.9, beta2=0.999, epsilon=1e-8, guard=None, fused_pack=True):
         self.net, self.lr, self.b1, self.b2, self.eps = net, learning_rate, beta1, beta2, epsilon
+        self.fused_pack = bool(fused_pack)
         self.m = torch.zeros_like(net.params)
         self.v = torch.zeros_like(net.params)
         self.t = 0
         self.guard = (net.dtype == _lib.Y2_F16) if guard is None else bool(guard)
         self.scaler = LossScaler(net) if self.guard else None
 
-    def step(self, grad_mult=1.0):
+    def step(self, grad_mult=1.0, full_check=False):
+        """full_check: scan every gradient element instead of the sentinel ranges (a gradient buffer that was
+        not produced by this context's backward pass)"""
         self.t += 1
         n = self.net
         if self.guard:
+            self.scaler.scan(n, full_check)
+        ctrl = _ptr(self.scaler.ctrl) if self.guard else C.c_void_p(0)
+        if self.fused_pack and n.training:
+            # update + filter re-pack in one pass over the parameters (the context's packed copies stay current)
+            check(n.lib.y2_adam_step_packed(n.h, _ptr(self.m), _ptr(self.v), ctrl, self.t, self.lr, self.b1, self.b2,
+                                            self.eps, grad_mult, _stream()))
+        elif self.guard:
             check(n.lib.y2_adam_step_guarded(_ptr(n.params), _ptr(self.m), _ptr(self.v), _ptr(n.grads), n.n_params,
-                                             _ptr(self.scaler.ctrl), self.lr, self.b1, self.b2, self.eps,
-                                             grad_mult, _stream()))
-            self.scaler.after_step()
+                                             ctrl, self.lr, self.b1, self.b2, self.eps, grad_mult, _stream()))
+            n.params_changed()
         else:
             check(n.lib.y2_adam_step(_ptr(n.params), _ptr(self.m), _ptr(self.v), _ptr(n.grads), n.n_params, self.t,
                                      self.lr, self.b1, self.b2, self.eps, grad_mult, _stream()))
-        n.params_changed()
+            n.params_changed()
+        if self.guard:
+            self.scaler.after_step()
 
     # ---- tf.train.Saver slots (ADVICE r1: a resumed run must not restart Adam at t = 0)
     def export_state(self):
@@ -360,22 +378,30 @@ class AdamOptimizer:
 class MomentumOptimizer:
     """tf.train.MomentumOptimizer(0.001, 0.9) (src/imagenet/imagenet_train_darknet.py:58)."""
 
-    def __init__(self, net, learning_rate=1e-3, momentum=0.9, guard=None):
+    def __init__(self, net, learning_rate=1e-3, momentum=0.9, guard=None, fused_pack=True):
         self.net, self.lr, self.mom = net, learning_rate, momentum
+        self.fused_pack = bool(fused_pack)
         self.accum = torch.zeros_like(net.params)
         self.guard = (net.dtype == _lib.Y2_F16) if guard is None else bool(guard)
         self.scaler = LossScaler(net) if self.guard else None
 
-    def step(self, grad_mult=1.0):
+    def step(self, grad_mult=1.0, full_check=False):
         n = self.net
         if self.guard:
+            self.scaler.scan(n, full_check)
+        ctrl = _ptr(self.scaler.ctrl) if self.guard else C.c_void_p(0)
+        if self.fused_pack and n.training:
+            check(n.lib.y2_momentum_step_packed(n.h, _ptr(self.accum), ctrl, self.lr, self.mom, grad_mult, _stream()))
+        elif self.guard:
             check(n.lib.y2_momentum_step_guarded(_ptr(n.params), _ptr(self.accum), _ptr(n.grads), n.n_params,
-                                                 _ptr(self.scaler.ctrl), self.lr, self.mom, grad_mult, _stream()))
-            self.scaler.after_step()
+                                                 ctrl, self.lr, self.mom, grad_mult, _stream()))
+            n.params_changed()
         else:
             check(n.lib.y2_momentum_step(_ptr(n.params), _ptr(self.accum), _ptr(n.grads), n.n_params, self.lr,
                                          self.mom, grad_mult, _stream()))
-        n.params_changed()
+            n.params_changed()
+        if self.guard:
+            self.scaler.after_step()
 
     def export_state(self):
         return {"accum": self.accum.detach().cpu().numpy().copy()}

@@ -79,7 +79,7 @@ def rel_to_max(got, ref):
 @pytest.mark.parametrize("name,k,cin,cout,hw", C4_SHAPES, ids=[s[0] for s in C4_SHAPES])
 def test_c4_layer_shape_f16_vs_float64(name, k, cin, cout, hw):
     from tensorflow_yolo2_amd import engine as E
-    rng = np.random.default_rng(hash((k, cin, cout, hw)) % (2 ** 31))
+    rng = np.random.default_rng(k * 1000003 + cin * 1009 + cout * 31 + hw)
     x = f16_representable(rng.uniform(-1, 1, (N, hw, hw, cin)).astype(np.float32))
     w = f16_representable(np.clip(rng.normal(0, 0.1, (k, k, cin, cout)), -0.2, 0.2).astype(np.float32))
     b = rng.uniform(-0.5, 0.5, cout).astype(np.float32)
@@ -129,7 +129,7 @@ def test_c4_layer_in_network_f16_bn_passes(name, k, cin, cout, hw, pool):
     epilogue's batch statistics, BN + leaky (+ pool) forward, BN backward (dy, dgamma, dbeta) and the in-network
     weight gradient -- each against float64 arithmetic on the values the device stored."""
     from tensorflow_yolo2_amd import engine as E
-    rng = np.random.default_rng(hash((name, k, cin, cout)) % (2 ** 31))
+    rng = np.random.default_rng(k * 1000003 + cin * 1009 + cout * 31 + hw + 17 * pool + 5)
     spec = [(k, cin, cout, pool), (1, cout, 32, 0)]
     net = E.Network(spec, N, hw, hw, dtype="f16", training=True, grad_scale=1.0)
     params = R.init_params(spec, seed=4)
@@ -179,9 +179,24 @@ def test_c4_layer_in_network_f16_bn_passes(name, k, cin, cout, hw, pool):
     xhat = (y64 - mean) * inv
     dbeta, dgamma = dz.sum((0, 1, 2)), (dz * xhat).sum((0, 1, 2))
     dy_ref = params[0]["gamma"] * inv * (dz - dbeta / M - xhat * dgamma / M)
-    e_dy = rel_to_max(dy, dy_ref)
-    e_dg = rel_to_max(g[0]["gamma"], dgamma)
-    e_db = rel_to_max(g[0]["beta"], dbeta)
+    # Decision points: leaky'(z) at z ~ 0 and the arg-max of a 2x2 window with two near-equal maxima are
+    # decided in fp32 on the device and in float64 here; of ~1e8 elements a handful sit within fp32 round-off of
+    # the boundary and may legitimately fall the other way (each moves ONE dy entry by up to 0.9 |dA| scale).
+    # Such entries must (a) be few and (b) all sit at a near-tie; everything else is gated at 1e-3 of the max.
+    near = np.abs(z) < 1e-4
+    if pool:
+        zz_sorted = np.sort(zz, axis=3)
+        tie = (zz_sorted[:, :, :, 3, :] - zz_sorted[:, :, :, 2, :]) < 1e-4
+        near_w = near.reshape(N, Ho, 2, Ho, 2, cout).any((2, 4)) | tie
+        near = np.repeat(np.repeat(near_w, 2, axis=1), 2, axis=2)
+    bad = np.abs(dy - dy_ref) > TOL * np.abs(dy_ref).max()
+    nbad = int(bad.sum())
+    assert nbad <= 8 + 2e-7 * dy.size, ("too many dy entries off", nbad)
+    assert not (bad & ~near).any(), "a dy entry is off away from any decision boundary"
+    e_dy = rel_to_max(np.where(bad, dy_ref, dy), dy_ref)
+    flip = nbad * 2.0 * np.abs(dA).max()                       # what the flipped entries can move a channel sum by
+    e_dg = max(0.0, float(np.abs(g[0]["gamma"] - dgamma).max() - flip * np.abs(xhat).max())) / np.abs(dgamma).max()
+    e_db = max(0.0, float(np.abs(g[0]["beta"] - dbeta).max() - flip)) / np.abs(dbeta).max()
     # in-network weight gradient from the stored x and stored dy, sampled (ci, co) pairs over all pixels
     ci_s = np.unique(np.r_[0, cin - 1, rng.integers(0, cin, 4)])
     co_s = np.unique(np.r_[0, cout - 1, rng.integers(0, cout, 4)])
@@ -195,8 +210,12 @@ def test_c4_layer_in_network_f16_bn_passes(name, k, cin, cout, hw, pool):
             xs = x[:, h0 + dh - r:h1 + dh - r, w0 + dwi - r:w1 + dwi - r, :][..., ci_s].astype(np.float64)
             ref[dh, dwi] = np.einsum("nhwi,nhwo->io", xs, dys[:, h0:h1, w0:w1, :], optimize=True)
     e_dw = rel_to_max(g[0]["W"][:, :, ci_s][:, :, :, co_s], ref)
-    print("C4 net %-12s f16: conv %.2e  bn+act %.2e  dy %.2e  dgamma %.2e  dbeta %.2e  dW %.2e" %
-          (name, e_conv, e_act, e_dy, e_dg, e_db, e_dw))
+    if e_dw > TOL:
+        got = g[0]["W"][:, :, ci_s][:, :, :, co_s]
+        print("DBG dW mismatch: per-tap max err", np.abs(got - ref).max((2, 3)), "ref max", np.abs(ref).max(),
+              "ci_s", ci_s, "co_s", co_s, "got/ref sample", got[1, 1, :2, :2], ref[1, 1, :2, :2])
+    print("C4 net %-12s f16: conv %.2e  bn+act %.2e  dy %.2e (%d near-tie flips)  dgamma %.2e  dbeta %.2e  dW %.2e" %
+          (name, e_conv, e_act, e_dy, nbad, e_dg, e_db, e_dw))
     assert e_conv < TOL and e_act < TOL, (e_conv, e_act)
     # dy / dgamma / dbeta / dW are functions of the f16-stored dA and dy: their own storage rounding (2^-11 of
     # each value) stays inside 1e-3 of the max
@@ -240,3 +259,45 @@ def test_c4_first_layer_f16_vs_float64():
         amax = max(amax, float(np.abs(act).max()))
     print("C4 conv1 f16: conv %.2e  bn+act+pool %.2e" % (e_conv, worst / amax))
     assert e_conv < TOL and worst / amax < TOL
+
+
+def test_full_detector_step_f32_416_bs8_vs_torch_oracle():
+    """One whole detector step in the parity-grade mode at BASELINE.json configs[3]'s geometry (416x416, S=13;
+    batch 8 to bound the host time of the oracle): grid_net, loss, ious, object_mask, and gradients against the
+    PyTorch-CPU restatement (oracle/torch_ref.py, fp32 autograd).  The batch-64 run of the benchmarked f16 mode is
+    covered by the per-shape tests above and the property test in test_gpu_net.py."""
+    from oracle import torch_ref as T, loss_ref as L
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    n, size, S = 8, 416, 13
+    spec = E.CORE_SPEC + E.det_head_spec(30)
+    params = R.init_params(spec, seed=0)
+    x = synthetic.images(n, size, 1234)
+    labels = synthetic.det_labels(n, size, S, 4321)
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    tp = T.to_torch_params(params, torch.float32, requires_grad=True)
+    rnet, _ = T.run_stack(torch.tensor(x), tp, R.CORE_SPEC + R.det_head_spec(30), True)
+    rloss, rious, rmask, _ = T.get_loss(rnet.reshape(n, S, S, 30), torch.tensor(labels), 20, n, size, S, 2,
+                                        L.yolo_grid_offset(S, 2))
+    rloss.backward()
+    net = E.Network(spec, n, size, size, dtype="f32", core_layers=18, training=True)
+    net.load_params(params)
+    grid = net.forward(torch.as_tensor(x).cuda(), True, True)
+    e_grid = rel_to_max(grid.cpu().numpy(), rnet.detach().numpy().astype(np.float64))
+    loss, ious, mask, dnet = E.yolo_loss(grid, torch.as_tensor(labels).cuda(), 20, n, size, S, 2)
+    e_loss = abs(loss[4].item() - rloss.item()) / abs(rloss.item())
+    mism = int((mask.cpu().numpy() != rmask.numpy()).sum())
+    net.backward(dnet)
+    g = net.export_grads()
+    e_last = max(float(np.linalg.norm(g[21][k] - tp[21][k].grad.numpy()) / np.linalg.norm(tp[21][k].grad.numpy()))
+                 for k in ("W", "gamma", "beta"))
+    cosines = {}
+    for l in (0, 7, 17, 18):
+        a = g[l]["W"].ravel().astype(np.float64)
+        b = tp[l]["W"].grad.numpy().ravel().astype(np.float64)
+        cosines[l] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+    print("C4 f32 step bs8: grid %.2e  loss %.2e  mask mismatches %d  last-layer grads %.2e  cos(dW) %s" %
+          (e_grid, e_loss, mism, e_last, cosines))
+    assert e_grid < TOL and e_loss < TOL and e_last < TOL
+    # object_mask is index work: it may only differ where two IoUs tie to within fp32 round-off of the two sides
+    assert mism == 0 or rel_to_max(ious.cpu().numpy(), rious.detach().numpy().astype(np.float64)) < 3e-3
+    assert all(c > 0.999 for c in cosines.values()), cosines

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import nn_ref as R, loss_ref as L, optim_ref as O, data_ref as D
+from _obs import gate
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +26,8 @@ def l2err(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-TOL = {"f32": 1e-5, "f16": 4e-3, "bf16": 3e-2}
+# about twice the maxima observed on MI355X (gpurun_out/observed_errors.txt, round 2): f32 1.7e-6, f16 5.5e-4, bf16 3.9e-3
+TOL = {"f32": 4e-6, "f16": 1.2e-3, "bf16": 8e-3}
 
 
 def mesh(n):
@@ -72,7 +74,7 @@ def test_conv2d_vs_oracle(case, dtype):
     b = rng.uniform(-0.5, 0.5, co).astype(np.float32)
     y = E.conv2d(dev(x), dev(wt), dev(b), dtype=dtype).cpu().numpy()
     ref = R.conv2d_same(x.astype(np.float64), wt.astype(np.float64)) + b
-    assert relerr(y, ref) < TOL[dtype], relerr(y, ref)
+    gate("conv2d fwd %s" % dtype, relerr(y, ref), TOL[dtype])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
@@ -86,8 +88,8 @@ def test_conv2d_backward_vs_oracle(case, dtype):
     dy = rng.standard_normal((n, h, w, co)).astype(np.float32)
     dx, dw = E.conv2d_backward(dev(x), dev(wt), dev(dy), dtype=dtype)
     rdx, rdw = R.conv2d_same_backward(x.astype(np.float64), wt.astype(np.float64), dy.astype(np.float64))
-    assert relerr(dx.cpu().numpy(), rdx) < TOL[dtype], ("dx", relerr(dx.cpu().numpy(), rdx))
-    assert relerr(dw.cpu().numpy(), rdw) < TOL[dtype], ("dw", relerr(dw.cpu().numpy(), rdw))
+    gate("conv2d dx %s" % dtype, relerr(dx.cpu().numpy(), rdx), TOL[dtype])
+    gate("conv2d dw %s" % dtype, relerr(dw.cpu().numpy(), rdw), TOL[dtype])
 
 
 def test_conv2d_edge_single_pixel_and_unit_batch():
@@ -134,9 +136,9 @@ def test_stack_forward(first3, training, dtype):
     net.load_params(params)
     out = net.forward(dev(x), training, training, update_moving=True).cpu().numpy()
     ref, caches, movings = R.run_stack(x, params, spec, training, np.float64)
-    tol = {"f32": 2e-5, "f16": 1e-2, "bf16": 8e-2}[dtype]
+    tol = {"f32": 4e-6, "f16": 5e-3, "bf16": 3e-2}[dtype]   # observed 1.7e-6 / 2.5e-3 / 1.4e-2
     assert out.shape == ref.shape
-    assert relerr(out, ref) < tol, relerr(out, ref)
+    gate("stack forward vs unquantised oracle %s" % dtype, relerr(out, ref), tol)
     if training:   # UPDATE_OPS: moving <- 0.99 moving + 0.01 batch (biased variance)
         got = net.export_params()
         for l, mv in enumerate(movings):
@@ -161,17 +163,17 @@ def test_stack_backward(first3, dtype):
     # against the oracle with the same storage points quantised (oracle quantizer()).
     q = R.quantizer(dtype)
     ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q)
-    assert l2err(out.cpu().numpy(), ref) < {"f32": 1e-5, "f16": 1e-3, "bf16": 8e-3}[dtype]
+    gate("stack forward vs quantised oracle %s" % dtype, l2err(out.cpu().numpy(), ref),
+         {"f32": 4e-6, "f16": 1e-3, "bf16": 1e-6}[dtype])       # observed 1.5e-6 / 7.3e-4 / 2.8e-7
     dout = rng.standard_normal(ref.shape).astype(np.float32)
     net.backward(dev(dout))
     _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,
                                      grad_scale=net.grad_scale)
     grads = net.export_grads()
-    tol = {"f32": 2e-4, "f16": 1e-2, "bf16": 6e-2}[dtype]
+    tol = {"f32": 5e-6, "f16": 4e-3, "bf16": 1e-2}[dtype]    # observed 1.7e-6 / 1.9e-3 / 4.3e-3
     for l in range(len(spec)):
         for k in ("W", "gamma", "beta"):
-            e = l2err(grads[l][k], rgrads[l][k])
-            assert e < tol, (l, k, e)
+            gate("stack backward %s first3=%d" % (dtype, first3), l2err(grads[l][k], rgrads[l][k]), tol)
         # conv bias gradient is mathematically zero under batch-stat BN: absolute check
         scale = np.abs(rgrads[l]["gamma"]).max() + np.abs(rgrads[l]["beta"]).max()
         assert np.abs(grads[l]["b"]).max() < 1e-2 * scale + 1e-3
@@ -315,18 +317,17 @@ def test_first_layer_paths_odd_and_wide(shape, dtype):
     q = R.quantizer(dtype)
     ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q)
     assert out.shape == ref.shape
-    assert l2err(out.cpu().numpy(), ref) < {"f32": 1e-5, "f16": 1e-3}[dtype]
+    gate("first layer forward %s" % dtype, l2err(out.cpu().numpy(), ref), {"f32": 3e-6, "f16": 4e-4}[dtype])   # 9.5e-7 / 1.6e-4
     dout = rng.standard_normal(ref.shape).astype(np.float32)
     net.backward(dev(dout))
     _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,
                                      grad_scale=net.grad_scale)
     grads = net.export_grads()
     # f16: dy and y are stored / staged in half precision (12 k pixels summed per filter element)
-    tol = {"f32": 2e-4, "f16": 2.5e-2}[dtype]
+    tol = {"f32": 4e-6, "f16": 2.5e-2}[dtype]     # observed 1.2e-6 / 2.1e-2
     for l in range(len(spec)):
         for k in ("W", "gamma", "beta"):
-            e = l2err(grads[l][k], rgrads[l][k])
-            assert e < tol, (l, k, e)
+            gate("first layer backward %s" % dtype, l2err(grads[l][k], rgrads[l][k]), tol)
 
 
 @pytest.mark.gpu
@@ -345,7 +346,7 @@ def test_conv2d_random_shapes_forward_and_backward(dtype):
         cases.append((int(rng.integers(1, 4)), int(rng.integers(3, 60)), int(rng.integers(3, 120)),
                       int(rng.choice([32, 64, 96, 128, 256])), int(rng.choice([30, 32, 64, 128, 200, 256])),
                       int(rng.choice([1, 3]))))
-    tol = {"f32": (2e-5, 2e-5), "f16": (5e-3, 1e-2)}[dtype]
+    tol = {"f32": (5e-6, 5e-6), "f16": (8e-4, 8e-4)}[dtype]   # observed 1.9e-6 / 3.6e-4
     for (n, h, w, ci, co, k) in cases:
         x = rng.standard_normal((n, h, w, ci)).astype(np.float32)
         wt = (rng.standard_normal((k, k, ci, co)) / np.sqrt(k * k * ci)).astype(np.float32)
@@ -359,4 +360,6 @@ def test_conv2d_random_shapes_forward_and_backward(dtype):
         e_y = l2err(y, ref.detach().permute(0, 2, 3, 1).numpy())
         e_dx = l2err(dx.cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
         e_dw = l2err(dw.cpu().numpy(), wtt.grad.permute(2, 3, 1, 0).numpy())
-        assert e_y < tol[0] and e_dx < tol[1] and e_dw < tol[1], ((n, h, w, ci, co, k), e_y, e_dx, e_dw)
+        gate("conv sweep y %s" % dtype, e_y, tol[0])
+        gate("conv sweep dx %s" % dtype, e_dx, tol[1])
+        gate("conv sweep dw %s" % dtype, e_dw, tol[1])

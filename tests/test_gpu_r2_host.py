@@ -232,27 +232,27 @@ def test_guarded_adam_matches_oracle_and_skips_on_overflow():
     for t in range(1, 4):
         g = rng.standard_normal(p.shape).astype(np.float32) * 1e-2
         net.grads.copy_(torch.as_tensor(g))
-        opt.step()
+        opt.step(full_check=True)
         p, m, v = O.adam_step(p, m, v, g, t)
         assert np.abs(net.params.cpu().numpy() - p).max() < 1e-6
     assert opt.scaler.state() == (0, 3, 0)
     # an inf anywhere in the buffer: the step is skipped as a whole, nothing is poisoned
     before = (net.params.clone(), opt.m.clone(), opt.v.clone())
     g = rng.standard_normal(p.shape).astype(np.float32)
-    g[-3] = np.inf
+    g[g.size // 2] = np.inf                                     # an arbitrary element: the full scan
     net.grads.copy_(torch.as_tensor(g))
-    opt.step()
+    opt.step(full_check=True)
     assert torch.equal(net.params, before[0]) and torch.equal(opt.m, before[1]) and torch.equal(opt.v, before[2])
     assert opt.scaler.state() == (1, 3, 1)
-    g[-3] = np.nan
+    g[g.size // 2] = np.nan
     net.grads.copy_(torch.as_tensor(g))
-    opt.step()                                                  # the host saw the first overflow: scale halved
+    opt.step(full_check=True)                                                  # the host saw the first overflow: scale halved
     assert opt.scaler.scale == 512.0 and net.grad_scale == 512.0
     assert torch.isfinite(net.params).all() and opt.scaler.state() == (1, 3, 2)
     # a clean step resumes at t = 4 with the bias correction of t = 4
     g = rng.standard_normal(p.shape).astype(np.float32) * 1e-2
     net.grads.copy_(torch.as_tensor(g))
-    opt.step()
+    opt.step()                                                  # sentinel scan (the production default)
     p, m, v = O.adam_step(p, m, v, g, 4)
     assert np.abs(net.params.cpu().numpy() - p).max() < 1e-6
     assert opt.scaler.state()[:2] == (0, 4)
@@ -264,7 +264,7 @@ def test_guarded_adam_matches_oracle_and_skips_on_overflow():
     mo.step()
     pm, acc = O.momentum_step(pm, acc, g)
     assert np.abs(net.params.cpu().numpy() - pm).max() < 1e-6
-    g[0] = -np.inf
+    g[0] = -np.inf                                              # the first filter is a sentinel range
     net.grads.copy_(torch.as_tensor(g))
     keep = net.params.clone()
     mo.step()
@@ -406,3 +406,44 @@ def test_backward_marks_rejects_out_of_range_layers():
     with pytest.raises(_lib.Y2Error):
         net.backward_marks(torch.ones_like(out), [0, 2])
     net.backward_marks(torch.ones_like(out), [1, 0])
+
+
+# ---------------------------------------------------------------- fused optimizer + filter re-pack
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("kind", ["adam", "momentum"])
+def test_fused_optimizer_repack_equals_separate_passes(dtype, kind):
+    """y2_*_step_packed: same parameters and slots as the flat step bit for bit, and the packed filter copies it
+    leaves behind give the same forward as a context that re-packs from the updated parameters."""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    core = [(k, ci, co, int(p)) for (k, ci, co, p) in R.scaled_spec(R.CORE_SPEC, 4)]
+    head = [(3, core[-1][2], 256, 0), (1, 256, 30, 0)]
+    spec = core + head
+    n, size = 2, 64
+    x = dev(synthetic.images(n, size, 3))
+    nets, opts = [], []
+    for fused in (True, False):
+        net = E.Network(spec, n, size, size, dtype=dtype, core_layers=len(core), training=True)
+        net.init_params(5)
+        cls = E.AdamOptimizer if kind == "adam" else E.MomentumOptimizer
+        opts.append(cls(net, guard=False, fused_pack=fused))
+        nets.append(net)
+    rng = np.random.default_rng(0)
+    for step in range(3):
+        g = torch.as_tensor(rng.standard_normal(nets[0].n_params).astype(np.float32) * 1e-2).cuda()
+        outs = []
+        for net, opt in zip(nets, opts):
+            net.grads.copy_(g)
+            opt.step()
+            outs.append(net.forward(x, True, True).clone())
+        assert torch.equal(nets[0].params, nets[1].params), step
+        assert torch.equal(opts[0].m, opts[1].m) if kind == "adam" else torch.equal(opts[0].accum, opts[1].accum)
+        assert torch.equal(outs[0], outs[1]), step
+    # guarded form: a flagged step leaves parameters AND packed copies alone
+    net = nets[0]
+    opt = (E.AdamOptimizer if kind == "adam" else E.MomentumOptimizer)(net, guard=True, fused_pack=True)
+    before = net.forward(x, True, True).clone()
+    g = torch.zeros_like(net.grads); g[0] = float("inf")
+    net.grads.copy_(g)
+    keep = net.params.clone()
+    opt.step(full_check=True)
+    assert torch.equal(net.params, keep) and torch.equal(net.forward(x, True, True), before)
