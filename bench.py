@@ -138,6 +138,54 @@ def f32_mode(args, images, labels, device, total_flops):
             "whole_step_tflops": tf, "peak": MFMA_PEAK_TFLOPS["f32"], "whole_step_frac": tf / MFMA_PEAK_TFLOPS["f32"]}
 
 
+def bench_yolov2(args, images, labels, device, rank, world, dist):
+    """train step of the YOLOv2 anchor model (yolo2_nets/yolov2.py): same contract, its own metric name"""
+    import torch
+    from tensorflow_yolo2_amd.yolo2_nets.yolov2 import YOLOv2Trainer
+    tr = YOLOv2Trainer(args.batch, args.image_size, dtype=args.dtype, device=device, seed=0)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        tr.step(images, labels)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step(images, labels)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        flops = tr.flops_per_step()
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        out = {"metric": "images/sec fwd+bwd YOLOv2 (Darknet-19 + passthrough + anchor loss) 416x416",
+               "value": world * args.batch * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "YOLOv2 train step: stem (13 layers) + pool + 13x13 stack (7 layers) + passthrough "
+                                      "concat 3072 + head (3x3, 1x1 -> 125) + anchor loss + backward + Adam "
+                                      "(north-star model, not in the reference)",
+                          "image_size": args.image_size, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                          "S": args.image_size // 32, "B": tr.B, "parallelism": "dp%d" % world},
+               "whole_step_tflops": flops / (ms * 1e-3) / 1e12,
+               "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                            "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None,
+                            "kernel": "whole step (algorithmic conv FLOPs / wall time)"}}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,6 +202,9 @@ def main():
     ap.add_argument("--no-f32-mode", action="store_true")
     ap.add_argument("--f32-steps", type=int, default=3)
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: core forward only (inference BN)")
+    ap.add_argument("--model", default="detector", choices=["detector", "yolov2"],
+                    help="detector: the reference's Darknet-19 grid detector (the headline); yolov2: the north star's "
+                         "anchor model (passthrough + anchor loss), not in the reference")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU functional test)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="functional test of the N>1 path on one GPU")
     args = ap.parse_args()
@@ -193,6 +244,8 @@ def main():
     images = torch.as_tensor(synthetic.images(bs, size, 1234 + rank)).to(device)
     labels = torch.as_tensor(synthetic.det_labels(bs, size, S, 4321 + rank)).to(device)
 
+    if args.model == "yolov2":
+        return bench_yolov2(args, images, labels, device, rank, world, dist)
     if args.forward_only:
         net = E.Network(spec_core, bs, size, size, dtype=args.dtype, training=False, device=device)
         net.init_params(0)

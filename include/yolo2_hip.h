@@ -94,6 +94,10 @@ int y2_backward(y2_ctx* ctx, const float* dout, int layer_lo, int layer_hi, void
  * pass continues; no join on `stream` until the end, unlike one y2_backward call per slice). */
 int y2_backward_marks(y2_ctx* ctx, const float* dout, int n_marks, const int* mark_layers, void* stream);
 int y2_wait_mark(y2_ctx* ctx, int k, void* stream);
+/* y2_backward over all layers that also writes the gradient with respect to the stack's input, fp32 NHWC
+ * [N,H,W,in_chl of layer 0]: for stacks composed into larger graphs (the YOLOv2 detector of the north star: 13x13
+ * stack and head behind the passthrough concat).  The 3-channel image layer has no input gradient. */
+int y2_backward_input(y2_ctx* ctx, const float* dout, float* dinput, void* stream);
 /* copy a layer's saved activation (post BN+leaky+pool input of `layer`, or conv output) for tests */
 int y2_debug_read(y2_ctx* ctx, int layer, int what, float* dst, void* stream);
 
@@ -144,6 +148,9 @@ int y2_passthrough_concat(const float* fine, const float* coarse, float* out, in
                           void* stream);
 int y2_passthrough_concat_backward(const float* dout, float* dfine, float* dcoarse, int N, int H, int W, int Cf,
                                    int Cc, void* stream);
+/* dst += src on fp32 buffers: the gradient of a tensor with two consumers (the 26x26x512 activation feeds the pool
+ * and the passthrough) */
+int y2_accumulate(float* dst, const float* src, size_t n, void* stream);
 /* anchor decode: net [N,S,S,B,5+C] (tx,ty,tw,th,to,classes), anchors [B][2] in cell units ->
  * boxes [N,S*S*B,4] (cx,cy,w,h relative to the image), scores [N,S*S*B,C] = sigmoid(to)*softmax(classes) */
 int y2_decode_anchors(const float* net, const float* anchors, float* boxes, float* scores, int N, int S, int B, int C,
@@ -154,6 +161,14 @@ int y2_decode_anchors(const float* net, const float* anchors, float* boxes, floa
 int y2_nms(const float* boxes, const float* scores, const int* classes, int N, int K, float iou_thresh,
            float score_thresh, int max_out, int class_aware, int* keep, int* count, void* stream);
 
+/* YOLOv2 anchor-box loss, forward + gradient (specification: oracle/ext_ref.py yolov2_loss): net [N,S,S,B,5+C]
+ * raw outputs, labels = the reference's label grid [N,S,S,5+C] (one box per cell, img_dataset/pascal_voc.py:146-163),
+ * anchors [B][2] in cell units, scales = {coord, object, noobject, class, iou_thresh} (NULL: 1, 5, 1, 1, 0.6).
+ * loss[5] = coord, object, noobject, class, total (mean over the batch); dnet (nullable) same shape as net. */
+size_t y2_yolov2_loss_workspace_bytes(int batch);
+int y2_yolov2_loss(const float* net, const float* labels, const float* anchors, int batch, int S, int B, int num_class,
+                   float image_size, const float* scales, float* loss, float* dnet, void* workspace, void* stream);
+
 /* ---- optimizers on flat buffers (pascal_train_darknet.py:51, imagenet_train_darknet.py:58) */
 int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n, int step, float lr,
                  float beta1, float beta2, float eps, float grad_mult, void* stream);
@@ -162,7 +177,7 @@ int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, 
 /* The same updates guarded against half-precision gradient overflow (dynamic loss scaling; the fp32
  * reference cannot overflow): ctrl = 8 zero-initialised 32-bit device words {found_inf, step, skipped, -,
  * lr_t, ...}.  A scan sets ctrl.found_inf: y2_grad_check reads the context's SENTINEL ranges of its bound gradient
- * buffer (b / gamma / beta of every layer and the first filter, ~30 k floats: every non-finite value of the
+ * buffer (b / gamma / beta of every layer and one row of the first filter, ~30 k floats: every non-finite value of the
  * backward pass reaches them -- an inf / NaN in a layer's incoming gradient makes the channel sums dbeta
  * non-finite, a dy that overflows at its own f16 store is an operand of the dgrad below it, and the first layer's
  * dy feeds its filter gradient directly); y2_grad_check_full reads every element of any buffer.

@@ -104,3 +104,95 @@ def nms(boxes, scores, classes=None, iou_thresh=0.5, score_thresh=0.0, max_out=1
             if nms_iou(boxes[i], boxes[j]) > thr:
                 sup[b] = True
     return keep
+
+
+# ---------------------------------------------------------------------------
+# YOLOv2 anchor-box ("region") loss, forward + analytic gradient.  NOT in the reference (its get_loss is the
+# YOLOv1 grid loss); the north star names a "confidence/class/coord multi-part loss" on the anchor model, so
+# this is the specification csrc/ext.hip's yolov2_loss_kernel is tested against (parity unpinned; the gradient
+# is cross-checked against torch autograd of the same formula in tests/test_oracle.py).
+#
+#   net     [N,S,S,B,5+C]  raw outputs (tx, ty, tw, th, to, class logits)
+#   labels  [N,S,S,5+C]    the reference's label grid (img_dataset/pascal_voc.py:146-163): resp, cx, cy, w, h in
+#                          resized pixels, one-hot class -- one ground-truth box per cell
+#   anchors [B,2]          (w, h) in cell units
+# With g = ground truth in cell units (gx = cx / image_size * S, ...), (row, col) its cell, b* the anchor whose
+# (w, h) has the largest shape IoU with (gw, gh) (first one on ties), p = the decoded prediction
+# (px = sigmoid(tx) + col, py = sigmoid(ty) + row, pw = aw exp(tw), ph = ah exp(th)):
+#   coord    = coord_scale  * [(sig(tx) - (gx - col))^2 + (sig(ty) - (gy - row))^2 + (tw - ln(gw/aw))^2 + (th - ln(gh/ah))^2]
+#   object   = object_scale * (sig(to) - IoU(p, g))^2         IoU is a constant target (no gradient through it)
+#   class    = class_scale  * cross_entropy(softmax(logits), class)
+#                                                             ... summed over the responsible (cell, b*) pairs
+#   noobject = noobject_scale * sig(to)^2   over every other (cell, anchor) whose best IoU with ANY ground truth of
+#                                           its image is <= thresh
+#   loss = (coord + object + class + noobject) / N            (parts returned in that order, then the total)
+# ---------------------------------------------------------------------------
+YOLOV2_SCALES = dict(coord_scale=1.0, object_scale=5.0, noobject_scale=1.0, class_scale=1.0, thresh=0.6)
+
+
+def _box_iou_cwh(ax, ay, aw, ah, bx, by, bw, bh):
+    iw = np.maximum(0.0, np.minimum(ax + aw / 2, bx + bw / 2) - np.maximum(ax - aw / 2, bx - bw / 2))
+    ih = np.maximum(0.0, np.minimum(ay + ah / 2, by + bh / 2) - np.maximum(ay - ah / 2, by - bh / 2))
+    inter = iw * ih
+    uni = aw * ah + bw * bh - inter
+    return np.where(uni > 0, inter / np.where(uni > 0, uni, 1.0), 0.0)
+
+
+def yolov2_loss(net, labels, anchors, image_size, coord_scale=1.0, object_scale=5.0, noobject_scale=1.0,
+                class_scale=1.0, thresh=0.6, dtype=np.float64):
+    """-> (loss[5] = coord, object, noobject, class, total; dnet [N,S,S,B,5+C])"""
+    net = np.asarray(net, dtype)
+    labels = np.asarray(labels, dtype)
+    an = np.asarray(anchors, dtype)
+    n, s, _, b, d = net.shape
+    c = d - 5
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    dnet = np.zeros_like(net)
+    parts = np.zeros(4, dtype)
+    col = np.arange(s, dtype=dtype)[None, :, None]
+    row = np.arange(s, dtype=dtype)[:, None, None]
+    for i in range(n):
+        t = net[i]
+        sx, sy, so = sig(t[..., 0]), sig(t[..., 1]), sig(t[..., 4])
+        px, py = sx + col, sy + row
+        pw, ph = an[None, None, :, 0] * np.exp(t[..., 2]), an[None, None, :, 1] * np.exp(t[..., 3])
+        cells = np.argwhere(labels[i, :, :, 0] > 0)
+        truths = []
+        for (r, q) in cells:
+            lab = labels[i, r, q]
+            truths.append((lab[1] / image_size * s, lab[2] / image_size * s, lab[3] / image_size * s,
+                           lab[4] / image_size * s, int(np.argmax(lab[5:])), int(r), int(q)))
+        best = np.zeros((s, s, b), dtype)
+        for (gx, gy, gw, gh, _k, _r, _q) in truths:
+            best = np.maximum(best, _box_iou_cwh(px, py, pw, ph, gx, gy, gw, gh))
+        resp = np.zeros((s, s, b), bool)
+        for (gx, gy, gw, gh, k, r, q) in truths:
+            inter = np.minimum(gw, an[:, 0]) * np.minimum(gh, an[:, 1])
+            shape_iou = inter / (gw * gh + an[:, 0] * an[:, 1] - inter)
+            bs = int(np.argmax(shape_iou))                       # first maximum
+            resp[r, q, bs] = True
+            tt = t[r, q, bs]
+            ex, ey = sx[r, q, bs] - (gx - q), sy[r, q, bs] - (gy - r)
+            ew, eh = tt[2] - np.log(gw / an[bs, 0]), tt[3] - np.log(gh / an[bs, 1])
+            parts[0] += coord_scale * (ex * ex + ey * ey + ew * ew + eh * eh)
+            dnet[i, r, q, bs, 0] = coord_scale * 2 * ex * sx[r, q, bs] * (1 - sx[r, q, bs])
+            dnet[i, r, q, bs, 1] = coord_scale * 2 * ey * sy[r, q, bs] * (1 - sy[r, q, bs])
+            dnet[i, r, q, bs, 2] = coord_scale * 2 * ew
+            dnet[i, r, q, bs, 3] = coord_scale * 2 * eh
+            iou = float(_box_iou_cwh(px[r, q, bs], py[r, q, bs], pw[r, q, bs], ph[r, q, bs], gx, gy, gw, gh))
+            eo = so[r, q, bs] - iou
+            parts[1] += object_scale * eo * eo
+            dnet[i, r, q, bs, 4] = object_scale * 2 * eo * so[r, q, bs] * (1 - so[r, q, bs])
+            lg = tt[5:]
+            m = lg.max()
+            lse = m + np.log(np.exp(lg - m).sum())
+            parts[3] += class_scale * (lse - lg[k])
+            sm = np.exp(lg - lse)
+            sm[k] -= 1.0
+            dnet[i, r, q, bs, 5:] = class_scale * sm
+        noobj = (~resp) & (best <= thresh)
+        parts[2] += noobject_scale * (so[noobj] ** 2).sum()
+        dnet[i, ..., 4] += np.where(noobj, noobject_scale * 2 * so * so * (1 - so), 0.0)
+    parts = parts / n
+    dnet = dnet / n
+    return np.concatenate([parts, [parts.sum()]]).astype(dtype), dnet

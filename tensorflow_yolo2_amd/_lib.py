@@ -46,6 +46,7 @@ SIGNATURES = {
     "y2_backward": (_i, [_vp, _vp, _i, _i, _vp]),
     "y2_backward_marks": (_i, [_vp, _vp, _i, _pi, _vp]),
     "y2_wait_mark": (_i, [_vp, _i, _vp]),
+    "y2_backward_input": (_i, [_vp, _vp, _vp, _vp]),
     "y2_debug_read": (_i, [_vp, _i, _i, _vp, _vp]),
     "y2_profile_enable": (_i, [_vp, _i]),
     "y2_profile_collect": (_i, [_vp, C.POINTER(C.c_double), _pi, _i]),
@@ -62,8 +63,11 @@ SIGNATURES = {
     "y2_reorg": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "y2_passthrough_concat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_passthrough_concat_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "y2_accumulate": (_i, [_vp, _vp, _sz, _vp]),
     "y2_decode_anchors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp]),
+    "y2_yolov2_loss_workspace_bytes": (_sz, [_i]),
+    "y2_yolov2_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "y2_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
     "y2_grad_check": (_i, [_vp, _vp, _vp]),

@@ -89,6 +89,20 @@ static int chan_copy(const float* src, float* dst, size_t M, int C, int lds, int
     return Y2_OK;
 }
 
+// dst += src (the 26x26x512 activation of the YOLOv2 graph has two consumers -- the pool and the passthrough --
+// so its gradient is the sum of two paths)
+__global__ void accumulate_kernel(float4* __restrict__ dst, const float4* __restrict__ src, size_t n4, float* dt,
+                                  const float* st, size_t tail0, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = dst[i];
+        const float4 b = src[i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        dst[i] = a;
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) dt[i] += st[i];
+}
+
 // ---------------------------------------------------------------------------
 // anchor decode: net [N,S,S,B,5+C] = (tx, ty, tw, th, to, class logits)
 //   bx = (sigmoid(tx) + col)/S, by = (sigmoid(ty) + row)/S, bw = pw*exp(tw)/S, bh = ph*exp(th)/S
@@ -245,6 +259,134 @@ __global__ void maxpool_kernel(const float* __restrict__ x, float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// YOLOv2 anchor-box loss, forward + gradient in one kernel (specification: oracle/ext_ref.py yolov2_loss; the
+// reference has no anchor model).  One block per image: the image's ground-truth boxes (one per responsible
+// cell of the reference's label grid) go to LDS, then one thread per (cell, anchor) pair decodes its
+// prediction, finds its best IoU over those boxes and writes its whole gradient row.
+// ---------------------------------------------------------------------------
+struct V2LossArgs {
+    const float* net;      // [N][S][S][B][5+C]
+    const float* labels;   // [N][S][S][5+C]
+    const float* anchors;  // [B][2] cell units
+    float* dnet;           // same shape as net (nullable)
+    float* partial;        // [N][4] coord, object, noobject, class of one image
+    int N, S, B, C;
+    float image_size, coord, obj, noobj, cls, thresh;
+};
+constexpr int kV2MaxTruth = 1024;
+
+Y2_DEV float v2_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+Y2_DEV float v2_iou(float ax, float ay, float aw, float ah, float bx, float by, float bw, float bh) {
+    const float iw = fmaxf(0.0f, fminf(ax + aw / 2, bx + bw / 2) - fmaxf(ax - aw / 2, bx - bw / 2));
+    const float ih = fmaxf(0.0f, fminf(ay + ah / 2, by + bh / 2) - fmaxf(ay - ah / 2, by - bh / 2));
+    const float inter = iw * ih;
+    const float uni = aw * ah + bw * bh - inter;
+    return uni > 0.0f ? inter / uni : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void yolov2_loss_kernel(V2LossArgs a) {
+    __shared__ float tr[kV2MaxTruth][4];
+    __shared__ int ntr;
+    __shared__ float red[4][256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cells = a.S * a.S, D = 5 + a.C, LD = 5 + a.C;
+    const float fs = (float)a.S;
+    if (tid == 0) ntr = 0;
+    __syncthreads();
+    for (int cell = tid; cell < cells; cell += 256) {
+        const float* lab = a.labels + ((size_t)n * cells + cell) * LD;
+        if (lab[0] > 0.0f) {
+            const int k = atomicAdd(&ntr, 1);
+            tr[k][0] = lab[1] / a.image_size * fs; tr[k][1] = lab[2] / a.image_size * fs;
+            tr[k][2] = lab[3] / a.image_size * fs; tr[k][3] = lab[4] / a.image_size * fs;
+        }
+    }
+    __syncthreads();
+    const int nt = ntr;
+    float t_coord = 0.f, t_obj = 0.f, t_noobj = 0.f, t_cls = 0.f;
+    const float invN = 1.0f / (float)a.N;
+    for (int p = tid; p < cells * a.B; p += 256) {
+        const int cell = p / a.B, b = p - cell * a.B;
+        const int row = cell / a.S, col = cell - row * a.S;
+        const float* t = a.net + (((size_t)n * cells + cell) * a.B + b) * D;
+        float* g = a.dnet ? a.dnet + (((size_t)n * cells + cell) * a.B + b) * D : nullptr;
+        const float* lab = a.labels + ((size_t)n * cells + cell) * LD;
+        const float aw = a.anchors[2 * b], ah = a.anchors[2 * b + 1];
+        const float sx = v2_sigmoid(t[0]), sy = v2_sigmoid(t[1]), so = v2_sigmoid(t[4]);
+        const float px = sx + (float)col, py = sy + (float)row, pw = aw * expf(t[2]), ph = ah * expf(t[3]);
+        bool responsible = false;
+        float gx = 0.f, gy = 0.f, gw = 1.f, gh = 1.f;
+        if (lab[0] > 0.0f) {
+            gx = lab[1] / a.image_size * fs; gy = lab[2] / a.image_size * fs;
+            gw = lab[3] / a.image_size * fs; gh = lab[4] / a.image_size * fs;
+            int bs = 0;
+            float bi = -1.0f;
+            for (int k = 0; k < a.B; ++k) {   // the anchor whose shape fits best, first one on ties
+                const float kw = a.anchors[2 * k], kh = a.anchors[2 * k + 1];
+                const float inter = fminf(gw, kw) * fminf(gh, kh);
+                const float si = inter / (gw * gh + kw * kh - inter);
+                if (si > bi) { bi = si; bs = k; }
+            }
+            responsible = (bs == b);
+        }
+        if (responsible) {
+            const float ex = sx - (gx - (float)col), ey = sy - (gy - (float)row);
+            const float ew = t[2] - logf(gw / aw), eh = t[3] - logf(gh / ah);
+            t_coord += a.coord * (ex * ex + ey * ey + ew * ew + eh * eh);
+            const float iou = v2_iou(px, py, pw, ph, gx, gy, gw, gh);
+            const float eo = so - iou;
+            t_obj += a.obj * eo * eo;
+            int k = 0;
+            float bestl = lab[5], m = t[5];
+            for (int c = 1; c < a.C; ++c) {
+                if (lab[5 + c] > bestl) { bestl = lab[5 + c]; k = c; }     // class = argmax of the one-hot
+                m = fmaxf(m, t[5 + c]);
+            }
+            float se = 0.f;
+            for (int c = 0; c < a.C; ++c) se += expf(t[5 + c] - m);
+            const float lse = m + logf(se);
+            t_cls += a.cls * (lse - t[5 + k]);
+            if (g) {
+                g[0] = a.coord * 2.0f * ex * sx * (1.0f - sx) * invN;
+                g[1] = a.coord * 2.0f * ey * sy * (1.0f - sy) * invN;
+                g[2] = a.coord * 2.0f * ew * invN;
+                g[3] = a.coord * 2.0f * eh * invN;
+                g[4] = a.obj * 2.0f * eo * so * (1.0f - so) * invN;
+                for (int c = 0; c < a.C; ++c)
+                    g[5 + c] = a.cls * (expf(t[5 + c] - lse) - (c == k ? 1.0f : 0.0f)) * invN;
+            }
+        } else {
+            float best = 0.f;
+            for (int k = 0; k < nt; ++k) best = fmaxf(best, v2_iou(px, py, pw, ph, tr[k][0], tr[k][1], tr[k][2], tr[k][3]));
+            const bool pen = best <= a.thresh;
+            if (pen) t_noobj += a.noobj * so * so;
+            if (g) {
+                g[0] = g[1] = g[2] = g[3] = 0.f;
+                g[4] = pen ? a.noobj * 2.0f * so * so * (1.0f - so) * invN : 0.f;
+                for (int c = 0; c < a.C; ++c) g[5 + c] = 0.f;
+            }
+        }
+    }
+    red[0][tid] = t_coord; red[1][tid] = t_obj; red[2][tid] = t_noobj; red[3][tid] = t_cls;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s)
+            for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + s];
+        __syncthreads();
+    }
+    if (tid < 4) a.partial[n * 4 + tid] = red[tid][0];
+}
+__global__ void yolov2_loss_finalize_kernel(const float* partial, float* loss, int N) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < 4; ++k) p[k] += partial[n * 4 + k];
+    float tot = 0.f;
+    for (int k = 0; k < 4; ++k) { loss[k] = p[k] / (float)N; tot += loss[k]; }
+    loss[4] = tot;
+}
+
 extern "C" {
 
 int y2_maxpool2x2(const float* x, float* y, int N, int H, int W, int C, void* stream) {
@@ -324,6 +466,36 @@ int y2_nms(const float* boxes, const float* scores, const int* classes, int N, i
     else if (K <= 2048) NMS_LAUNCH(2048);
     else NMS_LAUNCH(4096);
 #undef NMS_LAUNCH
+    EXTCHK(hipGetLastError());
+    return Y2_OK;
+}
+
+int y2_accumulate(float* dst, const float* src, size_t n, void* stream) {
+    if (!dst || !src) return fail(Y2_ERR_ARG, "null tensor");
+    const size_t n4 = n / 4;
+    size_t nb = (n4 + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(accumulate_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (float4*)dst,
+                       (const float4*)src, n4, dst, src, n4 * 4, n);
+    EXTCHK(hipGetLastError());
+    return Y2_OK;
+}
+
+size_t y2_yolov2_loss_workspace_bytes(int batch) { return (size_t)batch * 4 * sizeof(float) + 256; }
+
+int y2_yolov2_loss(const float* net, const float* labels, const float* anchors, int batch, int S, int B, int num_class,
+                   float image_size, const float* scales, float* loss, float* dnet, void* workspace, void* stream) {
+    if (!net || !labels || !anchors || !loss || !workspace) return fail(Y2_ERR_ARG, "null tensor");
+    if (batch < 1 || S < 1 || S * S > kV2MaxTruth || B < 1 || num_class < 1) return fail(Y2_ERR_ARG, "bad loss geometry");
+    V2LossArgs a{};
+    a.net = net; a.labels = labels; a.anchors = anchors; a.dnet = dnet; a.partial = (float*)workspace;
+    a.N = batch; a.S = S; a.B = B; a.C = num_class; a.image_size = image_size;
+    a.coord = scales ? scales[0] : 1.0f; a.obj = scales ? scales[1] : 5.0f; a.noobj = scales ? scales[2] : 1.0f;
+    a.cls = scales ? scales[3] : 1.0f; a.thresh = scales ? scales[4] : 0.6f;
+    hipLaunchKernelGGL(yolov2_loss_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, a);
+    EXTCHK(hipGetLastError());
+    hipLaunchKernelGGL(yolov2_loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a.partial, loss, batch);
     EXTCHK(hipGetLastError());
     return Y2_OK;
 }

@@ -158,7 +158,8 @@ hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H
                              hipStream_t s);
 hipError_t launch_pack_act(int dtype, const float* in, void* xp, int N, int H, int W, int C, int Cs,
                            hipStream_t s);
-hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s);
+hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s,
+                              float scale = 1.0f);
 
 // ---- batch norm
 struct BnFinalizeArgs {

@@ -114,6 +114,7 @@ struct y2_ctx {
     std::vector<hipEvent_t> mark_main, mark_side;
     int n_marks = 0;
     const int* cur_marks = nullptr;
+    float* dinput = nullptr;        // y2_backward_input: gradient wrt the stack's input, fp32 [N,H,W,cin]
     std::vector<ProfRec> prof_recs;
     size_t prof_used = 0;
     size_t sz() const { return dtype_size(dtype); }
@@ -438,7 +439,7 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
         p.W = params + y.pW;
         p.w_off = y.pW;
         p.wf = c->ws + y.wf;
-        p.wd = (training && l > 0) ? (void*)(c->ws + y.wd) : nullptr;
+        p.wd = training ? (void*)(c->ws + y.wd) : nullptr;   // layer 0 too: y2_backward_input wants its dgrad
         p.taps = y.k * y.k; p.Cin = y.cin; p.Cout = y.cout; p.Cout_pad = y.cout_pad; p.Kc = y.cin_s;
         p.Cin_pad = y.cin_pad; p.Cdy = y.ldy;
         p.wf_frag = conv_filter_layout(p.taps, y.W, y.cin_s * (int)c->sz(), y.cout, y.M);   // forward launch
@@ -471,8 +472,10 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
             rg.push_back((unsigned)c->L[l].pb);
             rg.push_back((unsigned)(3 * c->L[l].cout));
         }
+        // first filter: a dy_0 that overflows at its own store makes every dW_0[t][ci][co] of its channel co
+        // non-finite (inf * x, or inf * 0 = NaN), so one (tap 0, ci 0) row of couts is a complete sentinel
         rg.push_back((unsigned)c->L[0].pW);
-        rg.push_back((unsigned)((size_t)c->L[0].k * c->L[0].k * c->L[0].cin * c->L[0].cout));
+        rg.push_back((unsigned)(c->L[0].first3 ? 27 * c->L[0].cout : c->L[0].cout));
         c->n_chkranges = (int)(rg.size() / 2);
         HIPCHK(hipMemcpyAsync(c->ws + c->o_chkranges, rg.data(), rg.size() * sizeof(unsigned), hipMemcpyHostToDevice,
                               (hipStream_t)stream));
@@ -739,17 +742,17 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 forked = true;
             }
             { ProfScope _p(c, ws_, CAT_WGRAD); HIPCHK(launch_wgrad_auto(c->dtype, g, ws_)); }
-            if (l > 0) {
+            if (l > 0 || c->dinput) {
                 ConvArgs a{};
                 a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
                 a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.ldy; a.M = y.M; a.Cout = y.cin; a.ldy = y.cin;
                 a.taps = y.k * y.k;
                 int bp = 0;
-                const Layer& z = c->L[l - 1];
+                const Layer& z = c->L[l > 0 ? l - 1 : 0];
                 // the BN-backward reduce of the layer below rides in this dgrad's epilogue (it needs that layer's
                 // conv output, scale and shift beside the dA tile the epilogue holds anyway); the first layer
                 // keeps its own recomputing reduce
-                const bool fuse = !no_fuse && l - 1 >= layer_lo && !z.first3 && z.ldy == y.cin;
+                const bool fuse = !no_fuse && l > 0 && l - 1 >= layer_lo && !z.first3 && z.ldy == y.cin;
                 if (fuse) {
                     float* zs = (float*)(c->ws + z.stat);
                     a.bw_y = c->ws + (z.pool ? z.ysel : z.y);   // same pixel grid as this launch's output either way
@@ -758,6 +761,8 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s, &bp)); }
                 if (fuse) fused_P = (y.M + bp - 1) / bp;
                 c->dA_cur ^= 1;
+                if (l == 0)   // the stack's input gradient leaves in fp32 NHWC, loss scale divided out
+                    HIPCHK(launch_cast_to_f32(c->dtype, dA[c->dA_cur], c->dinput, (size_t)y.M, y.cin, y.cin, s, inv_gs));
             }
         }
         for (int k = 0; k < c->n_marks; ++k)
@@ -794,6 +799,17 @@ int y2_backward_marks(y2_ctx* c, const float* dout, int n_marks, const int* mark
     const int rc = y2_backward(c, dout, 0, (int)c->L.size(), stream);
     c->n_marks = 0;
     c->cur_marks = nullptr;
+    return rc;
+}
+// Full backward pass that also returns the gradient with respect to the stack's INPUT (fp32 NHWC [N,H,W,cin]):
+// what a composed graph needs of a stack that is not fed by a placeholder (the YOLOv2 detector's 13x13 and head
+// stacks).  Not available for the 3-channel first layer (the reference never differentiates the image either).
+int y2_backward_input(y2_ctx* c, const float* dout, float* dinput, void* stream) {
+    if (!dinput) return fail(Y2_ERR_ARG, "null input gradient");
+    if (c->L.empty() || c->L[0].first3) return fail(Y2_ERR_ARG, "the 3-channel image layer has no input gradient");
+    c->dinput = dinput;
+    const int rc = y2_backward(c, dout, 0, (int)c->L.size(), stream);
+    c->dinput = nullptr;
     return rc;
 }
 int y2_wait_mark(y2_ctx* c, int k, void* stream) {

@@ -89,24 +89,26 @@ hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H
 
 // [rows][lds] of T -> fp32 [rows][C]
 template <typename T>
-__global__ void cast_f32_kernel(const T* src, float* dst, size_t rows, int C, int lds) {
+__global__ void cast_f32_kernel(const T* src, float* dst, size_t rows, int C, int lds, float scale) {
     const size_t total = rows * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / C;
         const int c = (int)(i % C);
-        dst[i] = Elem<T>::to_f32(src[r * lds + c]);
+        const float v = Elem<T>::to_f32(src[r * lds + c]);
+        dst[i] = scale == 1.0f ? v : v * scale;
     }
 }
-hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s) {
+hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s,
+                              float scale) {
     size_t total = rows * C;
     size_t nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;
     if (nb < 1) nb = 1;
     dim3 g((unsigned)nb), b(256);
     switch (dtype) {
-        case 0: hipLaunchKernelGGL(cast_f32_kernel<float>, g, b, 0, s, (const float*)src, dst, rows, C, lds); break;
-        case 1: hipLaunchKernelGGL(cast_f32_kernel<half_t>, g, b, 0, s, (const half_t*)src, dst, rows, C, lds); break;
-        case 2: hipLaunchKernelGGL(cast_f32_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)src, dst, rows, C, lds); break;
+        case 0: hipLaunchKernelGGL(cast_f32_kernel<float>, g, b, 0, s, (const float*)src, dst, rows, C, lds, scale); break;
+        case 1: hipLaunchKernelGGL(cast_f32_kernel<half_t>, g, b, 0, s, (const half_t*)src, dst, rows, C, lds, scale); break;
+        case 2: hipLaunchKernelGGL(cast_f32_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)src, dst, rows, C, lds, scale); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

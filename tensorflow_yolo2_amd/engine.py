@@ -206,6 +206,13 @@ class Network:
             assert dout.is_cuda and dout.dtype == torch.float32 and dout.is_contiguous()
         check(self.lib.y2_backward(self.h, _ptr(dout), layer_lo, layer_hi, _stream()))
 
+    def backward_input(self, dout):
+        """full backward; also returns d loss / d input of the stack, fp32 [N,H,W,cin] (composed graphs)"""
+        assert dout.is_cuda and dout.dtype == torch.float32 and dout.is_contiguous()
+        dx = torch.empty((self.batch, self.height, self.width, self.spec[0][1]), dtype=torch.float32, device=self.device)
+        check(self.lib.y2_backward_input(self.h, _ptr(dout), _ptr(dx), _stream()))
+        return dx
+
     PROFILE_CATEGORIES = ("conv_fwd", "conv1_fwd", "dgrad", "wgrad", "conv1_wgrad", "bn_fwd", "bn_bwd", "misc")
 
     def backward_marks(self, dout, mark_layers):
@@ -529,6 +536,15 @@ def passthrough_concat_backward(dout, cf):
     return dfine, dcoarse
 
 
+def accumulate(dst, src):
+    """dst += src (fp32 device tensors of equal size)"""
+    lib = _lib.load()
+    assert dst.is_cuda and dst.dtype == torch.float32 and dst.is_contiguous() and src.is_contiguous()
+    assert dst.numel() == src.numel() and src.dtype == torch.float32
+    check(lib.y2_accumulate(_ptr(dst), _ptr(src), dst.numel(), _stream()))
+    return dst
+
+
 def decode_anchors(net, anchors):
     """net [N,S,S,B,5+C], anchors [B,2] -> boxes [N,S*S*B,4], scores [N,S*S*B,C]"""
     lib = _lib.load()
@@ -540,6 +556,27 @@ def decode_anchors(net, anchors):
     scores = torch.empty((n, s * s * b, c), dtype=torch.float32, device=net.device)
     check(lib.y2_decode_anchors(_ptr(net), _ptr(an), _ptr(boxes), _ptr(scores), n, s, b, c, _stream()))
     return boxes, scores
+
+
+def yolov2_loss(net, labels, anchors, image_size, need_grad=True, scales=None):
+    """anchor-box loss of the YOLOv2 head (oracle/ext_ref.py yolov2_loss): net [N,S,S,B,5+C], labels [N,S,S,5+C]
+    -> (loss[5] = coord, object, noobject, class, total; dnet or None)"""
+    lib = _lib.load()
+    assert net.is_cuda and net.dtype == torch.float32 and net.is_contiguous() and net.dim() == 5
+    n, s, _, b, d = net.shape
+    labels = labels.contiguous().float()
+    assert tuple(labels.shape) == (n, s, s, d), labels.shape
+    an = torch.as_tensor(np.asarray(anchors, np.float32)).to(net.device).contiguous()
+    sc = None
+    if scales is not None:
+        sc = torch.as_tensor(np.asarray([scales[k] for k in ("coord_scale", "object_scale", "noobject_scale",
+                                                              "class_scale", "thresh")], np.float32)).to(net.device)
+    loss = torch.empty(5, dtype=torch.float32, device=net.device)
+    dnet = torch.empty_like(net) if need_grad else None
+    ws = torch.empty(lib.y2_yolov2_loss_workspace_bytes(n), dtype=torch.uint8, device=net.device)
+    check(lib.y2_yolov2_loss(_ptr(net), _ptr(labels), _ptr(an), n, s, b, d - 5, float(image_size), _ptr(sc), _ptr(loss),
+                             _ptr(dnet), _ptr(ws), _stream()))
+    return loss, dnet
 
 
 def nms(boxes, scores, classes=None, iou_thresh=0.5, score_thresh=0.0, max_out=100, class_aware=False):

@@ -100,6 +100,22 @@ class GradReducer:
     def _range(self, lo, hi):
         return slice_range([o[0] for o in self.net._offsets], self.net.n_params, self.net.num_layers, lo, hi)
 
+    def reduce_all_async(self):
+        """SUM-reduce the whole gradient buffer on the communication stream once the work queued so far on the
+        current stream is done (a stack of a composed graph whose backward just ran); join() before the update"""
+        dist = _dist()
+        if dist is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            reduce_flat(self.net.grads, [(0, self.net.n_params)], dist, self.strategy)
+
+    def join(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
     def backward_and_reduce(self, dout):
         dist = _dist()
         net = self.net

@@ -205,3 +205,87 @@ def test_gpu_yolov2_composed_detector_matches_composed_oracle():
         refk = X.nms(b[i], s[i], c[i], 0.45, 0.02, 50, True)
         assert int(count[i]) == len(refk) > 0
         np.testing.assert_array_equal(keep[i, :len(refk)].cpu().numpy(), np.array(refk, np.int32))
+
+
+# ---------------------------------------------------------------- trainable YOLOv2 (anchor loss + composed backward)
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,S,size", [(3, 5, 160), (8, 13, 416), (1, 19, 608)])
+def test_gpu_yolov2_loss_matches_specification(n, S, size):
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from tensorflow_yolo2_amd.yolo2_nets.yolov2 import ANCHORS_VOC
+    rng = np.random.default_rng(n * 100 + S)
+    net = (rng.standard_normal((n, S, S, 5, 25)) * 0.7).astype(np.float32)
+    lab = synthetic.det_labels(n, size, S, 5 + n)
+    if n > 2:
+        lab[1] = 0                                        # an image without objects
+    ref_loss, ref_d = X.yolov2_loss(net, lab, ANCHORS_VOC, size, dtype=np.float64)
+    loss, dnet = E.yolov2_loss(dev(net), dev(lab), ANCHORS_VOC, size)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=2e-5)
+    err = np.abs(dnet.cpu().numpy() - ref_d).max() / np.abs(ref_d).max()
+    assert err < 2e-5, err
+    # forward only, and other scales
+    sc = dict(coord_scale=2.0, object_scale=3.0, noobject_scale=0.5, class_scale=1.5, thresh=0.4)
+    l2, d2 = E.yolov2_loss(dev(net), dev(lab), ANCHORS_VOC, size, need_grad=False, scales=sc)
+    r2, _ = X.yolov2_loss(net, lab, ANCHORS_VOC, size, dtype=np.float64, **sc)
+    assert d2 is None
+    np.testing.assert_allclose(l2.cpu().numpy(), r2, rtol=2e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_yolov2_train_step_gradients_match_composed_oracle():
+    """The north star's TRAINABLE model at reduced width (f32): forward, anchor loss and the backward pass through
+    head -> passthrough concat -> 13x13 stack -> 2x2 pool (+ the passthrough branch) -> stem, against the same
+    composition of the oracle's pieces; then optimizer steps in f32 and f16 keep the loss falling and finite."""
+    import torch
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from tensorflow_yolo2_amd.yolo2_nets import yolov2
+    n, size = 2, 96
+    S = size // 32
+    tr = yolov2.YOLOv2Trainer(n, size, dtype="f32", seed=3, width_div=8)
+    sa, sb, sc = tr.specs
+    x = synthetic.images(n, size, 21)
+    lab = synthetic.det_labels(n, size, S, 22)
+    stem, deep, head = tr.nets
+    pa, pb, pc = stem.export_params(), deep.export_params(), head.export_params()
+    # ---- oracle composition, float64
+    fine, ca, _ = R.run_stack(x, pa, sa, True, np.float64)
+    pooled = R.max_pool_2x2(fine)
+    coarse, cb, _ = R.run_stack(pooled, pb, sb, True, np.float64)
+    cat = X.passthrough_concat(fine, coarse)
+    out, cc, _ = R.run_stack(cat, pc, sc, True, np.float64)
+    ref_loss, dnet = X.yolov2_loss(out.reshape(n, S, S, 5, 25), lab, tr.anchors, size)
+    dcat, gc = R.run_stack_backward(pc, cc, dnet.reshape(out.shape), np.float64, need_input_grad=True)
+    dfine_a, dcoarse = X.passthrough_concat_backward(dcat, tr.cf)
+    dpooled, gb = R.run_stack_backward(pb, cb, dcoarse, np.float64, need_input_grad=True)
+    dfine = dfine_a + R.max_pool_2x2_backward(fine, dpooled)
+    _, ga = R.run_stack_backward(pa, ca, dfine, np.float64)
+    # ---- device: the same step without the optimizer
+    grid, fine_d = tr.forward(dev(x), True)
+    assert np.abs(grid.cpu().numpy().reshape(out.shape) - out).max() < 1e-3 * np.abs(out).max()
+    loss, dn = E.yolov2_loss(grid.contiguous(), dev(lab), tr.anchors, size)
+    assert abs(loss[4].item() - ref_loss[4]) < 1e-3 * ref_loss[4]
+    dcat_d = head.backward_input(dn.view(n, S, S, -1))
+    assert np.abs(dcat_d.cpu().numpy() - dcat).max() < 2e-3 * np.abs(dcat).max()
+    df_d, dc_d = E.passthrough_concat_backward(dcat_d, tr.cf)
+    dp_d = deep.backward_input(dc_d)
+    E.accumulate(df_d, E.max_pool_2x2_backward(fine_d, dp_d))
+    assert np.abs(df_d.cpu().numpy() - dfine).max() < 5e-3 * np.abs(dfine).max()
+    stem.backward(df_d)
+    for net, ref, name in ((head, gc, "head"), (deep, gb, "deep"), (stem, ga, "stem")):
+        g = net.export_grads()
+        for l in (0, len(g) - 1):
+            e = np.linalg.norm(g[l]["W"] - ref[l]["W"]) / np.linalg.norm(ref[l]["W"])
+            assert e < 2e-2, (name, l, e)
+    # ---- whole steps: the loss falls, everything stays finite (f32 and the benchmarked f16 mode)
+    for dtype in ("f32", "f16"):
+        t2 = yolov2.YOLOv2Trainer(n, size, dtype=dtype, seed=3, width_div=8)
+        losses = [float(t2.step(dev(x), dev(lab))[4]) for _ in range(8)]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], (dtype, losses)
+        for net in t2.nets:
+            assert torch.isfinite(net.params).all()
+    # multi-scale: another input size on the same three parameter sets
+    x2 = synthetic.images(n, 128, 5)
+    l2 = t2.step(dev(x2), dev(synthetic.det_labels(n, 128, 4, 6)))
+    assert np.isfinite(float(l2[4])) and len(t2.ctx) == 2
+    assert t2.ctx[128][0].params.data_ptr() == t2.ctx[96][0].params.data_ptr()
