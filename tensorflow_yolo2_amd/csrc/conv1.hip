@@ -372,13 +372,22 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
         for (int ps = 0; ps < 16 / RPIe; ++ps) {
             const int j = ps * RPIe + pl;                   // pooled pixel of the tile, 0..15
             float m[EPC];
+            Chunk<T> ys;
+            unsigned arg = 0;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 Chunk<T> c = ld_chunk<T>(ew + ((d >> 1) * 32 + 2 * j + (d & 1)) * EROW + ch * 16);
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) m[e] = fmaxf(m[e], leaky01(fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e])));
+                for (int e = 0; e < EPC; ++e) {
+                    const float act = leaky01(fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]));
+                    if (act > m[e]) {          // first maximum in row-major window order
+                        m[e] = act;
+                        ys.v[e] = c.v[e];
+                        arg = (arg & ~(3u << (2 * e))) | ((unsigned)d << (2 * e));
+                    }
+                }
             }
             const int wo = w0 / 2 + j;
             if (wo < Wo) {
@@ -386,6 +395,11 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(m[e]);
                 st_chunk<T>((char*)a.out + (bpix(n, ho, wo, Ho, Wo) * 32 + ch * EPC) * SZ, o);
+                if (a.ysel) {
+                    const size_t pix = ((size_t)n * Ho + ho) * Wo + wo;
+                    st_chunk<T>((char*)a.ysel + (pix * 32 + ch * EPC) * SZ, ys);
+                    a.idx[pix * CPR + ch] = (unsigned short)arg;
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

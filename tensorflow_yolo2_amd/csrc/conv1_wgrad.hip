@@ -368,4 +368,306 @@ hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hip
     return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------
+// LINEAR form for the pooled first layer (kernels.h: Conv1WgradLinArgs): nothing of the first layer's conv
+// output is read -- it is never stored.  Per row pair: the four input rows go to LDS, dz (= dA * leaky'(z) at the
+// window's arg-max position, zero at the other three: both from the forward pass's ysel / idx) is scattered into
+// two LDS row images, and the tr-read MFMAs accumulate X(dz) and the Gram matrix G of the input patches.
+// Streams x4 + dA + ysel + idx = 42 B per pixel pair-of-rows-quarter instead of y + dA + x4 = 88 B/pixel.
+// Each block leaves its partial [48*32 + 48*48] in `part`; conv1_lin_reduce adds the blocks (fixed order: no
+// atomics, run-to-run identical), conv1_dw_finalize combines with the BN-backward constants.
+// ---------------------------------------------------------------------------
+constexpr int kLinAcc = 48 * 32 + 48 * 48;
+
+constexpr int kLinThreads = 256;   // measured: 512 threads + register prefetch of the next row pair 297 us, this form 252
+constexpr int kLinItems = 0;     // items (pooled pixel x chunk) per thread held in registers one row pair ahead
+
+template <typename T>
+__global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1WgradLinArgs a, float* part) {
+    // also the BN-backward REDUCE of this layer, for free: dA and ysel pass through here anyway, and nothing in this
+    // kernel needs the sums (S1 = sum g, S2 = sum g * ysel -> psum[block][2][32]; the finalize runs after it)
+    constexpr int SZ = sizeof(T), EPC = 16 / SZ, CPP = 32 / EPC;
+    constexpr int DYP = 32 * SZ, XP = 4 * SZ;
+    constexpr int NTH = kLinThreads, NW = NTH / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wp = (a.W + 15) & ~15;
+    const int dz_bytes = Wp * DYP;
+    const int x_bytes = ((Wp + 4) * XP + 15) & ~15;
+    char* dz_l = smem;                   // [2 rows][Wp][32]
+    char* x_l = smem + 2 * dz_bytes;     // [4 rows][x_bytes]
+    const int x_chunks = x_bytes / 16;
+    const int Ho = a.H / 2, Wo = a.W / 2;
+    const int prs = a.N * Ho;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+
+    for (int i = tid; i < 2 * (Wp - a.W) * CPP; i += NTH) {     // k-padding pixels of the dz rows: zero, once
+        const int r = i / ((Wp - a.W) * CPP), j = i % ((Wp - a.W) * CPP);
+        *(u32x4*)(dz_l + r * dz_bytes + a.W * DYP + j * 16) = u32x4{0, 0, 0, 0};
+    }
+    const int ch = tid % CPP, c0 = ch * EPC;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = a.scale[c0 + e];
+        sh[e] = a.shift[c0 + e];
+    }
+    f32x16 acc1, acc2, g11, g12, g22;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1[q] = acc2[q] = g11[q] = g12[q] = g22[q] = 0.f;
+    float s1[EPC], s2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+
+    const int nitems = Wo * CPP;
+    // the dA / ysel / idx of a row pair are requested while the MFMAs of the previous one run (two blocks of eight
+    // waves per CU: in-place loads leave the HBM latency of every row pair exposed)
+    u32x4 pda[kLinItems ? kLinItems : 1], pys[kLinItems ? kLinItems : 1];
+    unsigned pix_[kLinItems ? kLinItems : 1];
+    auto prefetch = [&](int pr) {
+        const int n = pr / Ho, ho = pr - n * Ho;
+        const size_t prow = ((size_t)n * Ho + ho) * Wo;
+#pragma unroll
+        for (int k = 0; k < kLinItems; ++k) {
+            const int item = tid + k * NTH;
+            if (item < nitems) {
+                pda[k] = *(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16);
+                pys[k] = *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16);
+                pix_[k] = a.idx[prow * CPP + item];
+            }
+        }
+    };
+    auto process = [&](const u32x4& dar, const u32x4& ysr, unsigned ix, int item) {
+        const int wo = item / CPP;
+        Chunk<T> dav, ysv;
+        *(u32x4*)dav.v = dar;
+        *(u32x4*)ysv.v = ysr;
+        T gz[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float yf = Elem<T>::to_f32(ysv.v[e]);
+            const float g = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yf, sc[e], sh[e]));
+            s1[e] += g;
+            s2[e] = fmaf(g, yf, s2[e]);
+            gz[e] = Elem<T>::from_f32(g);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            Chunk<T> o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] = (((ix >> (2 * e)) & 3u) == (unsigned)d) ? gz[e] : Elem<T>::from_f32(0.f);
+            st_chunk<T>(dz_l + (d >> 1) * dz_bytes + (size_t)(2 * wo + (d & 1)) * DYP + ch * 16, o);
+        }
+    };
+    if (kLinItems && (int)blockIdx.x < prs) prefetch(blockIdx.x);
+    for (int pr = blockIdx.x; pr < prs; pr += gridDim.x) {
+        const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho;
+        const char* xrow = (const char*)a.x4 + (bpix(n, h0, 0, a.H, a.W) - (size_t)(a.W + 2)) * XP;
+        const size_t xpitch = (size_t)(a.W + 1) * XP;
+        __syncthreads();   // previous row pair fully consumed
+        for (int kh = 0; kh < 4; ++kh)
+            for (int i0 = w * 64; i0 < x_chunks; i0 += NTH) {
+                const int i = i0 + lane;
+                if (i < x_chunks) glds16(xrow + kh * xpitch + (size_t)i * 16, x_l + kh * x_bytes + i0 * 16);
+            }
+        const size_t prow = ((size_t)n * Ho + ho) * Wo;
+#pragma unroll
+        for (int k = 0; k < kLinItems; ++k) {
+            const int item = tid + k * NTH;
+            if (item < nitems) process(pda[k], pys[k], pix_[k], item);
+        }
+        for (int item = tid + kLinItems * NTH; item < nitems; item += NTH)      // wider images: the rest in place
+            process(*(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16),
+                    *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16), a.idx[prow * CPP + item], item);
+        if (kLinItems && pr + (int)gridDim.x < prs) prefetch(pr + gridDim.x);
+        __syncthreads();   // LDS-DMA drained (vmcnt(0)) and the dz images complete
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const char* dzr = dz_l + r * dz_bytes;
+            for (int s = w; s * 16 < a.W; s += NW) {
+                const int w0 = s * 16;
+                if constexpr (SZ == 2) {
+                    const int pix = w0 + 8 * hh + qq;
+                    const char* pb = dzr + pix * DYP + (16 * g1 + 4 * pp) * 2;
+                    typename Elem<T>::frag fb = tr_frag<T>(pb, pb + 4 * DYP);
+                    const char* pa1 = x_l + (r + g1) * x_bytes + (pix + pp) * XP;
+                    typename Elem<T>::frag fa1 = tr_frag<T>(pa1, pa1 + 4 * XP);
+                    const char* pa2 = x_l + (r + 2) * x_bytes + (pix + pp) * XP;
+                    typename Elem<T>::frag fa2 = tr_frag<T>(pa2, pa2 + 4 * XP);
+                    // Gram operands: the SAME registers serve as B (k = pixel on both sides); k-padding pixels of
+                    // the last group hold the next row's data in the x image: masked out of one side
+                    typename Elem<T>::frag fg1 = fa1, fg2 = fa2;
+                    if (w0 + 16 > a.W) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (w0 + 8 * hh + j >= a.W) { fg1[j] = (T)0.f; fg2[j] = (T)0.f; }
+                    }
+                    mma32(acc1, fa1, fb);
+                    mma32(acc2, fa2, fb);
+                    mma32(g11, fa1, fg1);
+                    mma32(g12, fa1, fg2);
+                    mma32(g22, fa2, fg2);
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        const int pix = w0 + 2 * k2 + hh;
+                        const float vm = pix < a.W ? 1.f : 0.f;
+                        const float b = *(const float*)(dzr + pix * DYP + r32 * 4);
+                        const float a1 = *(const float*)(x_l + (r + (r32 >> 4)) * x_bytes + pix * XP + (r32 & 15) * 4);
+                        const float a2 = *(const float*)(x_l + (r + 2) * x_bytes + pix * XP + (r32 & 15) * 4);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b, acc2, 0, 0, 0);
+                        g11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1 * vm, g11, 0, 0, 0);
+                        g12 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a2 * vm, g12, 0, 0, 0);
+                        g22 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, a2 * vm, g22, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- the waves through LDS, four at a time (fixed order) -> this block's partial: Xdz [48][32] then G [48][48]
+    float* red = (float*)smem;   // [4][kLinAcc] (G's lower-left block is filled by symmetry in the finalize)
+    constexpr int PER = (kLinAcc + NTH - 1) / NTH;
+    float tot[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) tot[k] = 0.f;
+    for (int round = 0; round < NW / 4; ++round) {
+        __syncthreads();
+        if ((w >> 2) == round) {
+            float* o = red + (w & 3) * kLinAcc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = acc_row(q, hh);
+                o[r * 32 + r32] = acc1[q];
+                if (r < 16) o[(32 + r) * 32 + r32] = acc2[q];
+                float* g = o + 48 * 32;
+                g[r * 48 + r32] = g11[q];
+                if (r32 < 16) g[r * 48 + 32 + r32] = g12[q];
+                if (r < 16 && r32 < 16) g[(32 + r) * 48 + 32 + r32] = g22[q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * NTH;
+            if (i < kLinAcc) {
+                bool used = true;
+                if (i >= 48 * 32) {
+                    const int j = i - 48 * 32, r = j / 48, c = j % 48;
+                    used = !(r >= 32 && c < 32);
+                }
+                if (used) tot[k] += (red[i] + red[kLinAcc + i]) + (red[2 * kLinAcc + i] + red[3 * kLinAcc + i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * NTH;
+        if (i < kLinAcc) part[(size_t)blockIdx.x * kLinAcc + i] = tot[k];
+    }
+    // ---- BN-backward partial sums of this block: threads with the same chunk (tid % CPP) are CPP apart
+    __syncthreads();
+    float* sr = (float*)smem;    // [2][NTH][EPC]
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sr[tid * EPC + e] = s1[e];
+        sr[(NTH + tid) * EPC + e] = s2[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int k = tid >> 5, cc = tid & 31;
+        const int chunk = cc / EPC, e = cc % EPC;
+        float t = 0.f;
+        for (int j = chunk; j < NTH; j += CPP) t += sr[(k * NTH + j) * EPC + e];
+        a.psum[((size_t)blockIdx.x * 2 + k) * 32 + cc] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_lin_reduce_kernel(const float* part, int nblocks, float* acc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kLinAcc) return;
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 3 < nblocks; b += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v4[u] += part[(size_t)(b + u) * kLinAcc + i];
+    for (; b < nblocks; ++b) v4[0] += part[(size_t)b * kLinAcc + i];
+    acc[i] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+}
+
+// dW[t][c][co] = inv_gs * (scale X(dz) - ka X(1) - kb (G W + b X(1)))   (rows r = kh*16 + kw*4 + c)
+__global__ __launch_bounds__(1024) void conv1_dw_finalize_kernel(Conv1DwFinalizeArgs a) {
+    __shared__ float G[48][49];
+    __shared__ float Wp[48][32];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 48 * 48; i += 1024) {
+        const int r = i / 48, c = i % 48;
+        G[r][c] = (r >= 32 && c < 32) ? a.acc[48 * 32 + c * 48 + r] : a.acc[48 * 32 + i];   // symmetry
+    }
+    for (int i = tid; i < 48 * 32; i += 1024) {
+        const int r = i >> 5, co = i & 31;
+        const int kh = r >> 4, e = r & 15, kw = e >> 2, c = e & 3;
+        Wp[r][co] = (kw < 3 && c < 3) ? a.W[((kh * 3 + kw) * 3 + c) * 32 + co] : 0.f;
+    }
+    __syncthreads();
+    if (tid >= 27 * 32) return;
+    const int co = tid & 31, tc = tid >> 5;           // tc = (kh*3 + kw)*3 + c
+    const int c = tc % 3, kw = (tc / 3) % 3, kh = tc / 9;
+    const int r = kh * 16 + kw * 4 + c;
+    constexpr int kOnes = 1 * 16 + 1 * 4 + 3;          // centre tap, channel 3 (= 1 inside the image)
+    const float x1 = G[kOnes][r];
+    float gw = 0.f;
+    for (int k = 0; k < 48; ++k) gw = fmaf(G[r][k], Wp[k][co], gw);
+    const float xy = gw + a.bias[co] * x1;
+    const float xdz = a.acc[r * 32 + co];
+    const float ka = a.coef[co], kb = a.coef[32 + co];
+    a.dW[tc * 32 + co] = (a.scale[co] * xdz - ka * x1 - kb * xy) * a.inv_grad_scale;
+}
+
+template <typename T>
+static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
+    constexpr int SZ = sizeof(T);
+    const int Wp = (a.W + 15) & ~15;
+    size_t lds = 2 * (size_t)Wp * 32 * SZ + 4 * (size_t)((((Wp + 4) * 4 * SZ) + 15) & ~15);
+    size_t red = 4 * (size_t)kLinAcc * sizeof(float);
+    const size_t red2 = 2 * (size_t)kLinThreads * (16 / SZ) * sizeof(float);
+    if (red < red2) red = red2;
+    if (lds < red) lds = red;
+    if (lds > 160 * 1024) return hipErrorOutOfMemory;
+    auto kern = conv1_wgrad_lin_kernel<T>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int prs = a.N * (a.H / 2);
+    const int nb = prs < 512 ? prs : 512;
+    float* part = a.acc + kLinAcc;        // [nb][kLinAcc] behind the totals
+    if (a.nblocks_out) *a.nblocks_out = nb;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(kLinThreads), lds, s, a, part);
+    hipLaunchKernelGGL(conv1_lin_reduce_kernel, dim3((kLinAcc + 255) / 256), dim3(256), 0, s, part, nb, a.acc);
+    return hipGetLastError();
+}
+
+bool conv1_wgrad_lin_ok(int H, int W, int pool, int ldy, int elem_size) {
+    const int Wp = (W + 15) & ~15;
+    size_t lds = 2 * (size_t)Wp * 32 * elem_size + 4 * (size_t)((((Wp + 4) * 4 * elem_size) + 15) & ~15);
+    const size_t red = 4 * (size_t)kLinAcc * sizeof(float);
+    if (lds < red) lds = red;
+    return pool && (H % 2) == 0 && (W % 2) == 0 && ldy == 32 && lds <= 160 * 1024;
+}
+size_t conv1_wgrad_lin_scratch_floats() { return (size_t)kLinAcc * (1 + 512); }
+
+hipError_t launch_conv1_wgrad_lin(int dtype, const Conv1WgradLinArgs& a, hipStream_t s) {
+    switch (dtype) {
+        case 0: return c1lin_T<float>(a, s);
+        case 1: return c1lin_T<half_t>(a, s);
+        case 2: return c1lin_T<bf16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_conv1_dw_finalize(const Conv1DwFinalizeArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(conv1_dw_finalize_kernel, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace y2

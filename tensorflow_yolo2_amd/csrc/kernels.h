@@ -65,6 +65,11 @@ struct Conv1PoolArgs {
     int N, H, W;
     int nblocks;
     int store_y;
+    // training, linear form of the backward pass (conv1_wgrad.hip): instead of the conv output (64 B/pixel) keep,
+    // per pooled pixel, the conv output at the window's first arg-max (ysel [Mout][32] of T) and WHICH of the four
+    // positions it was (idx [Mout][chunks] u16: 2 bits per channel of a 16-byte chunk)
+    void* ysel = nullptr;
+    unsigned short* idx = nullptr;
 };
 // backward reduce pass of the same layer with the conv output recomputed (x4 + dA in, psum out)
 struct Conv1BnBwdArgs {
@@ -101,6 +106,36 @@ struct Conv1WgradFusedArgs {
 };
 bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy, int elem_size);
 hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s);
+// Linear form (no conv output of the first layer in HBM at all).  With dy = scale dz - (ka + kb y):
+//     dW = scale * X(dz) - ka * X(1) - kb * X(y),   X(v)[t][c][co] = sum_p x[p + t][c] v[p][co]
+// and y = conv(x, W) + b:  X(y) = G W + b X(1),  G = the Gram matrix of the 27-element input patches
+// (weights-independent).  The kernel accumulates X(dz) [48][32] and G [48][48] (rows kh*16 + kw*4 + c; channel 3
+// of the stored input is 1 inside the image, so G's row of the centre tap's channel 3 IS X(1)); a one-block
+// finalize combines them with the BN-backward constants.
+struct Conv1WgradLinArgs {
+    const void* x4;             // [N][H+2][W+2][4], channel 3 = 1 inside the image
+    const void* dA;             // [Mout][32] of T
+    const void* ysel;           // [Mout][32] of T
+    const unsigned short* idx;  // [Mout][chunks]
+    const float *scale, *shift;
+    float* acc;                 // [48*32 + 48*48] totals, followed by the per-block partials (conv1_wgrad_lin_scratch_floats)
+    float* psum;                // out: BN-backward partial sums [blocks][2][32] (S1, S2) -- the reduce pass rides here
+    int* nblocks_out;           // host: number of partial records written
+    int N, H, W;
+};
+struct Conv1DwFinalizeArgs {
+    const float* acc;           // as above
+    const float* W;             // fp32 HWIO [3][3][3][32]
+    const float* bias;
+    const float* scale;
+    const float* coef;          // [2][32] ka, kb
+    float* dW;                  // out [3][3][3][32]
+    float inv_grad_scale;
+};
+bool conv1_wgrad_lin_ok(int H, int W, int pool, int ldy, int elem_size);
+size_t conv1_wgrad_lin_scratch_floats();   // acc: totals + per-block partials
+hipError_t launch_conv1_wgrad_lin(int dtype, const Conv1WgradLinArgs& a, hipStream_t s);
+hipError_t launch_conv1_dw_finalize(const Conv1DwFinalizeArgs& a, hipStream_t s);
 
 // ---- weight-gradient GEMM  dW[t][ci][co] += sum_p X[p+t][ci] * dY[p][co]
 struct WgradArgs {

@@ -72,7 +72,7 @@ struct Layer {
     size_t pW, pb, pg, pbeta;  // float offsets into params / grads
     size_t smm, smv;           // float offsets into state
     // byte offsets into the workspace
-    size_t xin, y, stat, wf, wd, dyp, ysel;
+    size_t xin, y, stat, wf, wd, dyp, ysel, idx0;
 };
 
 struct y2_ctx {
@@ -98,7 +98,10 @@ struct y2_ctx {
     size_t part_rows, part_ld;
     size_t total_infer = 0, total_train = 0;
     int dA_cur = 0;
-    size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0;
+    // pooled 3-channel first layer, training: the linear form of its backward pass (conv1_wgrad.hip) -- its conv
+    // output is never stored
+    bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
+    size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0;
     int n_chkranges = 0, n_smallranges = 0, opt_tile_blocks = 0;
     std::vector<PackLayer> packtab;
     int pack_blocks = 0;
@@ -194,7 +197,11 @@ static void plan(y2_ctx* c) {
     for (size_t l = 0; l < c->L.size(); ++l) c->L[l].dyp = take(c->dy_geom((int)l).bytes(sz));
     for (size_t l = 0; l < c->L.size(); ++l) {   // pooled layers: conv output at the arg-max (BnActArgs::ysel)
         Layer& y = c->L[l];
-        y.ysel = (y.pool && !y.first3) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
+        const bool lin1 = y.first3 && c->L.size() > 1 && conv1_pool_ok(y.H, y.W, y.pool, y.cout) &&
+                          conv1_wgrad_lin_ok(y.H, y.W, y.pool, y.ldy, (int)sz);
+        y.ysel = (y.pool && (!y.first3 || lin1)) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
+        y.idx0 = lin1 ? take((size_t)c->N * y.Ho * y.Wo * (y.ldy * sz / 16) * sizeof(unsigned short) + 256) : 0;
+        if (lin1) c->o_lin = take(conv1_wgrad_lin_scratch_floats() * sizeof(float));
     }
     // BN-backward partial sums [P][2][ldy]: P <= 2048 from the reduce kernel, or one record per 128+ pixel tile
     // of the dgrad above when the reduce is fused into that dgrad's epilogue
@@ -593,7 +600,8 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             q.N = c->N; q.H = y.H; q.W = y.W;
             const int tiles = c->N * (y.H / 2) * ((y.W + 31) / 32);
             q.nblocks = (tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4;
-            q.store_y = c->bound_training ? 1 : 0;
+            q.store_y = (c->bound_training && !c->lin1()) ? 1 : 0;
+            if (c->lin1()) { q.ysel = c->ws + y.ysel; q.idx = (unsigned short*)(c->ws + y.idx0); }
             HIPCHK(launch_conv1_pool(c->dtype, q, s));
             continue;
         }
@@ -694,9 +702,21 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         const bool fused1 = y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz());
         const bool rec1 = y.first3 && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
                           conv1_pool_ok(y.H, y.W, y.pool, y.cout);
+        const bool lin1 = y.first3 && c->lin1();
         {
             PROF(CAT_BN_BWD);
-            if (rec1) {   // pooled first layer: recompute the conv output instead of reading it (80 -> 24 B/pixel)
+            if (lin1) {
+                // linear form: the reduce pass rides in the weight-gradient kernel, which does not need its result
+                Conv1WgradLinArgs g{};
+                g.x4 = c->ws + y.xin + c->in_geom(l).base_off(sz); g.dA = b.dA; g.ysel = c->ws + y.ysel;
+                g.idx = (const unsigned short*)(c->ws + y.idx0);
+                g.scale = b.scale; g.shift = b.shift; g.acc = (float*)(c->ws + c->o_lin); g.psum = psum;
+                int nbl = 0;
+                g.nblocks_out = &nbl;
+                g.N = c->N; g.H = y.H; g.W = y.W;
+                HIPCHK(launch_conv1_wgrad_lin(c->dtype, g, s));
+                b.P = nbl;
+            } else if (rec1) {   // pooled first layer: recompute the conv output instead of reading it (80 -> 24 B/pixel)
                 Conv1BnBwdArgs q{};
                 q.x4 = c->ws + y.xin + c->in_geom(l).base_off(sz); q.w = c->ws + y.wf; q.bias = c->params + y.pb;
                 q.scale = b.scale; q.shift = b.shift; q.dA = b.dA; q.psum = psum;
@@ -712,10 +732,17 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             }
             fused_P = 0;
             HIPCHK(launch_bn_bwd_finalize(b, s));
-            if (!fused1) HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
+            if (!fused1 && !lin1) HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
         }
         char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
-        if (fused1) {
+        if (lin1) {
+            // no conv output of this layer exists: dW = scale X(dz) - ka X(1) - kb (G W + b X(1))  (conv1_wgrad.hip)
+            Conv1DwFinalizeArgs f{};
+            f.acc = (float*)(c->ws + c->o_lin); f.W = c->params + y.pW; f.bias = c->params + y.pb; f.scale = b.scale;
+            f.coef = b.coef; f.dW = c->grads + y.pW; f.inv_grad_scale = inv_gs;
+            PROF(CAT_CONV1_WGRAD);
+            HIPCHK(launch_conv1_dw_finalize(f, s));
+        } else if (fused1) {
             // the first layer's dy has one consumer: apply pass and weight gradient in one kernel
             Conv1WgradFusedArgs g{};
             g.x4 = xin; g.y = b.y; g.dA = b.dA;
@@ -835,10 +862,22 @@ int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
         if (y.first3 && !c->bound_training && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
             conv1_pool_ok(y.H, y.W, y.pool, y.cout))
             return fail(Y2_ERR_STATE, "inference binding: the pooled first layer does not store its conv output");
+        if (y.first3 && c->lin1()) {   // the linear form never stores this layer's conv output: recompute it (tests)
+            Conv1Args a{};
+            a.x4 = c->ws + y.xin + c->in_geom(l).base_off(sz); a.w = c->ws + y.wf; a.y = c->ws + y.y;
+            a.bias = c->params + y.pb;
+            a.part_cnt = (float*)(c->ws + c->o_part_cnt); a.part_mean = (float*)(c->ws + c->o_part_mean);
+            a.part_m2 = (float*)(c->ws + c->o_part_m2);
+            a.N = c->N; a.H = y.H; a.W = y.W; a.M = y.M;
+            const int nb = (y.M + 127) / 128;
+            a.nblocks = nb > 2048 ? 2048 : nb;
+            a.stats_only = 0;
+            HIPCHK(launch_conv1_fwd(c->dtype, a, s));
+        }
         HIPCHK(launch_cast_to_f32(c->dtype, c->ws + y.y, dst, (size_t)y.M, y.cout, y.ldy, s));
     } else if (what == 2) {
         if (!c->bound_training) return fail(Y2_ERR_STATE, "no gradients in inference binding");
-        if (y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz()))
+        if (y.first3 && (c->lin1() || conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz())))
             return fail(Y2_ERR_STATE, "the first layer's dy is fused into its weight gradient and never stored");
         HIPCHK(launch_unpack_act(c->dtype, c->ws + y.dyp + c->dy_geom(l).base_off(sz), dst, c->N, y.H, y.W, y.cout,
                                  y.ldy, s));

@@ -7,7 +7,9 @@
 
 namespace y2 {
 
-// image fp32 [N][H][W][3] -> x4 [N][H+2][W+2][4] of T (channel 3 = 0); border pre-zeroed
+// image fp32 [N][H][W][3] -> x4 [N][H+2][W+2][4] of T; border pre-zeroed.  Channel 3 = 1 inside the image: its
+// filter weights are zero (pack_conv1_kernel), so the convolution ignores it, and the Gram matrix of the input
+// patches (conv1_wgrad.hip, linear form) gets its "sum of x over the valid taps" row from it for free
 template <typename T>
 __global__ void pack_input_kernel(const float* __restrict__ img, T* __restrict__ x4, int N, int H, int W) {
     const size_t total = (size_t)N * H * W;
@@ -20,7 +22,7 @@ __global__ void pack_input_kernel(const float* __restrict__ img, T* __restrict__
         d[0] = Elem<T>::from_f32(s[0]);
         d[1] = Elem<T>::from_f32(s[1]);
         d[2] = Elem<T>::from_f32(s[2]);
-        d[3] = Elem<T>::from_f32(0.f);
+        d[3] = Elem<T>::from_f32(1.f);
     }
 }
 template <typename T>
