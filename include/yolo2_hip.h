@@ -169,6 +169,38 @@ size_t y2_yolov2_loss_workspace_bytes(int batch);
 int y2_yolov2_loss(const float* net, const float* labels, const float* anchors, int batch, int S, int B, int num_class,
                    float image_size, const float* scales, float* loss, float* dnet, void* workspace, void* stream);
 
+/* ---- ResNet-50 backbone swap (src/yolo2_nets/tf_resnet.py:12-32, src/pascal/pascal_train_resnet.py:37-50):
+ *      graph-level operators on fp32 NHWC tensors that the conv-BN-leaky stacks do not have.  The 1x1 / 3x3
+ *      convolutions of the bottleneck units (slim_dir/nets/resnet_v1.py:68-112) go through y2_conv2d /
+ *      y2_conv2d_backward; a stride-2 unit = the stride-1 convolution + y2_subsample, slim's own definition of
+ *      conv2d_same (slim_dir/nets/resnet_utils.py:77-122). --------------------------------------------------- */
+/* slim.batch_norm (resnet_arg_scope: decay 0.997, epsilon 1e-5, scale; resnet_utils.py:230-257) on [rows][channels],
+ * + optional residual add (before the activation) + optional ReLU: y = act(gamma (x - mean) / sqrt(var + eps) + beta
+ * + residual).  is_training: batch statistics (saved in save_mean / save_var for the backward pass), moving
+ * statistics updated when update_moving; else the moving statistics normalise. */
+int y2_batch_norm_forward(const float* x, const float* residual, float* y, size_t rows, int channels, const float* gamma,
+                          const float* beta, float* moving_mean, float* moving_var, float* save_mean, float* save_var,
+                          float eps, float decay, int is_training, int update_moving, int relu, void* stream);
+/* dx, dgamma, dbeta (and dresidual = the gradient entering before the activation, nullable) */
+int y2_batch_norm_backward(const float* dy, const float* y, const float* x, float* dx, float* dresidual, size_t rows,
+                           int channels, const float* gamma, const float* save_mean, const float* save_var, float eps,
+                           int is_training, int relu, float* dgamma, float* dbeta, void* stream);
+/* resnet_utils.subsample = max_pool2d([1,1], stride=factor) (resnet_utils.py:60-75): forward x [N,H,W,C] ->
+ * y [N,ceil(H/f),ceil(W/f),C]; forward = 0: x is the gradient at the coarse grid, y the gradient at [N,H,W,C] */
+int y2_subsample(const float* x, float* y, int N, int H, int W, int C, int factor, int forward, void* stream);
+/* slim.max_pool2d(net, [3,3], stride=2) with padding 'SAME' (resnet_v1.py:198) and its gradient */
+int y2_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int y2_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream);
+/* root block: conv2d_same(net, 64, 7, stride=2) on the image [N,H,W,3], filter HWIO [7][7][3][Cout] (resnet_v1.py:197) */
+int y2_conv7x7s2(const float* x, const float* w, float* y, int N, int H, int W, int Cout, void* stream);
+int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* stream);
+/* slim.fully_connected tail (pascal_train_resnet.py:41-46): y <- act(y + bias) in place; backward dz = dy [y > 0],
+ * dbias = column sums; tf.nn.dropout(x, keep_prob) with a mask that is a function of (seed, index) */
+int y2_bias_relu(float* y, const float* bias, size_t rows, int channels, int relu, void* stream);
+int y2_bias_relu_backward(const float* dy, const float* y, float* dz, float* dbias, size_t rows, int channels, int relu,
+                          void* stream);
+int y2_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t seed, void* stream);
+
 /* ---- optimizers on flat buffers (pascal_train_darknet.py:51, imagenet_train_darknet.py:58) */
 int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n, int step, float lr,
                  float beta1, float beta2, float eps, float grad_mult, void* stream);

@@ -68,6 +68,16 @@ SIGNATURES = {
     "y2_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp]),
     "y2_yolov2_loss_workspace_bytes": (_sz, [_i]),
     "y2_yolov2_loss": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "y2_batch_norm_forward": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _i, _vp]),
+    "y2_batch_norm_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
+    "y2_subsample": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "y2_maxpool3x3s2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "y2_maxpool3x3s2_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "y2_conv7x7s2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "y2_conv7x7s2_backward_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "y2_bias_relu": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
+    "y2_bias_relu_backward": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
+    "y2_dropout": (_i, [_vp, _vp, _sz, _f, _u64, _vp]),
     "y2_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
     "y2_grad_check": (_i, [_vp, _vp, _vp]),

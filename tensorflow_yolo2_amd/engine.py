@@ -643,3 +643,127 @@ def conv2d_backward(x, w, dy, dtype="f32"):
     check(lib.y2_conv2d_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), n, h, wd, ci, co, k, dt,
                                  _ptr(ws), _stream()))
     return dx, dw
+
+
+# ---- operators of the ResNet-50 backbone swap (csrc/resnet_ops.hip; reference: slim_dir/nets/resnet_v1.py,
+# resnet_utils.py, pascal/pascal_train_resnet.py:37-50) on fp32 NHWC device tensors -----------------------------
+def _chk(*ts):
+    for t in ts:
+        assert t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
+
+
+def batch_norm_forward(x, gamma, beta, moving_mean, moving_var, residual=None, is_training=True, update_moving=False,
+                       relu=True, eps=1e-5, decay=0.997):
+    """slim.batch_norm (+ residual add, + ReLU) on [..., C] -> (y, save_mean, save_var)"""
+    lib = _lib.load()
+    _chk(x, gamma, beta, moving_mean, moving_var, residual)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    y = torch.empty_like(x)
+    sm = torch.empty(c, dtype=torch.float32, device=x.device)
+    sv = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib.y2_batch_norm_forward(_ptr(x), _ptr(residual), _ptr(y), rows, c, _ptr(gamma), _ptr(beta), _ptr(moving_mean),
+                                    _ptr(moving_var), _ptr(sm), _ptr(sv), float(eps), float(decay), int(is_training),
+                                    int(update_moving), int(relu), _stream()))
+    return y, sm, sv
+
+
+def batch_norm_backward(dy, y, x, gamma, save_mean, save_var, is_training=True, relu=True, want_residual=False, eps=1e-5):
+    """-> (dx, dresidual or None, dgamma, dbeta)"""
+    lib = _lib.load()
+    _chk(dy, y, x, gamma, save_mean, save_var)
+    c = x.shape[-1]
+    rows = x.numel() // c
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_residual else None
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    check(lib.y2_batch_norm_backward(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), _ptr(dres), rows, c, _ptr(gamma),
+                                     _ptr(save_mean), _ptr(save_var), float(eps), int(is_training), int(relu), _ptr(dg),
+                                     _ptr(db), _stream()))
+    return dx, dres, dg, db
+
+
+def subsample(x, factor, out_hw=None):
+    """resnet_utils.subsample; with out_hw=(H, W): the gradient (x at the coarse grid -> fine grid [N,H,W,C])"""
+    lib = _lib.load()
+    _chk(x)
+    if out_hw is None:
+        n, h, w, c = x.shape
+        if factor == 1:
+            return x
+        y = torch.empty((n, (h + factor - 1) // factor, (w + factor - 1) // factor, c), dtype=torch.float32, device=x.device)
+        check(lib.y2_subsample(_ptr(x), _ptr(y), n, h, w, c, int(factor), 1, _stream()))
+        return y
+    if factor == 1:
+        return x
+    n, _, _, c = x.shape
+    h, w = out_hw
+    y = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    check(lib.y2_subsample(_ptr(x), _ptr(y), n, h, w, c, int(factor), 0, _stream()))
+    return y
+
+
+def max_pool_3x3_s2(x):
+    lib = _lib.load()
+    _chk(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=torch.float32, device=x.device)
+    check(lib.y2_maxpool3x3s2(_ptr(x), _ptr(y), n, h, w, c, _stream()))
+    return y
+
+
+def max_pool_3x3_s2_backward(x, dy):
+    lib = _lib.load()
+    _chk(x, dy)
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    check(lib.y2_maxpool3x3s2_backward(_ptr(x), _ptr(dy), _ptr(dx), n, h, w, c, _stream()))
+    return dx
+
+
+def conv7x7_s2(x, w):
+    lib = _lib.load()
+    _chk(x, w)
+    n, h, wd, _ = x.shape
+    co = w.shape[3]
+    y = torch.empty((n, (h + 1) // 2, (wd + 1) // 2, co), dtype=torch.float32, device=x.device)
+    check(lib.y2_conv7x7s2(_ptr(x), _ptr(w), _ptr(y), n, h, wd, co, _stream()))
+    return y
+
+
+def conv7x7_s2_backward_filter(x, dy):
+    lib = _lib.load()
+    _chk(x, dy)
+    n, h, wd, _ = x.shape
+    co = dy.shape[3]
+    dw = torch.empty((7, 7, 3, co), dtype=torch.float32, device=x.device)
+    check(lib.y2_conv7x7s2_backward_filter(_ptr(x), _ptr(dy), _ptr(dw), n, h, wd, co, _stream()))
+    return dw
+
+
+def bias_relu_(y, bias, relu=True):
+    lib = _lib.load()
+    _chk(y, bias)
+    c = y.shape[-1]
+    check(lib.y2_bias_relu(_ptr(y), _ptr(bias), y.numel() // c, c, int(relu), _stream()))
+    return y
+
+
+def bias_relu_backward(dy, y, relu=True):
+    lib = _lib.load()
+    _chk(dy, y)
+    c = y.shape[-1]
+    dz = torch.empty_like(dy)
+    db = torch.empty(c, dtype=torch.float32, device=dy.device)
+    check(lib.y2_bias_relu_backward(_ptr(dy), _ptr(y), _ptr(dz), _ptr(db), y.numel() // c, c, int(relu), _stream()))
+    return dz, db
+
+
+def dropout(x, keep_prob, seed):
+    """tf.nn.dropout: kept elements scaled by 1/keep_prob; the same (seed) regenerates the mask for the gradient"""
+    lib = _lib.load()
+    _chk(x)
+    y = torch.empty_like(x)
+    check(lib.y2_dropout(_ptr(x), _ptr(y), x.numel(), float(keep_prob), int(seed), _stream()))
+    return y

@@ -1,0 +1,268 @@
+"""Counterpart of src/yolo2_nets/tf_resnet.py + the graph of src/pascal/pascal_train_resnet.py:37-50: slim's
+resnet_v1_50 (global_pool=False) in front of the YOLO grid head
+    flatten -> fully_connected 4096 (ReLU) -> dropout 0.5 -> fully_connected S*S*(5B+C) (ReLU) -> [-1,S,S,5B+C]
+trained with get_loss and AdamOptimizer(0.0005) -- BASELINE.json configs[4]'s "ResNet-50 slim backbone swap".
+
+The backbone is a DAG (shortcuts), so it is not an engine.Network stack: it is composed here from graph-level
+operators, every one a HIP kernel behind the C ABI -- the bottleneck units' 1x1 / 3x3 convolutions are the MFMA
+implicit-GEMM kernels (y2_conv2d / y2_conv2d_backward; a fully connected layer is a 1x1 convolution on a 1x1 map),
+csrc/resnet_ops.hip has slim.batch_norm (+ residual add + ReLU), subsample, the 3x3/2 max pool, the 7x7/2 root
+convolution, bias + ReLU and dropout.  Variable names are slim's (checkpoints of the reference's resnet graph map
+one to one).  The reference trains this model at batch 4 and 224x224 (the FC head fixes the input size): the
+operator-level composition is written for parity, the Darknet path is the tuned one.
+"""
+import numpy as np
+import torch
+
+from .. import engine as E
+
+BN_EPS, BN_DECAY = 1e-5, 0.997          # resnet_utils.resnet_arg_scope (slim_dir/nets/resnet_utils.py:230-233)
+
+# tf_resnet.py:19-28: (depth, depth_bottleneck, stride) per unit
+BLOCKS_50 = [("block1", [(256, 64, 1)] * 2 + [(256, 64, 2)]),
+             ("block2", [(512, 128, 1)] * 3 + [(512, 128, 2)]),
+             ("block3", [(1024, 256, 1)] * 5 + [(1024, 256, 2)]),
+             ("block4", [(2048, 512, 1)] * 3)]
+
+
+def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, feat_hw=7):
+    """(name, shape, trainable) in slim's creation order"""
+    def bn(scope, c):
+        s = scope.rstrip("/") + "/BatchNorm/"
+        return [(s + "gamma", (c,), True), (s + "beta", (c,), True), (s + "moving_mean", (c,), False),
+                (s + "moving_variance", (c,), False)]
+    out = [("conv1/weights", (7, 7, 3, root_depth), True)] + bn("conv1", root_depth)
+    cin = root_depth
+    for bname, units in blocks:
+        for i, (depth, db, _stride) in enumerate(units):
+            p = "%s/unit_%d/bottleneck_v1/" % (bname, i + 1)
+            if depth != cin:
+                out += [(p + "shortcut/weights", (1, 1, cin, depth), True)] + bn(p + "shortcut", depth)
+            out += [(p + "conv1/weights", (1, 1, cin, db), True)] + bn(p + "conv1", db)
+            out += [(p + "conv2/weights", (3, 3, db, db), True)] + bn(p + "conv2", db)
+            out += [(p + "conv3/weights", (1, 1, db, depth), True)] + bn(p + "conv3", depth)
+            cin = depth
+    flat = feat_hw * feat_hw * cin
+    out += [("yolo_fc1/weights", (flat, fc_hidden), True), ("yolo_fc1/biases", (fc_hidden,), True),
+            ("yolo_fc2/weights", (fc_hidden, fc_out), True), ("yolo_fc2/biases", (fc_out,), True)]
+    return out
+
+
+class ResNet50Yolo:
+    """resnet_v1_50 + the YOLO fully connected head, forward / backward / Adam(0.0005)"""
+
+    def __init__(self, batch, image_size=224, B=2, num_class=20, dtype="f16", blocks=None, root_depth=64,
+                 fc_hidden=4096, seed=0, device="cuda:0", learning_rate=0.0005, keep_prob=0.5):
+        assert image_size % 32 == 0
+        self.batch, self.size, self.S, self.B, self.num_class = batch, image_size, image_size // 32, B, num_class
+        self.dtype, self.device, self.keep_prob = dtype, torch.device(device), keep_prob
+        self.blocks = blocks or BLOCKS_50
+        self.out_c = 5 * B + num_class
+        self.vars = variable_list(self.blocks, root_depth, fc_hidden, self.S * self.S * self.out_c, self.S)
+        n_train = sum(int(np.prod(s)) for (_n, s, t) in self.vars if t)
+        n_state = sum(int(np.prod(s)) for (_n, s, t) in self.vars if not t)
+        self.params = torch.zeros(n_train, dtype=torch.float32, device=self.device)      # ONE flat buffer: one Adam
+        self.grads = torch.zeros(n_train, dtype=torch.float32, device=self.device)
+        self.state = torch.zeros(n_state, dtype=torch.float32, device=self.device)
+        self.p, self.g = {}, {}
+        ot = os_ = 0
+        for (name, shape, trainable) in self.vars:
+            n = int(np.prod(shape))
+            if trainable:
+                self.p[name] = self.params[ot:ot + n].view(shape)
+                self.g[name] = self.grads[ot:ot + n].view(shape)
+                ot += n
+            else:
+                self.p[name] = self.state[os_:os_ + n].view(shape)
+                os_ += n
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.t = 0
+        self.lr = learning_rate
+        self.drop_seed = seed * 7919 + 1
+        self.init_params(seed)
+        self.tape = None
+
+    # ---- variables ---------------------------------------------------------
+    def init_params(self, seed=0):
+        """slim defaults: variance_scaling_initializer (truncated normal, stddev sqrt(1.3 * 2 / fan_in)) for the
+        convolutions, xavier_initializer for fully connected weights, zeros for biases, BN 1 / 0 / 0 / 1"""
+        rng = np.random.default_rng(seed)
+        for (name, shape, _t) in self.vars:
+            if name.endswith("weights") and len(shape) == 4:
+                std = np.sqrt(1.3 * 2.0 / (shape[0] * shape[1] * shape[2]))
+                w = rng.standard_normal(shape)
+                bad = np.abs(w) > 2
+                while bad.any():
+                    w[bad] = rng.standard_normal(int(bad.sum()))
+                    bad = np.abs(w) > 2
+                val = (w * std).astype(np.float32)
+            elif name.endswith("weights"):
+                lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+                val = rng.uniform(-lim, lim, shape).astype(np.float32)
+            elif name.endswith("gamma") or name.endswith("moving_variance"):
+                val = np.ones(shape, np.float32)
+            else:
+                val = np.zeros(shape, np.float32)
+            self.p[name].copy_(torch.as_tensor(val))
+
+    def load_params(self, params):
+        for name, val in params.items():
+            self.p[name].copy_(torch.as_tensor(np.asarray(val, np.float32)).to(self.device))
+
+    def export_params(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.p.items()}
+
+    def export_grads(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.g.items()}
+
+    # ---- building blocks ---------------------------------------------------
+    def _conv(self, x, name, stride=1):
+        """slim.conv2d without bias; stride 2: 1x1 -> subsample then convolve, 3x3 -> conv2d_same = convolve at stride 1
+        then subsample (resnet_utils.py:77-122)"""
+        w = self.p[name]
+        k = w.shape[0]
+        if stride == 1:
+            return E.conv2d(x, w, None, self.dtype), ("conv", name, x, 1)
+        if k == 1:
+            xs = E.subsample(x, stride)
+            return E.conv2d(xs, w, None, self.dtype), ("conv1s", name, x, xs, stride)
+        full = E.conv2d(x, w, None, self.dtype)
+        return E.subsample(full, stride), ("conv3s", name, x, tuple(full.shape[1:3]), stride)
+
+    def _conv_backward(self, rec, dy):
+        kind, name = rec[0], rec[1]
+        w = self.p[name]
+        if kind == "conv":
+            dx, dw = E.conv2d_backward(rec[2], w, dy.contiguous(), self.dtype)
+        elif kind == "conv1s":
+            x, xs, stride = rec[2], rec[3], rec[4]
+            dxs, dw = E.conv2d_backward(xs, w, dy.contiguous(), self.dtype)
+            dx = E.subsample(dxs, stride, out_hw=tuple(x.shape[1:3]))
+        else:
+            x, hw, stride = rec[2], rec[3], rec[4]
+            dfull = E.subsample(dy.contiguous(), stride, out_hw=hw)
+            dx, dw = E.conv2d_backward(x, w, dfull, self.dtype)
+        self.g[name].copy_(dw.view(self.g[name].shape))      # every variable has exactly one consumer
+        return dx
+
+    def _bn(self, x, scope, relu, residual=None):
+        s = scope.rstrip("/") + "/BatchNorm/"
+        y, sm, sv = E.batch_norm_forward(x, self.p[s + "gamma"], self.p[s + "beta"], self.p[s + "moving_mean"],
+                                         self.p[s + "moving_variance"], residual, self._training, self._update_moving,
+                                         relu, BN_EPS, BN_DECAY)
+        return y, ("bn", s, x, y, sm, sv, relu, residual is not None)
+
+    def _bn_backward(self, rec, dy):
+        _k, s, x, y, sm, sv, relu, has_res = rec
+        dx, dres, dg, db = E.batch_norm_backward(dy.contiguous(), y, x, self.p[s + "gamma"], sm, sv, self._training, relu,
+                                                 has_res, BN_EPS)
+        self.g[s + "gamma"].copy_(dg)
+        self.g[s + "beta"].copy_(db)
+        return dx, dres
+
+    # ---- graph ---------------------------------------------------------------
+    def forward(self, images, is_training=True, update_moving=False, dropout=True):
+        """images [N,size,size,3] fp32 -> grid_net [N,S,S,5B+C] (pascal_train_resnet.py:37-50)"""
+        assert tuple(images.shape) == (self.batch, self.size, self.size, 3) and images.is_cuda
+        self._training, self._update_moving = bool(is_training), bool(update_moving)
+        tape = []
+        x = E.conv7x7_s2(images.contiguous(), self.p["conv1/weights"])                     # resnet_v1.py:197
+        tape.append(("conv7", images))
+        x, r = self._bn(x, "conv1", True); tape.append(r)
+        pooled = E.max_pool_3x3_s2(x); tape.append(("pool", x)); x = pooled                # resnet_v1.py:198
+        for bname, units in self.blocks:
+            for i, (depth, db, stride) in enumerate(units):                                  # resnet_v1.py:99-112
+                sc = "%s/unit_%d/bottleneck_v1/" % (bname, i + 1)
+                unit = {"in": x, "stride": stride}
+                if depth == x.shape[3]:
+                    shortcut = E.subsample(x, stride)
+                    unit["short"] = None
+                else:
+                    sconv, r1 = self._conv(x, sc + "shortcut/weights", stride)
+                    shortcut, r2 = self._bn(sconv, sc + "shortcut", False)
+                    unit["short"] = (r1, r2)
+                a, c1 = self._conv(x, sc + "conv1/weights"); a, b1 = self._bn(a, sc + "conv1", True)
+                a, c2 = self._conv(a, sc + "conv2/weights", stride); a, b2 = self._bn(a, sc + "conv2", True)
+                a, c3 = self._conv(a, sc + "conv3/weights")
+                out, b3 = self._bn(a, sc + "conv3", True, residual=shortcut.contiguous())   # relu(shortcut + BN(conv3))
+                unit["res"] = (c1, b1, c2, b2, c3, b3)
+                tape.append(("unit", unit))
+                x = out
+        feat = x                                                                              # [N,S,S,depth]
+        n = self.batch
+        flat = feat.reshape(n, 1, 1, -1).contiguous()                                         # slim.flatten (NHWC order)
+        w1 = self.p["yolo_fc1/weights"]
+        fc1 = E.conv2d(flat, w1.view(1, 1, *w1.shape), None, self.dtype).view(n, -1)          # FC = 1x1 conv on a 1x1 map
+        E.bias_relu_(fc1, self.p["yolo_fc1/biases"], True)
+        use_drop = bool(dropout and is_training)
+        self.drop_seed += 1
+        h = E.dropout(fc1, self.keep_prob, self.drop_seed) if use_drop else fc1
+        w2 = self.p["yolo_fc2/weights"]
+        fc2 = E.conv2d(h.view(n, 1, 1, -1), w2.view(1, 1, *w2.shape), None, self.dtype).view(n, -1)
+        E.bias_relu_(fc2, self.p["yolo_fc2/biases"], True)
+        tape.append(("head", feat, flat, fc1, h, fc2, use_drop, self.drop_seed))
+        self.tape = tape
+        return fc2.view(n, self.S, self.S, self.out_c)
+
+    def backward(self, dgrid):
+        """gradients of every trainable variable into self.grads"""
+        assert self.tape is not None
+        n = self.batch
+        _k, feat, flat, fc1, h, fc2, use_drop, seed = self.tape[-1]
+        dz2, db2 = E.bias_relu_backward(dgrid.reshape(n, -1).contiguous(), fc2, True)
+        self.g["yolo_fc2/biases"].copy_(db2)
+        w2 = self.p["yolo_fc2/weights"]
+        dh, dw2 = E.conv2d_backward(h.view(n, 1, 1, -1), w2.view(1, 1, *w2.shape), dz2.view(n, 1, 1, -1), self.dtype)
+        self.g["yolo_fc2/weights"].copy_(dw2.view(self.g["yolo_fc2/weights"].shape))
+        dh = dh.view(n, -1)
+        dfc1 = E.dropout(dh.contiguous(), self.keep_prob, seed) if use_drop else dh        # same mask, same 1/keep scale
+        dz1, db1 = E.bias_relu_backward(dfc1.contiguous(), fc1, True)
+        self.g["yolo_fc1/biases"].copy_(db1)
+        w1 = self.p["yolo_fc1/weights"]
+        dflat, dw1 = E.conv2d_backward(flat, w1.view(1, 1, *w1.shape), dz1.view(n, 1, 1, -1), self.dtype)
+        self.g["yolo_fc1/weights"].copy_(dw1.view(self.g["yolo_fc1/weights"].shape))
+        dx = dflat.reshape(feat.shape).contiguous()
+        for rec in reversed(self.tape[:-1]):
+            if rec[0] == "unit":
+                u = rec[1]
+                c1, b1, c2, b2, c3, b3 = u["res"]
+                da, dshort = self._bn_backward(b3, dx)
+                da = self._conv_backward(c3, da)
+                da, _ = self._bn_backward(b2, da)
+                da = self._conv_backward(c2, da)
+                da, _ = self._bn_backward(b1, da)
+                dxin = self._conv_backward(c1, da)
+                if u["short"] is None:
+                    dsx = E.subsample(dshort, u["stride"], out_hw=tuple(u["in"].shape[1:3]))
+                else:
+                    r1, r2 = u["short"]
+                    ds, _ = self._bn_backward(r2, dshort)
+                    dsx = self._conv_backward(r1, ds)
+                dx = E.accumulate(dxin.contiguous(), dsx.contiguous())
+            elif rec[0] == "pool":
+                dx = E.max_pool_3x3_s2_backward(rec[1], dx.contiguous())
+            elif rec[0] == "bn":
+                dx, _ = self._bn_backward(rec, dx)
+            elif rec[0] == "conv7":
+                dw = E.conv7x7_s2_backward_filter(rec[1].contiguous(), dx.contiguous())
+                self.g["conv1/weights"].copy_(dw)
+
+    def step(self, images, labels):
+        """one iteration of pascal_train_resnet.py:49-62: get_loss + AdamOptimizer(0.0005).minimize"""
+        grid = self.forward(images, True, update_moving=True)
+        loss, ious, mask, dnet = E.yolo_loss(grid, labels, self.num_class, self.batch, self.size, self.S, self.B)
+        self.backward(dnet)
+        self.t += 1
+        lib = E._lib.load()
+        E.check(lib.y2_adam_step(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads),
+                                 self.params.numel(), self.t, self.lr, 0.9, 0.999, 1e-8, 1.0, E._stream()))
+        return loss, ious, mask
+
+
+def resnet_v1_50(inputs, num_classes=None, is_training=True, global_pool=False, output_stride=None, reuse=None,
+                 scope='resnet_v1_50', **kw):
+    """tf_resnet.py:12-32 signature: returns the model object whose .forward(inputs) evaluates the graph"""
+    if num_classes is not None or global_pool or output_stride is not None:
+        raise NotImplementedError("the reference's swap uses the dense features only (global_pool=False, no logits)")
+    return ResNet50Yolo(inputs.shape[0], inputs.shape[1], **kw)

@@ -1,0 +1,214 @@
+"""GPU tests (-m gpu) of the ResNet-50 backbone swap (BASELINE.json configs[4]):
+the graph-level operators of csrc/resnet_ops.hip one by one, then slim's resnet_v1_50 + the YOLO fully connected
+head composed from them (yolo2_nets/tf_resnet.py) against the PyTorch-CPU restatement of the same slim code
+(oracle/resnet_ref.py: src/slim_dir/nets/resnet_v1.py:68-112,185-199, resnet_utils.py:60-122,230-257,
+src/pascal/pascal_train_resnet.py:37-50)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import resnet_ref as RR, loss_ref as L
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_subsample_and_maxpool3_match_slim_semantics():
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(0)
+    # resnet_v1_test.py:58-70 testSubsampleThreeByThree / FourByFour: x = mesh(3) / mesh(4), factor 2
+    mesh = lambda n: (np.arange(n)[:, None] + np.arange(n)[None, :]).astype(np.float32).reshape(1, n, n, 1)
+    np.testing.assert_array_equal(E.subsample(dev(mesh(3)), 2).cpu().numpy()[0, :, :, 0], [[0, 2], [2, 4]])
+    np.testing.assert_array_equal(E.subsample(dev(mesh(4)), 2).cpu().numpy()[0, :, :, 0], [[0, 2], [2, 4]])
+    for shape in ((2, 9, 7, 5), (1, 16, 16, 8), (3, 5, 12, 3)):
+        x = np.round(rng.standard_normal(shape), 1).astype(np.float32)           # ties inside windows
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        ref = RR.max_pool_3x3_s2_same(xt.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        y = E.max_pool_3x3_s2(dev(x))
+        np.testing.assert_array_equal(y.cpu().numpy(), ref.detach().numpy().astype(np.float32))
+        dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        # distinct values: the gradient routing is unambiguous
+        x2 = rng.permutation(x.size).reshape(shape).astype(np.float32)
+        x2t = torch.tensor(x2, dtype=torch.float64, requires_grad=True)
+        RR.max_pool_3x3_s2_same(x2t.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).backward(torch.tensor(dy, dtype=torch.float64))
+        dx = E.max_pool_3x3_s2_backward(dev(x2), dev(dy))
+        np.testing.assert_allclose(dx.cpu().numpy(), x2t.grad.numpy(), rtol=1e-6, atol=1e-6)
+        s = E.subsample(dev(x), 2)
+        np.testing.assert_array_equal(s.cpu().numpy(), x[:, ::2, ::2, :])
+        g = rng.standard_normal(tuple(s.shape)).astype(np.float32)
+        back = E.subsample(dev(g), 2, out_hw=shape[1:3]).cpu().numpy()
+        want = np.zeros(shape, np.float32); want[:, ::2, ::2, :] = g
+        np.testing.assert_array_equal(back, want)
+
+
+@pytest.mark.parametrize("relu,res,training", [(True, False, True), (False, False, True), (True, True, True), (True, False, False)])
+def test_batch_norm_forward_backward(relu, res, training):
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(3)
+    shape = (3, 6, 5, 40)
+    x = rng.standard_normal(shape).astype(np.float32) * 2 + 0.5
+    r = rng.standard_normal(shape).astype(np.float32) if res else None
+    gamma = rng.uniform(0.5, 1.5, 40).astype(np.float32); beta = rng.uniform(-0.5, 0.5, 40).astype(np.float32)
+    mm = rng.uniform(-0.3, 0.3, 40).astype(np.float32); mv = rng.uniform(0.5, 2.0, 40).astype(np.float32)
+    dy = rng.standard_normal(shape).astype(np.float32)
+    p = {"s/BatchNorm/gamma": torch.tensor(gamma, dtype=torch.float64, requires_grad=True),
+         "s/BatchNorm/beta": torch.tensor(beta, dtype=torch.float64, requires_grad=True),
+         "s/BatchNorm/moving_mean": torch.tensor(mm, dtype=torch.float64),
+         "s/BatchNorm/moving_variance": torch.tensor(mv, dtype=torch.float64)}
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    rt = torch.tensor(r, dtype=torch.float64, requires_grad=True) if res else None
+    mov = {}
+    yt = RR.batch_norm(xt.permute(0, 3, 1, 2), p, "s", training, mov).permute(0, 2, 3, 1)
+    if res:
+        yt = yt + rt
+    if relu:
+        yt = F.relu(yt)
+    yt.backward(torch.tensor(dy, dtype=torch.float64))
+    dmm, dmv = dev(mm), dev(mv)
+    y, sm, sv = E.batch_norm_forward(dev(x), dev(gamma), dev(beta), dmm, dmv, dev(r) if res else None, training, training, relu)
+    assert rel(y.cpu().numpy(), yt.detach().numpy()) < 1e-5
+    if training:
+        assert rel(dmm.cpu().numpy(), mov["s/BatchNorm/moving_mean"].numpy()) < 1e-5
+        assert rel(dmv.cpu().numpy(), mov["s/BatchNorm/moving_variance"].numpy()) < 1e-5
+    dx, dres, dg, db = E.batch_norm_backward(dev(dy), y, dev(x), dev(gamma), sm, sv, training, relu, res)
+    assert rel(dx.cpu().numpy(), xt.grad.numpy()) < 2e-5
+    assert rel(dg.cpu().numpy(), p["s/BatchNorm/gamma"].grad.numpy()) < 2e-5
+    assert rel(db.cpu().numpy(), p["s/BatchNorm/beta"].grad.numpy()) < 2e-5
+    if res:
+        assert rel(dres.cpu().numpy(), rt.grad.numpy()) < 1e-6
+
+
+def test_root_convolution_7x7_stride2():
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(4)
+    for (n, h, w) in ((2, 32, 32), (1, 21, 30)):
+        x = rng.uniform(-1, 1, (n, h, w, 3)).astype(np.float32)
+        wt = (rng.standard_normal((7, 7, 3, 16)) * 0.1).astype(np.float32)
+        xt = torch.tensor(x, dtype=torch.float64)
+        wtt = torch.tensor(wt, dtype=torch.float64, requires_grad=True)
+        ref = RR.conv2d_same(xt.permute(0, 3, 1, 2), wtt, 2).permute(0, 2, 3, 1)
+        y = E.conv7x7_s2(dev(x), dev(wt))
+        assert tuple(y.shape) == tuple(ref.shape) and rel(y.cpu().numpy(), ref.detach().numpy()) < 1e-5
+        dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        ref.backward(torch.tensor(dy, dtype=torch.float64))
+        dw = E.conv7x7_s2_backward_filter(dev(x), dev(dy))
+        assert rel(dw.cpu().numpy(), wtt.grad.numpy()) < 1e-5
+
+
+def test_dropout_mask_is_a_function_of_the_seed():
+    from tensorflow_yolo2_amd import engine as E
+    x = torch.ones(1 << 16, device="cuda")
+    a, b, c = E.dropout(x, 0.5, 7), E.dropout(x, 0.5, 7), E.dropout(x, 0.5, 8)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    vals = set(np.unique(a.cpu().numpy()).tolist())
+    assert vals == {0.0, 2.0}                                       # kept elements scaled by 1 / keep_prob
+    assert abs(float((a > 0).float().mean()) - 0.5) < 0.01
+    assert abs(float((E.dropout(x, 0.8, 3) > 0).float().mean()) - 0.8) < 0.01
+
+
+def _build(dtype, div=8, size=64, n=2, seed=1):
+    from tensorflow_yolo2_amd.yolo2_nets import tf_resnet
+    blocks = RR.scaled_blocks(div)
+    S = size // 32
+    m = tf_resnet.ResNet50Yolo(n, size, dtype=dtype, blocks=blocks, root_depth=64 // div, fc_hidden=4096 // div, seed=seed)
+    params = RR.init_params(blocks, seed=seed, root_depth=64 // div, fc_hidden=4096 // div, fc_out=S * S * 30, feat_hw=S)
+    rng = np.random.default_rng(seed + 1)
+    for k in params:                                                # non-trivial BN parameters and biases
+        if k.endswith("gamma"):
+            params[k] = rng.uniform(0.7, 1.3, params[k].shape).astype(np.float32)
+        elif k.endswith("beta") or k.endswith("biases"):
+            params[k] = rng.uniform(-0.2, 0.2, params[k].shape).astype(np.float32)
+    m.load_params(params)
+    return m, params, blocks
+
+
+def test_resnet50_yolo_forward_backward_vs_oracle():
+    """all 16 bottleneck units (3 + 4 + 6 + 3) at 1/8 width, 64x64 input, f32 convolutions: grid, loss and
+    gradients against float64 autograd of the slim restatement"""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    n, size, S = 2, 64, 2
+    m, params, blocks = _build("f32")
+    x = synthetic.images(n, size, 5)
+    labels = synthetic.det_labels(n, size, S, 6)
+    tp = RR.to_torch(params)
+    feat = RR.resnet_v1_50(torch.tensor(x, dtype=torch.float64), tp, blocks, True)
+    ref = RR.yolo_fc_head(feat, tp).reshape(n, S, S, 30)
+    grid = m.forward(dev(x), True, dropout=False)
+    e_grid = rel(grid.cpu().numpy(), ref.detach().numpy())
+    assert e_grid < 1e-3, e_grid
+    from oracle import torch_ref as T
+    rloss, _, rmask, _ = T.get_loss(ref, torch.tensor(labels, dtype=torch.float64), 20, n, size, S, 2, L.yolo_grid_offset(S, 2))
+    rloss.backward()
+    loss, ious, mask, dnet = E.yolo_loss(grid, dev(labels), 20, n, size, S, 2)
+    assert abs(loss[4].item() - rloss.item()) < 1e-3 * abs(rloss.item())
+    m.backward(dnet)
+    g = m.export_grads()
+    worst = {}
+    for name in ("yolo_fc2/weights", "yolo_fc2/biases", "yolo_fc1/weights", "block4/unit_3/bottleneck_v1/conv3/weights",
+                 "block4/unit_1/bottleneck_v1/shortcut/weights", "block3/unit_6/bottleneck_v1/conv2/weights",
+                 "block3/unit_6/bottleneck_v1/conv2/BatchNorm/gamma", "block2/unit_1/bottleneck_v1/conv1/weights",
+                 "block1/unit_3/bottleneck_v1/conv2/weights", "block1/unit_1/bottleneck_v1/shortcut/BatchNorm/beta",
+                 "conv1/BatchNorm/gamma", "conv1/weights"):
+        r = tp[name].grad.numpy()
+        worst[name] = float(np.linalg.norm(g[name] - r) / max(np.linalg.norm(r), 1e-30))
+    print("resnet50 f32 vs float64 oracle: grid %.2e, gradient l2 errors %s" % (e_grid, {k: "%.1e" % v for k, v in worst.items()}))
+    assert max(worst.values()) < 2e-2, worst
+    assert worst["yolo_fc2/weights"] < 1e-3
+
+
+def test_resnet50_yolo_dropout_and_training_steps():
+    """dropout: the backward pass regenerates the forward mask (gradients match the oracle given that mask);
+    AdamOptimizer(0.0005) steps lower the loss in f32 and in the f16 mode; moving statistics move with decay 0.997"""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    n, size, S = 2, 64, 2
+    m, params, blocks = _build("f32", seed=2)
+    x = synthetic.images(n, size, 7)
+    labels = synthetic.det_labels(n, size, S, 8)
+    grid = m.forward(dev(x), True, dropout=True)
+    _k, feat, flat, fc1, h, fc2, use_drop, seed = m.tape[-1]
+    mask = (h != 0) | (fc1 == 0)
+    keep = (E.dropout(torch.ones_like(fc1), 0.5, seed) > 0)
+    assert use_drop and torch.equal(h, fc1 * keep * 2.0)
+    tp = RR.to_torch(params)
+    f = RR.resnet_v1_50(torch.tensor(x, dtype=torch.float64), tp, blocks, True)
+    ref = RR.yolo_fc_head(f, tp, torch.tensor(keep.cpu().numpy(), dtype=torch.float64), 0.5).reshape(n, S, S, 30)
+    assert rel(grid.cpu().numpy(), ref.detach().numpy()) < 1e-3
+    from oracle import torch_ref as T
+    rloss, _, _, _ = T.get_loss(ref, torch.tensor(labels, dtype=torch.float64), 20, n, size, S, 2, L.yolo_grid_offset(S, 2))
+    rloss.backward()
+    loss, _, _, dnet = E.yolo_loss(grid, dev(labels), 20, n, size, S, 2)
+    m.backward(dnet)
+    g = m.export_grads()
+    r = tp["yolo_fc1/weights"].grad.numpy()
+    assert np.linalg.norm(g["yolo_fc1/weights"] - r) / np.linalg.norm(r) < 2e-3
+    for dtype in ("f32", "f16"):
+        m2, p2, _ = _build(dtype, seed=3)
+        mv0 = m2.p["conv1/BatchNorm/moving_variance"].clone()
+        losses = [float(m2.step(dev(x), dev(labels))[0][4]) for _ in range(6)]
+        assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0], (dtype, losses)
+        assert torch.isfinite(m2.params).all()
+        assert not torch.equal(m2.p["conv1/BatchNorm/moving_variance"], mv0)
+
+
+def test_resnet50_full_width_224_runs():
+    """BASELINE.json configs[4] geometry: full-width resnet_v1_50 at 224x224, batch 4 (pascal_train_resnet.py:26),
+    FC 100352 -> 4096 -> 1470: one train step in the f16 mode, finite, 7x7x30 grid"""
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.yolo2_nets import tf_resnet
+    n = 4
+    m = tf_resnet.ResNet50Yolo(n, 224, dtype="f16", seed=0)
+    assert sum(int(np.prod(s)) for (_n, s, t) in m.vars if t) == m.params.numel()
+    x = dev(synthetic.images(n, 224, 1))
+    lab = dev(synthetic.det_labels(n, 224, 7, 2))
+    l0 = float(m.step(x, lab)[0][4])
+    l1 = float(m.step(x, lab)[0][4])
+    assert np.isfinite([l0, l1]).all() and tuple(m.forward(x, False).shape) == (n, 7, 7, 30)
