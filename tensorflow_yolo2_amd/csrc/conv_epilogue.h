@@ -124,16 +124,23 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
         s1[e] = 0.f;
         s2[e] = 0.f;
     }
+    // 16-bit types, whole tiles: the batch-norm sums come from the MATRIX pipe (idle in the epilogue) instead of
+    // ~4 VALU operations per stored element.  The wave's patch [pixel][cout] is read back transposed
+    // (ds_read_b64_tr_b16: lane = cout, 8 pixels per fragment); S1 = ones x y and S2 = diag(y y^T) on 32x32x16 MFMAs:
+    // exact products of the stored values, fp32 accumulation; the block's (mean, M2) record is formed in double.
+    bool mfma_stats = false;
+    if constexpr (SZ == 2) mfma_stats = stats && !bw && (m0 + BP <= a.M);   // block-uniform
     if (!bw) {
-        auto sweep = [&](auto full_tag) {
+        auto sweep = [&](auto full_tag, auto stat_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
+            constexpr bool VSTAT = decltype(stat_tag)::value;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int prow = it * RPIe + prow0;
                 Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
                 const bool pv = FULL || (mw0 + prow) < a.M;
                 if (!(EABL & 1) && pv && cch < a.ldy) st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
-                if (stats) {
+                if (VSTAT && stats) {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         float d = Elem<T>::to_f32(c.v[e]) - piv[e];
@@ -144,8 +151,9 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
                 }
             }
         };
-        if (mw0 + TP * 32 <= a.M) sweep(std::true_type{});   // wave-uniform
-        else sweep(std::false_type{});
+        if (mfma_stats) sweep(std::true_type{}, std::false_type{});
+        else if (mw0 + TP * 32 <= a.M) sweep(std::true_type{}, std::true_type{});   // wave-uniform
+        else sweep(std::false_type{}, std::true_type{});
     } else {
         // ---- dgrad: store dA and reduce S1 = sum g, S2 = sum g * y_sel of the layer below on the fly
         const bool cv = cch < a.ldy;
@@ -183,6 +191,67 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
                     s2[e] = fmaf(g, yf, s2[e]);
                 }
             }
+        }
+    }
+    if constexpr (SZ == 2) {
+        // Block-uniform choice: every wave of the block must take the same reduction path (tail blocks: the VALU one)
+        const bool blk_mfma = stats && !bw && (m0 + BP <= a.M);
+        if (blk_mfma) {
+            typedef typename Elem<T>::frag frag_t;
+            const int r32 = lane & 31, hh = lane >> 5;
+            const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+            frag_t ones;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+            float S1w[TC], S2w[TC];
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                f32x16 q1, q2;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) q1[q] = q2[q] = 0.f;
+                const char* pb = ew + (8 * hh + qq) * EROW + (i * 32 + 16 * g1 + 4 * pp) * 2;
+#pragma unroll
+                for (int kg = 0; kg < TP * 2; ++kg) {
+                    const char* p0 = pb + kg * 16 * EROW;
+                    const frag_t f = tr_frag<T>(p0, p0 + 4 * EROW);
+                    mma32(q1, ones, f);
+                    mma32(q2, f, f);
+                }
+                float dg = 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dg += (acc_row(q, hh) == r32) ? q2[q] : 0.f;
+                S1w[i] = q1[0];
+                S2w[i] = dg + __shfl_xor(dg, 32, 64);
+            }
+            __syncthreads();     // every wave is done reading its patch: the scratch below aliases it
+            float* sw = (float*)ew;   // [2][TC*32]
+            if (hh == 0) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    sw[i * 32 + r32] = S1w[i];
+                    sw[TC * 32 + i * 32 + r32] = S2w[i];
+                }
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < Cfg::BC; c += NW * 64) {
+                const int wcs = c / (TC * 32), cl = c % (TC * 32);
+                double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < WP; ++k) {
+                    const float* q = (const float*)(smem + (k * WC + wcs) * Cfg::EPW);
+                    S1 += (double)q[cl];
+                    S2 += (double)q[TC * 32 + cl];
+                }
+                const int co = n0 + c;
+                if (co < a.ldy) {
+                    const double md = S1 / (double)BP;
+                    const double m2 = S2 - S1 * md;
+                    a.part_mean[(size_t)pt * a.ldy + co] = (float)md;
+                    a.part_m2[(size_t)pt * a.ldy + co] = (float)(m2 > 0.0 ? m2 : 0.0);
+                }
+            }
+            if (threadIdx.x == 0 && ct == 0) a.part_cnt[pt] = (float)BP;
+            return;
         }
     }
     if (stats || bw) {
