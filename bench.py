@@ -340,12 +340,12 @@ def main():
         # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (separate
         # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction), bytes per launch
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_hbm_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
             sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k or "wgrad9" in k or "wgrad_kernel" in k]
             nl = sum(v["launches"] for v in sel)
             if nl and not args.forward_only and bs == 64 and size == 416 and args.dtype == "f16":
                 roof["traffic"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in sel) / nl
-                roof["traffic_source"] = "profiles/r01_e_pmc_hbm_traffic.json (same command, earlier run)"
+                roof["traffic_source"] = "profiles/r02_pmc_hbm_traffic.json (same command, earlier run)"
         except (OSError, ValueError, KeyError):
             pass
         if roof.get("avg_launch_ms"):

@@ -585,16 +585,23 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
     }
 }
 
-__global__ __launch_bounds__(256) void conv1_lin_reduce_kernel(const float* part, int nblocks, float* acc) {
+// block partials -> kLinMid slice sums (fixed order; a 2-D grid so that 512 partial records of 15 KB do not queue
+// behind one another in 15 blocks); the finalize adds the kLinMid slices
+constexpr int kLinMid = 16;
+__global__ __launch_bounds__(256) void conv1_lin_reduce_kernel(const float* part, int nblocks, float* mid) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= kLinAcc) return;
+    const int per = (nblocks + kLinMid - 1) / kLinMid;
+    const int b0 = blockIdx.y * per;
+    int b1 = b0 + per;
+    if (b1 > nblocks) b1 = nblocks;
     float v4[4] = {0.f, 0.f, 0.f, 0.f};
-    int b = 0;
-    for (; b + 3 < nblocks; b += 4)
+    int b = b0;
+    for (; b + 3 < b1; b += 4)
 #pragma unroll
         for (int u = 0; u < 4; ++u) v4[u] += part[(size_t)(b + u) * kLinAcc + i];
-    for (; b < nblocks; ++b) v4[0] += part[(size_t)b * kLinAcc + i];
-    acc[i] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+    for (; b < b1; ++b) v4[0] += part[(size_t)b * kLinAcc + i];
+    mid[(size_t)blockIdx.y * kLinAcc + i] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
 }
 
 // dW[t][c][co] = inv_gs * (scale X(dz) - ka X(1) - kb (G W + b X(1)))   (rows r = kh*16 + kw*4 + c)
@@ -602,9 +609,15 @@ __global__ __launch_bounds__(1024) void conv1_dw_finalize_kernel(Conv1DwFinalize
     __shared__ float G[48][49];
     __shared__ float Wp[48][32];
     const int tid = threadIdx.x;
+    auto total = [&](int i) {     // slice sums of conv1_lin_reduce_kernel, fixed order
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < kLinMid; ++k) v += a.acc[(size_t)k * kLinAcc + i];
+        return v;
+    };
     for (int i = tid; i < 48 * 48; i += 1024) {
         const int r = i / 48, c = i % 48;
-        G[r][c] = (r >= 32 && c < 32) ? a.acc[48 * 32 + c * 48 + r] : a.acc[48 * 32 + i];   // symmetry
+        G[r][c] = (r >= 32 && c < 32) ? total(48 * 32 + c * 48 + r) : total(48 * 32 + i);   // symmetry
     }
     for (int i = tid; i < 48 * 32; i += 1024) {
         const int r = i >> 5, co = i & 31;
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(1024) void conv1_dw_finalize_kernel(Conv1DwFinalize
     float gw = 0.f;
     for (int k = 0; k < 48; ++k) gw = fmaf(G[r][k], Wp[k][co], gw);
     const float xy = gw + a.bias[co] * x1;
-    const float xdz = a.acc[r * 32 + co];
+    const float xdz = total(r * 32 + co);
     const float ka = a.coef[co], kb = a.coef[32 + co];
     a.dW[tc * 32 + co] = (a.scale[co] * xdz - ka * x1 - kb * xy) * a.inv_grad_scale;
 }
@@ -641,10 +654,10 @@ static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     const int prs = a.N * (a.H / 2);
     const int nb = prs < 512 ? prs : 512;
-    float* part = a.acc + kLinAcc;        // [nb][kLinAcc] behind the totals
+    float* part = a.acc + (size_t)kLinMid * kLinAcc;        // [nb][kLinAcc] behind the slice sums
     if (a.nblocks_out) *a.nblocks_out = nb;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(kLinThreads), lds, s, a, part);
-    hipLaunchKernelGGL(conv1_lin_reduce_kernel, dim3((kLinAcc + 255) / 256), dim3(256), 0, s, part, nb, a.acc);
+    hipLaunchKernelGGL(conv1_lin_reduce_kernel, dim3((kLinAcc + 255) / 256, kLinMid), dim3(256), 0, s, part, nb, a.acc);
     return hipGetLastError();
 }
 
@@ -655,7 +668,7 @@ bool conv1_wgrad_lin_ok(int H, int W, int pool, int ldy, int elem_size) {
     if (lds < red) lds = red;
     return pool && (H % 2) == 0 && (W % 2) == 0 && ldy == 32 && lds <= 160 * 1024;
 }
-size_t conv1_wgrad_lin_scratch_floats() { return (size_t)kLinAcc * (1 + 512); }
+size_t conv1_wgrad_lin_scratch_floats() { return (size_t)kLinAcc * (kLinMid + 512); }
 
 hipError_t launch_conv1_wgrad_lin(int dtype, const Conv1WgradLinArgs& a, hipStream_t s) {
     switch (dtype) {

@@ -118,13 +118,13 @@ struct Conv1WgradLinArgs {
     const void* ysel;           // [Mout][32] of T
     const unsigned short* idx;  // [Mout][chunks]
     const float *scale, *shift;
-    float* acc;                 // [48*32 + 48*48] totals, followed by the per-block partials (conv1_wgrad_lin_scratch_floats)
+    float* acc;                 // 16 slice sums of [48*32 + 48*48], followed by the per-block partials (conv1_wgrad_lin_scratch_floats)
     float* psum;                // out: BN-backward partial sums [blocks][2][32] (S1, S2) -- the reduce pass rides here
     int* nblocks_out;           // host: number of partial records written
     int N, H, W;
 };
 struct Conv1DwFinalizeArgs {
-    const float* acc;           // as above
+    const float* acc;           // the 16 slice sums (added here)
     const float* W;             // fp32 HWIO [3][3][3][32]
     const float* bias;
     const float* scale;
