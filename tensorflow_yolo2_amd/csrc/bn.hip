@@ -96,7 +96,59 @@ __global__ __launch_bounds__(SLN * kFinCh) void bn_finalize_kernel(BnFinalizeArg
     }
 }
 
-hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
+// Long partial lists (the 208x208 / 104x104 layers: thousands of records, only C / 8 blocks in the merge above) are
+// first compressed to kCompress records by a 2-D grid: thread = channel, block = (slice of the list, 64 channels),
+// the same shifted-sum merge in double, emitted as (count, mean, M2) float records the merge above then takes.
+constexpr int kCompress = 64;
+__global__ __launch_bounds__(64) void bn_compress_kernel(const float* __restrict__ cnt, const float* __restrict__ mean,
+                                                         const float* __restrict__ m2, int P, int C, int ldp, float* ocnt,
+                                                         float* omean, float* om2) {
+    const int c = blockIdx.y * 64 + threadIdx.x;
+    const int sl = blockIdx.x;
+    const int per = (P + kCompress - 1) / kCompress;
+    const int p0 = sl * per;
+    int p1 = p0 + per;
+    if (p1 > P) p1 = P;
+    if (c >= C) return;
+    const double sft = p0 < p1 ? (double)mean[(size_t)p0 * ldp + c] : 0.0;
+    double n4[4] = {0, 0, 0, 0}, a4[4] = {0, 0, 0, 0}, b4[4] = {0, 0, 0, 0};
+    int p = p0;
+    for (; p + 3 < p1; p += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double k = cnt[p + u];
+            const double d = (double)mean[(size_t)(p + u) * ldp + c] - sft;
+            n4[u] += k;
+            a4[u] += k * d;
+            b4[u] += (double)m2[(size_t)(p + u) * ldp + c] + k * d * d;
+        }
+    }
+    for (; p < p1; ++p) {
+        const double k = cnt[p];
+        const double d = (double)mean[(size_t)p * ldp + c] - sft;
+        n4[0] += k;
+        a4[0] += k * d;
+        b4[0] += (double)m2[(size_t)p * ldp + c] + k * d * d;
+    }
+    const double n = (n4[0] + n4[1]) + (n4[2] + n4[3]), A = (a4[0] + a4[1]) + (a4[2] + a4[3]),
+                 B = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    double mt = n > 0 ? B - A * A / n : 0.0;
+    if (mt < 0) mt = 0;
+    omean[(size_t)sl * ldp + c] = (float)(n > 0 ? sft + A / n : 0.0);
+    om2[(size_t)sl * ldp + c] = (float)mt;
+    if (c == 0 || threadIdx.x == 0) ocnt[sl] = (float)n;     // every channel block writes the same count
+}
+
+hipError_t launch_bn_finalize(const BnFinalizeArgs& a0, hipStream_t s) {
+    BnFinalizeArgs a = a0;
+    if (a.P > 4096 && a.scratch) {   // measured: pays only for the 10,816-record list of the 208x208 layer
+        float* ocnt = a.scratch;
+        float* omean = ocnt + kCompress;
+        float* om2 = omean + (size_t)kCompress * a.ldp;
+        hipLaunchKernelGGL(bn_compress_kernel, dim3(kCompress, (a.C + 63) / 64), dim3(64), 0, s, a.part_cnt, a.part_mean,
+                           a.part_m2, a.P, a.C, a.ldp, ocnt, omean, om2);
+        a.part_cnt = ocnt; a.part_mean = omean; a.part_m2 = om2; a.P = kCompress;
+    }
     // short partial lists (the 13x13 / 26x26 layers: a few dozen records) finish sooner in 4-wave blocks
     if (a.P <= 512) hipLaunchKernelGGL(bn_finalize_kernel<32>, dim3((a.C + kFinCh - 1) / kFinCh), dim3(32 * kFinCh), 0, s, a);
     else hipLaunchKernelGGL(bn_finalize_kernel<128>, dim3((a.C + kFinCh - 1) / kFinCh), dim3(128 * kFinCh), 0, s, a);

@@ -214,6 +214,7 @@ struct BnFinalizeArgs {
     float eps, momentum;
     int update_moving;
     int bessel;
+    float* scratch = nullptr;   // >= 64 * (1 + 2 * ldp) floats: long partial lists are compressed to 64 records first
 };
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 hipError_t launch_bn_infer_prepare(const float* gamma, const float* beta, const float* mm, const float* mv,

@@ -51,12 +51,15 @@ hipError_t launch_get_iou(const float* b1, const float* b2, float* out, int n, h
     return hipGetLastError();
 }
 
-int loss_blocks(int N, int S) { return (N * S * S + 255) / 256; }
+// one wave per block: 10,816 cells at configs[3] then spread over 169 CUs instead of 43 (the kernel is a chain of
+// dependent scalar math per cell: latency, not throughput)
+constexpr int kLossThreads = 64;
+int loss_blocks(int N, int S) { return (N * S * S + kLossThreads - 1) / kLossThreads; }
 
-__global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a) {
-    __shared__ float red[4][256];
+__global__ __launch_bounds__(kLossThreads) void yolo_loss_kernel(LossArgs a) {
+    __shared__ float red[4][kLossThreads];
     const int cells = a.N * a.S * a.S;
-    const int cell = blockIdx.x * 256 + threadIdx.x;
+    const int cell = blockIdx.x * kLossThreads + threadIdx.x;
     float t_class = 0.f, t_obj = 0.f, t_noobj = 0.f, t_coord = 0.f;
     if (cell < cells) {
         const int B = a.B, C = a.C, D = C + 5 * B;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a) {
     red[2][threadIdx.x] = t_noobj;
     red[3][threadIdx.x] = t_coord;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = kLossThreads / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s)
             for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
         __syncthreads();
@@ -151,24 +154,34 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a) {
 }
 
 __global__ void yolo_loss_finalize_kernel(LossArgs a, int nblocks) {
-    // one wave: lanes 0..3 own one loss term each
-    const int k = threadIdx.x;
-    if (k < 4) {
-        double t = 0.0;
-        for (int b = 0; b < nblocks; ++b) t += (double)a.partial[b * 4 + k];
-        t /= (double)a.N;   // reduce_mean over the batch
-        if (k == 2) t *= (double)a.lambda_noobj;
-        if (k == 3) t *= (double)a.lambda_coord;
-        a.loss[k] = (float)t;
+    // one wave; every lane sums a strided share of the block partials of all four terms in double, then a
+    // fixed butterfly: the result does not depend on timing
+    const int lane = threadIdx.x;
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = lane; b < nblocks; b += 64)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] += (double)a.partial[b * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        for (int off = 32; off > 0; off >>= 1) t[k] += __shfl_xor(t[k], off, 64);
+    if (lane == 0) {
+        float l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double v = t[k] / (double)a.N;   // reduce_mean over the batch
+            if (k == 2) v *= (double)a.lambda_noobj;
+            if (k == 3) v *= (double)a.lambda_coord;
+            l[k] = (float)v;
+            a.loss[k] = l[k];
+        }
+        a.loss[4] = l[0] + l[1] + l[2] + l[3];   // net_utils.py:372 order
     }
-    __syncthreads();
-    if (k == 0) a.loss[4] = a.loss[0] + a.loss[1] + a.loss[2] + a.loss[3];   // net_utils.py:372 order
 }
 
 hipError_t launch_yolo_loss(const LossArgs& a, hipStream_t s) {
     if (a.B > kMaxB) return hipErrorInvalidValue;
     const int nb = loss_blocks(a.N, a.S);
-    hipLaunchKernelGGL(yolo_loss_kernel, dim3(nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(yolo_loss_kernel, dim3(nb), dim3(kLossThreads), 0, s, a);
     hipLaunchKernelGGL(yolo_loss_finalize_kernel, dim3(1), dim3(64), 0, s, a, nb);
     return hipGetLastError();
 }

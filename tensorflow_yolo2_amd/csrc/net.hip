@@ -94,6 +94,7 @@ struct y2_ctx {
     bool moving_pending = false;   // last forward ran with update_moving = 0
     std::vector<int> fwd_training;  // per layer BN mode of the last forward
     // shared scratch offsets
+    size_t o_part_scratch = 0;
     size_t o_part_cnt, o_part_mean, o_part_m2, o_psum, o_dA0, o_dA1, o_h32, o_dh32, o_xin_last_end;
     size_t part_rows, part_ld;
     size_t total_infer = 0, total_train = 0;
@@ -188,6 +189,7 @@ static void plan(y2_ctx* c) {
     }
     c->o_part_mean = take(max_slab * sizeof(float));
     c->o_part_m2 = take(max_slab * sizeof(float));
+    c->o_part_scratch = take((size_t)64 * (1 + 2 * max_ld) * sizeof(float));
     c->o_h32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
     c->o_packtab = take(c->L.size() * sizeof(PackLayer));
     c->o_chkranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
@@ -586,6 +588,7 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             f.moving_mean = c->state + y.smm; f.moving_var = c->state + y.smv;
             f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
             f.var = stat + 6 * y.ldy;
+            f.scratch = (float*)(c->ws + c->o_part_scratch);
             f.eps = kBnEps; f.momentum = kBnMomentum; f.update_moving = update_moving ? 1 : 0; f.bessel = c->bessel;
             HIPCHK(launch_bn_finalize(f, s));
         } else {

@@ -105,10 +105,10 @@ hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, hipStream_t s
 __global__ __launch_bounds__(256) void grad_check_ranges_kernel(const float* g, const unsigned* ranges, int nranges,
                                                                 OptCtrl* ctrl) {
     unsigned bad = 0;
-    for (int r = 0; r < nranges; ++r) {     // every block takes a strided share of every range
+    for (int r = blockIdx.x; r < nranges; r += gridDim.x) {     // a block per range (each is a few thousand floats)
         const float* p = g + ranges[2 * r];
         const unsigned cnt = ranges[2 * r + 1];
-        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x)
+        for (unsigned i = threadIdx.x; i < cnt; i += blockDim.x)
             bad |= (__float_as_uint(p[i]) & 0x7F800000u) == 0x7F800000u;
     }
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ctrl->found_inf, 1);
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void grad_check_ranges_kernel(const float* g, 
 hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s) {
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(grad_check_ranges_kernel, dim3(8), dim3(256), 0, s, g,
+    hipLaunchKernelGGL(grad_check_ranges_kernel, dim3(nranges < 64 ? nranges : 64), dim3(256), 0, s, g,
                        (const unsigned*)ranges_dev, nranges, (OptCtrl*)ctrl);
     return hipGetLastError();
 }
