@@ -233,6 +233,19 @@ int y2_adam_step_packed(y2_ctx* ctx, float* m, float* v, void* ctrl, int step, f
 int y2_momentum_step_packed(y2_ctx* ctx, float* accum, void* ctrl, float lr, float momentum, float grad_mult,
                             void* stream);
 
+/* The reference's train_op as ONE call (optimizer.minimize(loss) = compute_gradients + apply_gradients,
+ * src/pascal/pascal_train_darknet.py:49-51; imagenet_train_darknet.py:58): y2_backward over all layers, then, with
+ * ctrl, the sentinel overflow check (y2_grad_check), then y2_adam_step_packed / y2_momentum_step_packed -- and the
+ * same results, bit for bit.  What changes is the schedule on the single-GPU path: for the pooled 3-channel first
+ * layer every layer above it is checked and updated on the weight-gradient stream while the first layer's
+ * gradient kernel runs (their gradients are final by then; the first layer's overflow sentinel is replaced by a
+ * non-finite marker on the gradient tensor that feeds it, which decides the step before that kernel ends).
+ * Data-parallel callers, whose all-reduce sits between the two halves, keep the separate calls. */
+int y2_backward_adam(y2_ctx* ctx, const float* dout, float* m, float* v, void* ctrl, int step, float lr, float beta1,
+                     float beta2, float eps, float grad_mult, void* stream);
+int y2_backward_momentum(y2_ctx* ctx, const float* dout, float* accum, void* ctrl, float lr, float momentum,
+                         float grad_mult, void* stream);
+
 /* ---- single-op entry points (tf.nn.conv2d 'SAME' stride 1, darknet.py:20-21) used by the
  *      per-op parity tests; channel counts are padded internally to the kernels' granularity */
 size_t y2_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int k, int dtype);

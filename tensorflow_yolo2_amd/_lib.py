@@ -86,6 +86,8 @@ SIGNATURES = {
     "y2_momentum_step_guarded": (_i, [_vp, _vp, _vp, _sz, _vp, _f, _f, _f, _vp]),
     "y2_adam_step_packed": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step_packed": (_i, [_vp, _vp, _vp, _f, _f, _f, _vp]),
+    "y2_backward_adam": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _vp]),
+    "y2_backward_momentum": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _vp]),
     "y2_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "y2_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "y2_conv2d_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

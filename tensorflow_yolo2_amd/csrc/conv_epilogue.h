@@ -131,6 +131,8 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
     bool mfma_stats = false;
     if constexpr (SZ == 2) mfma_stats = stats && !bw && (m0 + BP <= a.M);   // block-uniform
     if (!bw) {
+        const bool chk = a.nonfinite != nullptr;
+        bool bad = false;
         auto sweep = [&](auto full_tag, auto stat_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             constexpr bool VSTAT = decltype(stat_tag)::value;
@@ -140,6 +142,13 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
                 Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
                 const bool pv = FULL || (mw0 + prow) < a.M;
                 if (!(EABL & 1) && pv && cch < a.ldy) st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
+                if (chk && pv) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float f = Elem<T>::to_f32(c.v[e]);
+                        bad |= (__float_as_uint(f) & 0x7F800000u) == 0x7F800000u;
+                    }
+                }
                 if (VSTAT && stats) {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
@@ -154,6 +163,7 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
         if (mfma_stats) sweep(std::true_type{}, std::false_type{});
         else if (mw0 + TP * 32 <= a.M) sweep(std::true_type{}, std::true_type{});   // wave-uniform
         else sweep(std::false_type{}, std::true_type{});
+        if (chk && __any(bad) && lane == 0) atomicOr(a.nonfinite, 1u);
     } else {
         // ---- dgrad: store dA and reduce S1 = sum g, S2 = sum g * y_sel of the layer below on the fly
         const bool cv = cch < a.ldy;

@@ -31,6 +31,9 @@ struct ConvArgs {
     const float* bw_scale = nullptr;
     const float* bw_shift = nullptr;
     float* bw_psum = nullptr;
+    // non-null (plain-store launches): set to 1 when a stored value is inf / NaN -- the early overflow guard of
+    // y2_backward_adam / _momentum watches the dgrad that feeds the first layer this way
+    unsigned* nonfinite = nullptr;
 };
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
@@ -291,7 +294,8 @@ hipError_t launch_momentum(float* p, float* acc, const float* g, size_t n, float
                            hipStream_t s);
 // dynamic loss scaling: ctrl = {int found_inf, int step, int skipped, float lr_t}
 hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, hipStream_t s);
-hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s);
+hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s,
+                                    unsigned* flag = nullptr);
 hipError_t launch_opt_ctrl_advance(void* ctrl, float lr, float b1, float b2, hipStream_t s);
 hipError_t launch_adam_guarded(float* p, float* m, float* v, const float* g, size_t n, const void* ctrl, float b1,
                                float b2, float eps, float gscale, hipStream_t s);

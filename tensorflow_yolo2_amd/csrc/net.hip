@@ -102,8 +102,20 @@ struct y2_ctx {
     // pooled 3-channel first layer, training: the linear form of its backward pass (conv1_wgrad.hip) -- its conv
     // output is never stored
     bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
-    size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0;
+    size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0;
     int n_chkranges = 0, n_smallranges = 0, opt_tile_blocks = 0;
+    // both range tables list the layers above the first one first: the optimizer step fused into the backward pass
+    // (y2_backward_adam / _momentum) checks and updates that part while the first layer's gradient is still
+    // being computed
+    int n_chk_upper = 0, n_small_upper = 0;
+    struct FusedOpt {
+        bool on = false;
+        int kind = 0;
+        float* slot0 = nullptr; float* slot1 = nullptr;
+        void* ctrl = nullptr;
+        float lr = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, gmult = 1.f;
+        int step = 0;
+    } fopt;
     std::vector<PackLayer> packtab;
     int pack_blocks = 0;
     // optional per-launch HIP-event bracketing (bench.py roofline leg)
@@ -194,6 +206,7 @@ static void plan(y2_ctx* c) {
     c->o_packtab = take(c->L.size() * sizeof(PackLayer));
     c->o_chkranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
     c->o_smallranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
+    c->o_nfflag = take(256);
     c->total_infer = off;
     // ---- training-only buffers
     for (size_t l = 0; l < c->L.size(); ++l) c->L[l].dyp = take(c->dy_geom((int)l).bytes(sz));
@@ -463,10 +476,12 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
     c->opt_tile_blocks = ntile;
     {   // parameters outside the filter tiles of the fused optimizer + re-pack pass
         std::vector<unsigned> rg;
-        for (size_t l = 0; l < c->L.size(); ++l) {
-            rg.push_back((unsigned)c->L[l].pb);
-            rg.push_back((unsigned)(3 * c->L[l].cout));
+        for (size_t l = 1; l <= c->L.size(); ++l) {      // layer 0 last
+            const Layer& y = c->L[l % c->L.size()];
+            rg.push_back((unsigned)y.pb);
+            rg.push_back((unsigned)(3 * y.cout));
         }
+        c->n_small_upper = (int)c->L.size() - 1;
         if (c->L[0].first3) {
             rg.push_back((unsigned)c->L[0].pW);
             rg.push_back((unsigned)(27 * c->L[0].cout));
@@ -477,10 +492,12 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
     }
     {   // sentinel ranges of y2_grad_check: b, gamma, beta of every layer (contiguous) + the first filter
         std::vector<unsigned> rg;
-        for (size_t l = 0; l < c->L.size(); ++l) {
-            rg.push_back((unsigned)c->L[l].pb);
-            rg.push_back((unsigned)(3 * c->L[l].cout));
+        for (size_t l = 1; l <= c->L.size(); ++l) {      // layer 0 last
+            const Layer& y = c->L[l % c->L.size()];
+            rg.push_back((unsigned)y.pb);
+            rg.push_back((unsigned)(3 * y.cout));
         }
+        c->n_chk_upper = (int)c->L.size() - 1;
         // first filter: a dy_0 that overflows at its own store makes every dW_0[t][ci][co] of its channel co
         // non-finite (inf * x, or inf * 0 = NaN), so one (tap 0, ci 0) row of couts is a complete sentinel
         rg.push_back((unsigned)c->L[0].pW);
@@ -650,6 +667,8 @@ int y2_update_moving_stats(y2_ctx* c, void* stream) {
     return Y2_OK;
 }
 
+static int fused_opt_part(y2_ctx* c, int part, hipStream_t s);
+
 int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* stream) {
     if (!c->ws || !c->bound_training) return fail(Y2_ERR_STATE, "bind with training=1 first");
     if (!c->fwd_saved) return fail(Y2_ERR_STATE, "run y2_forward before y2_backward");
@@ -676,6 +695,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
     }
     float* psum = (float*)(c->ws + c->o_psum);
     bool forked = false;
+    bool opt_early = false;   // fused optimizer: the layers above the first one were updated on the side stream
     int fused_P = 0;          // > 0: the dgrad of the layer above already reduced this layer's BN-backward sums
     static const bool no_fuse = getenv("Y2_NO_BNBWD_FUSE") != nullptr;
     if (c->overlap_wgrad && !c->side) {
@@ -706,6 +726,15 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         const bool rec1 = y.first3 && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
                           conv1_pool_ok(y.H, y.W, y.pool, y.cout);
         const bool lin1 = y.first3 && c->lin1();
+        if (lin1 && c->fopt.on && forked && l == 0) {
+            // Every gradient above this layer is complete once the side stream has passed the dgrad that was just
+            // queued: check and update those layers there, beside this layer's (compute-bound) gradient kernel.
+            HIPCHK(hipEventRecord(c->ev_fork, s));
+            HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            const int rc = fused_opt_part(c, 1, c->side);
+            if (rc != Y2_OK) return rc;
+            opt_early = true;
+        }
         {
             PROF(CAT_BN_BWD);
             if (lin1) {
@@ -783,6 +812,8 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 // conv output, scale and shift beside the dA tile the epilogue holds anyway); the first layer
                 // keeps its own recomputing reduce
                 const bool fuse = !no_fuse && l > 0 && l - 1 >= layer_lo && !z.first3 && z.ldy == y.cin;
+                if (l == 1 && z.first3 && c->fopt.on && c->fopt.ctrl && c->lin1() && forked)
+                    a.nonfinite = (unsigned*)(c->ws + c->o_nfflag);   // this launch stores dA_0: the early guard's view of layer 0
                 if (fuse) {
                     float* zs = (float*)(c->ws + z.stat);
                     a.bw_y = c->ws + (z.pool ? z.ysel : z.y);   // same pixel grid as this launch's output either way
@@ -805,6 +836,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         HIPCHK(hipEventRecord(c->ev_join, c->side));
         HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
     }
+    if (c->fopt.on) return fused_opt_part(c, opt_early ? 2 : 0, s);
     return Y2_OK;
 }
 
@@ -972,20 +1004,65 @@ int y2_momentum_step_guarded(float* params, float* accum, const float* grads, si
 // every filter is read and written by the update anyway, so its MFMA-operand copies (forward and dgrad layouts)
 // leave in the same pass -- the separate re-pack of the next y2_forward (193 MB read again) is not needed.
 // ctrl (nullable): the overflow guard of y2_adam_step_guarded (run y2_grad_check first); NULL: plain step `step`.
+// part: 0 = every parameter; 1 = the filter tiles and the small ranges of the layers above the first one;
+// 2 = the rest (the first layer's b / gamma / beta and a 3-channel first filter) -- 1 then 2 is 0.
 static int opt_step_packed(y2_ctx* c, int kind, float* slot0, float* slot1, void* ctrl, float lr_t_or_lr, float b1,
-                           float b2, float eps, float grad_mult, hipStream_t s) {
+                           float b2, float eps, float grad_mult, hipStream_t s, int part = 0) {
     if (!c->ws || !c->grads || !c->bound_training) return fail(Y2_ERR_STATE, "bind with training=1 first");
     OptPackArgs a{};
     a.p = c->params; a.slot0 = slot0; a.slot1 = slot1; a.g = c->grads; a.ctrl = ctrl;
     a.lr_t = lr_t_or_lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.gmult = grad_mult; a.kind = kind;
     a.tab = (const PackLayer*)(c->ws + c->o_packtab); a.nlayers = (int)c->packtab.size();
-    a.tile_blocks = c->opt_tile_blocks;
-    a.small = (const unsigned*)(c->ws + c->o_smallranges); a.nsmall = c->n_smallranges;
+    a.tile_blocks = part == 2 ? 0 : c->opt_tile_blocks;
+    const unsigned* small = (const unsigned*)(c->ws + c->o_smallranges);
+    a.small = part == 2 ? small + 2 * c->n_small_upper : small;
+    a.nsmall = part == 0 ? c->n_smallranges : (part == 1 ? c->n_small_upper : c->n_smallranges - c->n_small_upper);
     HIPCHK(launch_opt_pack(c->dtype, a, s));
-    if (!c->L.empty() && c->L[0].first3)
+    if (part != 1 && !c->L.empty() && c->L[0].first3)
         HIPCHK(launch_pack_conv1_weights(c->dtype, c->params + c->L[0].pW, c->ws + c->L[0].wf, s));
-    c->weights_dirty = false;
+    if (part != 1) c->weights_dirty = false;
     return Y2_OK;
+}
+// The optimizer step of y2_backward_adam / y2_backward_momentum, whole (part 0) or in its two parts.  With a guard,
+// parts 0 and 1 decide the step: part 1 from the sentinel ranges of the layers above the first one and the
+// non-finite marker of the dgrad that produced dA_0 (optim.hip: every overflow above reaches one of them; the first
+// layer's own sums are fp32 functions of that finite dA_0), so part 2 only follows the decision.
+static int fused_opt_part(y2_ctx* c, int part, hipStream_t s) {
+    const y2_ctx::FusedOpt& f = c->fopt;
+    double lr_t = f.lr;
+    if (f.ctrl) {
+        if (part != 2) {
+            const bool upper = part == 1;
+            HIPCHK(launch_grad_check_ranges(c->grads, c->ws + c->o_chkranges, upper ? c->n_chk_upper : c->n_chkranges,
+                                            f.ctrl, s, upper ? (unsigned*)(c->ws + c->o_nfflag) : nullptr));
+            HIPCHK(launch_opt_ctrl_advance(f.ctrl, f.lr, f.kind == 0 ? f.b1 : 0.9f, f.kind == 0 ? f.b2 : 0.999f, s));
+        }
+    } else if (f.kind == 0) {
+        lr_t = (double)f.lr * sqrt(1.0 - pow((double)f.b2, f.step)) / (1.0 - pow((double)f.b1, f.step));
+    }
+    return opt_step_packed(c, f.kind, f.slot0, f.slot1, f.ctrl, (float)lr_t, f.b1, f.b2, f.eps, f.gmult, s, part);
+}
+// Backward pass + guarded optimizer step + filter re-pack as ONE call (the reference's train_op =
+// optimizer.minimize(loss), src/pascal/pascal_train_darknet.py:49-51).  Same results as y2_backward followed by
+// y2_grad_check and y2_adam_step_packed; the difference is the schedule: with the pooled 3-channel first layer the
+// update of every layer above it runs on the weight-gradient stream while the first layer's gradient is computed.
+int y2_backward_adam(y2_ctx* c, const float* dout, float* m, float* v, void* ctrl, int step, float lr, float beta1,
+                     float beta2, float eps, float grad_mult, void* stream) {
+    if (!m || !v || (!ctrl && step < 1)) return fail(Y2_ERR_ARG, "bad arguments");
+    if (!c->grads) return fail(Y2_ERR_STATE, "bind with a gradient buffer first");
+    c->fopt = y2_ctx::FusedOpt{true, 0, m, v, ctrl, lr, beta1, beta2, eps, grad_mult, step};
+    const int rc = y2_backward(c, dout, 0, (int)c->L.size(), stream);
+    c->fopt.on = false;
+    return rc;
+}
+int y2_backward_momentum(y2_ctx* c, const float* dout, float* accum, void* ctrl, float lr, float momentum,
+                         float grad_mult, void* stream) {
+    if (!accum) return fail(Y2_ERR_ARG, "bad arguments");
+    if (!c->grads) return fail(Y2_ERR_STATE, "bind with a gradient buffer first");
+    c->fopt = y2_ctx::FusedOpt{true, 1, accum, nullptr, ctrl, lr, momentum, 0.f, 0.f, grad_mult, 0};
+    const int rc = y2_backward(c, dout, 0, (int)c->L.size(), stream);
+    c->fopt.on = false;
+    return rc;
 }
 int y2_adam_step_packed(y2_ctx* c, float* m, float* v, void* ctrl, int step, float lr, float beta1, float beta2,
                         float eps, float grad_mult, void* stream) {

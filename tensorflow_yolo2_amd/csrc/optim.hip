@@ -102,9 +102,14 @@ hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, hipStream_t s
 //   * a dy that overflows only at its own f16 store (finite sums) is an inf operand of dgrad_l -> dA_{l-1} -> dbeta_{l-1};
 //     in the first layer (no dgrad below it) dy feeds the filter gradient directly -> dW_0 (checked whole).
 // ranges: [offset, count] pairs of the flat gradient buffer: b / gamma / beta of every layer + the first filter.
+// flag (nullable): a non-finite marker set by a kernel of the backward pass (ConvArgs::nonfinite); consumed here.
 __global__ __launch_bounds__(256) void grad_check_ranges_kernel(const float* g, const unsigned* ranges, int nranges,
-                                                                OptCtrl* ctrl) {
+                                                                OptCtrl* ctrl, unsigned* flag) {
     unsigned bad = 0;
+    if (flag && blockIdx.x == 0 && threadIdx.x == 0) {
+        bad = *flag != 0;
+        *flag = 0;
+    }
     for (int r = blockIdx.x; r < nranges; r += gridDim.x) {     // a block per range (each is a few thousand floats)
         const float* p = g + ranges[2 * r];
         const unsigned cnt = ranges[2 * r + 1];
@@ -113,11 +118,13 @@ __global__ __launch_bounds__(256) void grad_check_ranges_kernel(const float* g, 
     }
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ctrl->found_inf, 1);
 }
-hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s) {
+hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s,
+                                    unsigned* flag) {
     hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(grad_check_ranges_kernel, dim3(nranges < 64 ? nranges : 64), dim3(256), 0, s, g,
-                       (const unsigned*)ranges_dev, nranges, (OptCtrl*)ctrl);
+    const int nb = nranges < 1 ? 1 : (nranges < 64 ? nranges : 64);
+    hipLaunchKernelGGL(grad_check_ranges_kernel, dim3(nb), dim3(256), 0, s, g, (const unsigned*)ranges_dev, nranges,
+                       (OptCtrl*)ctrl, flag);
     return hipGetLastError();
 }
 

@@ -19,11 +19,14 @@ namespace y2 {
 // TG = tap groups: with TG = 2 two waves share one (ci, co) tile, taps 0-4 and 5-8 -- twice the
 // waves per SIMD at the same accumulator footprint per wave (LDS reads and latency bubbles of
 // one wave hide behind the other's MFMAs) and no cross-wave reduction.
-template <typename T, int WI, int WO, int TG = 1, int KS = 1>
+// CW = 32-wide co sub-tiles per wave: with CW = 2 every X fragment feeds two MFMAs (1.4 instead of 2.4
+// transposed LDS reads per MFMA) and the block stages a dY tile twice as wide per X window (337 instead of
+// 144 FLOP per staged byte at 13x13 with 64 ci).
+template <typename T, int WI, int WO, int TG = 1, int KS = 1, int CW = 1>
 struct Wg9Cfg {
     static constexpr int NW = WI * WO * TG, NT = NW * 64;
     static constexpr int SZ = sizeof(T);
-    static constexpr int BI = 32 * WI, BO = 32 * WO;
+    static constexpr int BI = 32 * WI, BO = 32 * WO * CW;
     static constexpr int BKP = ((SZ == 2) ? 64 : 32) * KS;   // pixels per K step
     static constexpr int ROWX = BI * SZ, ROWY = BO * SZ;
     static constexpr int LPRX = ROWX / 16, LPRY = ROWY / 16;
@@ -44,9 +47,9 @@ Y2_DEV int wg9_swz(int row) {
 
 // NS LDS stages; NS-1 K steps of LDS-DMA stay in flight across the raw barrier (counted vmcnt):
 // with one wave per SIMD (as many waves as the dW tiling yields) this is what hides HBM latency.
-template <typename T, int WI, int WO, int NS, int TG, int T0, int NTAP, int KS = 1>
+template <typename T, int WI, int WO, int NS, int TG, int T0, int NTAP, int KS = 1, int CW = 1>
 Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
-    typedef Wg9Cfg<T, WI, WO, TG, KS> Cfg;
+    typedef Wg9Cfg<T, WI, WO, TG, KS, CW> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -103,11 +106,13 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
         }
     };
 
-    f32x16 acc[NTAP];
+    f32x16 acc[NTAP][CW];
 #pragma unroll
     for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+        for (int j = 0; j < CW; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[t][j][q] = 0.f;
 
     const int r32 = lane & 31, hh = lane >> 5;
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
@@ -135,7 +140,10 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
         if constexpr (SZ == 2) {
             // dY fragment address (no tap shift): rows kg*16 + 8*hh + qq (+4)
             const int fy = wg9_swz<ROWY, SZ>(qq);
-            const char* pyb = ys + (8 * hh + qq) * ROWY + (((wo * 4 + 2 * g1 + (pp >> 1)) ^ fy) * 16) + (pp & 1) * 8;
+            const char* pyb[CW];
+#pragma unroll
+            for (int j = 0; j < CW; ++j)
+                pyb[j] = ys + (8 * hh + qq) * ROWY + ((((wo * CW + j) * 4 + 2 * g1 + (pp >> 1)) ^ fy) * 16) + (pp & 1) * 8;
             // X fragment per tap: row = 8*hh + qq + shift[t]; the swizzle follows the LDS row
             const char* pxb[NTAP];
 #pragma unroll
@@ -148,10 +156,13 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
             // while the nine MFMAs of group kg issue (one wave per SIMD: nothing else hides the
             // ~100-cycle LDS latency; the compiler's own schedule keeps only one fragment ahead).
             typedef typename Elem<T>::frag frag_t;
-            frag_t fa0[NTAP], fa1[NTAP], fb0, fb1;
-            auto load_group = [&](int kg, frag_t (&fa)[NTAP], frag_t& fb) {
-                const char* py = pyb + kg * 16 * ROWY;
-                fb = tr_frag<T>(py, py + 4 * ROWY);
+            frag_t fa0[NTAP], fa1[NTAP], fb0[CW], fb1[CW];
+            auto load_group = [&](int kg, frag_t (&fa)[NTAP], frag_t (&fb)[CW]) {
+#pragma unroll
+                for (int j = 0; j < CW; ++j) {
+                    const char* py = pyb[j] + kg * 16 * ROWY;
+                    fb[j] = tr_frag<T>(py, py + 4 * ROWY);
+                }
 #pragma unroll
                 for (int t = 0; t < NTAP; ++t) {
                     const char* px = pxb[t] + kg * 16 * ROWX;
@@ -164,28 +175,37 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
             for (int kg = 0; kg < BKP / 16; kg += 2) {
                 load_group(kg + 1, fa1, fb1);
 #pragma unroll
-                for (int t = 0; t < NTAP; ++t) mma32(acc[t], fa0[t], fb0);
+                for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) mma32(acc[t][j], fa0[t], fb0[j]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kg + 2 < BKP / 16) load_group(kg + 2, fa0, fb0);
 #pragma unroll
-                for (int t = 0; t < NTAP; ++t) mma32(acc[t], fa1[t], fb1);
+                for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) mma32(acc[t][j], fa1[t], fb1[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll 4
             for (int s2 = 0; s2 < BKP / 2; ++s2) {
                 const int row = 2 * s2 + hh;
-                const float fb = *(const float*)(ys + row * ROWY + (wo * 32 + r32) * 4);
+                float fb[CW];
+#pragma unroll
+                for (int j = 0; j < CW; ++j) fb[j] = *(const float*)(ys + row * ROWY + ((wo * CW + j) * 32 + r32) * 4);
 #pragma unroll
                 for (int t = 0; t < NTAP; ++t) {
                     const float fa = *(const float*)(xs + (row + shift[t]) * ROWX + (wi * 32 + r32) * 4);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa, fb[j], acc[t][j], 0, 0, 0);
                 }
             }
         }
     }
-    const int co = co0 + wo * 32 + r32;
-    if (co < a.Cout) {
+#pragma unroll
+    for (int j = 0; j < CW; ++j) {
+        const int co = co0 + (wo * CW + j) * 32 + r32;
+        if (co >= a.Cout) continue;
 #pragma unroll
         for (int t = 0; t < NTAP; ++t)
 #pragma unroll
@@ -193,22 +213,22 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
                 const int ci = ci0 + wi * 32 + acc_row(q, hh);
                 if (ci < a.Cin) {
                     float* dst = a.dW + ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
-                    if (a.splitk == 1) *dst = acc[t][q] * a.scale;
-                    else atomicAdd(dst, acc[t][q] * a.scale);
+                    if (a.splitk == 1) *dst = acc[t][j][q] * a.scale;
+                    else atomicAdd(dst, acc[t][j][q] * a.scale);
                 }
             }
     }
 }
 
-template <typename T, int WI, int WO, int NS, int TG, int KS = 1>
+template <typename T, int WI, int WO, int NS, int TG, int KS = 1, int CW = 1>
 __global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9_kernel(WgradArgs a, int wrows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (TG == 1) {
-        wg9_body<T, WI, WO, NS, 1, 0, 9, KS>(a, wrows, smem);
+        wg9_body<T, WI, WO, NS, 1, 0, 9, KS, CW>(a, wrows, smem);
     } else {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (w < WI * WO) wg9_body<T, WI, WO, NS, 2, 0, 5, KS>(a, wrows, smem);   // same barrier count in both arms
-        else wg9_body<T, WI, WO, NS, 2, 5, 4, KS>(a, wrows, smem);
+        if (w < WI * WO) wg9_body<T, WI, WO, NS, 2, 0, 5, KS, CW>(a, wrows, smem);   // same barrier count in both arms
+        else wg9_body<T, WI, WO, NS, 2, 5, 4, KS, CW>(a, wrows, smem);
     }
 }
 
@@ -427,17 +447,19 @@ static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0)
     return hipGetLastError();
 }
 
-template <typename T, int WI, int WO, int NS, int TG = 1, int KS = 1>
-static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s) {
-    typedef Wg9Cfg<T, WI, WO, TG, KS> Cfg;
+template <typename T, int WI, int WO, int NS, int TG = 1, int KS = 1, int CW = 1>
+static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s, int blocks_target = 0) {
+    typedef Wg9Cfg<T, WI, WO, TG, KS, CW> Cfg;
     static_assert(Cfg::NIY % Cfg::NW == 0, "dY pieces must split evenly over waves");
     const int pitch = a.W + 1;
     int wrows = Cfg::BKP + 2 * pitch + 2;
-    const int gran = Cfg::RPIX * Cfg::NW;           // every wave issues the same number of pieces
+    // deeper rings count the loads in flight, so every wave must issue the same number of pieces; two
+    // stages drain to zero and take whole pieces only
+    const int gran = NS > 2 ? Cfg::RPIX * Cfg::NW : Cfg::RPIX;
     wrows = (wrows + gran - 1) / gran * gran;
     size_t lds = NS * ((size_t)wrows * Cfg::ROWX + Cfg::YS);
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    auto kern = wgrad9_kernel<T, WI, WO, NS, TG, KS>;
+    auto kern = wgrad9_kernel<T, WI, WO, NS, TG, KS, CW>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
     const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
@@ -446,6 +468,7 @@ static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s) {
         // short image rows (big dW, K = a few thousand steps): two blocks per CU measured best;
         // long rows (tiny dW, K = 10^5 steps): ~3 blocks per CU to cover the HBM stream
         long sk = a.W <= 26 ? (512 + tiles / 2) / tiles : (768 + tiles - 1) / tiles;
+        if (blocks_target > 0) sk = (blocks_target + tiles / 2) / tiles;
         const long maxsk = (ksteps + 7) / 8;
         if (sk > maxsk) sk = maxsk;
         if (sk < 1) sk = 1;
@@ -550,6 +573,17 @@ hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s)
         case 14: return wg9_launch_ns<half_t, 2, 1, 3, 2>(a, s);     // 64 x 32, 3 stages
         case 16: return wg9_launch_ns<half_t, 2, 1, 2, 1>(a, s);     // 64 x 32 tiles, 2 waves (no tap split)
         case 50: return wg9_launch_ns<half_t, 2, 1, 2, 2, 2>(a, s);   // 64 x 32, K step of 128 pixels
+        // two co sub-tiles per wave
+        case 60: return wg9_launch_ns<half_t, 2, 2, 2, 2, 1, 2>(a, s, 256);   // 64 ci x 128 co, 8 waves, one block per CU
+        case 61: return wg9_launch_ns<half_t, 2, 2, 2, 2, 2, 2>(a, s, 256);   // same, K step 128
+        case 62: return wg9_launch_ns<half_t, 2, 1, 2, 2, 1, 2>(a, s, 512);   // 64 ci x 64 co, 4 waves, two blocks per CU
+        case 63: return wg9_launch_ns<half_t, 2, 1, 2, 2, 2, 2>(a, s, 512);
+        case 64: return wg9_launch_ns<half_t, 4, 1, 2, 2, 1, 2>(a, s, 256);   // 128 ci x 64 co, 8 waves
+        case 65: return wg9_launch_ns<half_t, 4, 1, 2, 2, 2, 2>(a, s, 256);
+        case 66: return wg9_launch_ns<half_t, 2, 2, 3, 2, 1, 2>(a, s, 256);   // 3 stages
+        case 67: return wg9_launch_ns<half_t, 4, 2, 2, 2, 1, 2>(a, s, 256);   // 128 ci x 128 co, 16 waves
+        case 68: return wg9_launch_ns<half_t, 2, 1, 3, 2, 1, 2>(a, s, 512);
+        case 69: return wg9_launch_ns<half_t, 2, 2, 2, 2, 1, 2>(a, s, 512);   // 64 x 128, two blocks per CU
         case 51: return wg9_launch_ns<half_t, 2, 2, 2, 2, 2>(a, s);   // 64 x 64, 8 waves, K step 128
         case 52: return wg9_launch_ns<half_t, 1, 2, 2, 2, 2>(a, s);
         // ring form (long rows)

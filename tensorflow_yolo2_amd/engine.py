@@ -367,6 +367,22 @@ class AdamOptimizer:
         if self.guard:
             self.scaler.after_step()
 
+    def backward_step(self, dout, grad_mult=1.0):
+        """train_op in one library call: net.backward(dout) + the (guarded) step + filter re-pack, with the update
+        of the layers above the first one overlapped with the first layer's gradient kernel (single-process
+        training; the data-parallel trainers reduce between backward() and step())."""
+        n = self.net
+        if not (self.fused_pack and n.training):
+            n.backward(dout)
+            return self.step(grad_mult)
+        self.t += 1
+        ctrl = _ptr(self.scaler.ctrl) if self.guard else C.c_void_p(0)
+        dout = dout.contiguous()
+        check(n.lib.y2_backward_adam(n.h, _ptr(dout), _ptr(self.m), _ptr(self.v), ctrl, self.t, self.lr, self.b1,
+                                     self.b2, self.eps, grad_mult, _stream()))
+        if self.guard:
+            self.scaler.after_step()
+
     # ---- tf.train.Saver slots (ADVICE r1: a resumed run must not restart Adam at t = 0)
     def export_state(self):
         t = self.scaler.state()[1] if self.guard else self.t
@@ -407,6 +423,19 @@ class MomentumOptimizer:
             check(n.lib.y2_momentum_step(_ptr(n.params), _ptr(self.accum), _ptr(n.grads), n.n_params, self.lr,
                                          self.mom, grad_mult, _stream()))
             n.params_changed()
+        if self.guard:
+            self.scaler.after_step()
+
+    def backward_step(self, dout, grad_mult=1.0):
+        """see AdamOptimizer.backward_step"""
+        n = self.net
+        if not (self.fused_pack and n.training):
+            n.backward(dout)
+            return self.step(grad_mult)
+        ctrl = _ptr(self.scaler.ctrl) if self.guard else C.c_void_p(0)
+        dout = dout.contiguous()
+        check(n.lib.y2_backward_momentum(n.h, _ptr(dout), _ptr(self.accum), ctrl, self.lr, self.mom, grad_mult,
+                                         _stream()))
         if self.guard:
             self.scaler.after_step()
 

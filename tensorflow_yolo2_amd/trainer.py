@@ -116,6 +116,16 @@ class GradReducer:
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
+    def backward_reduce_step(self, dout, opt):
+        """backward + gradient mean over the replicas + optimizer step.  One process: the library's fused train_op
+        (AdamOptimizer.backward_step); replicas: backward_and_reduce, then the step on the reduced gradients."""
+        if _dist() is None:
+            opt.backward_step(dout)
+            return 1
+        world = self.backward_and_reduce(dout)
+        opt.step(grad_mult=1.0 / world)
+        return world
+
     def backward_and_reduce(self, dout):
         dist = _dist()
         net = self.net
@@ -160,8 +170,7 @@ class DetectorTrainer:
 
     def step(self, images, labels):
         grid_net, (loss, ious, mask, dnet) = self.forward_loss(images, labels, True, True, update_moving=True)
-        world = self.reducer.backward_and_reduce(dnet)
-        self.opt.step(grad_mult=1.0 / world)
+        self.reducer.backward_reduce_step(dnet, self.opt)
         self.last = (loss, ious, mask)
         return loss, ious, mask
 
@@ -214,11 +223,10 @@ class MultiScaleDetectorTrainer:
         S = net.out_shape[1]
         grid_net = net.forward(images, True, True, update_moving=True)
         loss, ious, mask, dnet = yolo_loss(grid_net, labels, self.num_class, self.batch, size, S, self.B)
-        world = self.reducers[size].backward_and_reduce(dnet)
         self.opt.net = net                         # same flat buffers; keeps params_changed() on the live context
         if self.opt.scaler is not None:
             self.opt.scaler.attach(net)            # one loss scale for every size
-        self.opt.step(grad_mult=1.0 / world)
+        self.reducers[size].backward_reduce_step(dnet, self.opt)
         self.steps += 1
         return loss, ious, mask
 
@@ -239,6 +247,5 @@ class ClassifierTrainer:
     def step(self, images, labels):
         logits = self.net.forward(images, True, True, update_moving=True)
         loss, dlogits = softmax_cross_entropy(logits, labels)
-        world = self.reducer.backward_and_reduce(dlogits)
-        self.opt.step(grad_mult=1.0 / world)
+        self.reducer.backward_reduce_step(dlogits, self.opt)
         return loss, logits
