@@ -344,6 +344,7 @@ static int dev_rule(int W, int Cout) {
 // row_bytes = input channels * element size of the launch (forward: cin_s, dgrad: ldy).
 int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M) {
     if (taps != 9) return 0;
+    if (conv_rf_config(taps, W, row_bytes, Cout, M)) return 0;    // register-resident filters: fetched from K-contiguous rows
     if (!(W <= 26 || (W > 52 && W <= 104) || (W > 104 && Cout <= 32))) return 0;
     const bool narrow = ((M + 383) / 384) * ((Cout + 127) / 128) < 160;
     if (W <= 26 && Cout > 64 && M >= 384 * 8 && (row_bytes % 128) == 0 && !narrow) return 2;
@@ -355,9 +356,16 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M) {
 //   3x3, rows of 52                                        : conv_halo  (halo image + LDS filter ring)
 //   3x3 208-wide forward, and every 1x1                    : conv_igemm (per-tap staging)
 // *block_pixels receives the pixel-tile size used (= rows per BN partial record)
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels) {
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels, int* records) {
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
+    if (dtype != 0 && !a.bw_psum && conv_rf_config(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M)) {
+        int rec = 0;
+        e = launch_conv_rf(dtype, a, s, &bp, &rec);
+        if (block_pixels) *block_pixels = bp;
+        if (records) *records = rec;
+        return e;
+    }
     if (conv_filter_layout(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M)) e = launch_conv_haloq(dtype, a, s, &bp);
 #ifdef Y2_DEV
     else if (a.taps == 9 && dtype == 1 && dev_rule(a.W, a.Cout) >= 0)
@@ -366,6 +374,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_p
     else if (a.taps == 9 && a.W <= 52) e = launch_conv_halo(dtype, a, s, &bp);
     else e = launch_conv_igemm(dtype, a, s);
     if (block_pixels) *block_pixels = bp;
+    if (records) *records = (a.M + bp - 1) / bp;
     return e;
 }
 

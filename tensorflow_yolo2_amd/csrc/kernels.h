@@ -39,7 +39,11 @@ hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // 
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
 hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels); // + filters via registers
 int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M);   // filter layout launch_conv expects (0/1/2)
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels = nullptr);  // policy
+// policy; *records = rows of the BN partial list written (one per pixel tile)
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels = nullptr, int* records = nullptr);
+// 3x3, filters resident in registers, persistent workgroups over the bordered pixel space (conv_rf.hip)
+int conv_rf_config(int taps, int W, int row_bytes, int Cout, int M);   // 0: not this form
+hipError_t launch_conv_rf(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels, int* records);
 int conv_block_pixels(int Cout);
 int conv_block_couts(int Cout);
 

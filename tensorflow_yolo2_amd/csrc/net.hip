@@ -48,6 +48,11 @@ static int fail(int code, const char* fmt, ...) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
+static inline size_t part_rows_bound(int N, int H, int W, int cout) {
+    const size_t bp = conv_block_pixels(cout);
+    return ((size_t)N * (H + 1) * (W + 1) + bp - 1) / bp;
+}
+
 constexpr float kBnEps = 1e-3f;       // tf.layers.batch_normalization defaults
 constexpr float kBnMomentum = 0.99f;
 
@@ -181,7 +186,8 @@ static void plan(y2_ctx* c) {
             y.wf = take((size_t)y.cout_pad * y.k * y.k * y.cin_s * sz);
             y.wd = take((size_t)y.cin_pad * y.k * y.k * y.ldy * sz);
         }
-        size_t prow = y.first3 ? 2048 : (size_t)(y.M + conv_block_pixels(y.cout) - 1) / conv_block_pixels(y.cout);
+        // one record per pixel tile; the persistent form tiles the bordered positions (conv_rf.hip)
+        size_t prow = y.first3 ? 2048 : part_rows_bound(c->N, y.H, y.W, y.cout);
         if (prow > max_part_rows) max_part_rows = prow;
         if ((size_t)y.ldy > max_ld) max_ld = y.ldy;
         size_t mo = (size_t)c->N * y.Ho * y.Wo * y.ldy;
@@ -195,7 +201,7 @@ static void plan(y2_ctx* c) {
     // partial slabs are sized for the worst (rows x channels) product over layers
     size_t max_slab = 0;
     for (auto& y : c->L) {
-        size_t prow = y.first3 ? 2048 : (size_t)(y.M + conv_block_pixels(y.cout) - 1) / conv_block_pixels(y.cout);
+        size_t prow = y.first3 ? 2048 : part_rows_bound(c->N, y.H, y.W, y.cout);
         size_t s = prow * y.ldy;
         if (s > max_slab) max_slab = s;
     }
@@ -592,9 +598,9 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             if (training) { a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2; }
             a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.cin_s; a.M = y.M; a.Cout = y.cout; a.ldy = y.ldy;
             a.taps = y.k * y.k;
-            int bp = 0;
-            { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s, &bp)); }
-            P = (y.M + bp - 1) / bp;
+            int bp = 0, rec = 0;
+            { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }
+            P = rec;
         }
         PROF(CAT_BN_FWD);
         if (training) {
@@ -819,8 +825,9 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                     a.bw_y = c->ws + (z.pool ? z.ysel : z.y);   // same pixel grid as this launch's output either way
                     a.bw_scale = zs; a.bw_shift = zs + z.ldy; a.bw_psum = psum;
                 }
-                { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s, &bp)); }
-                if (fuse) fused_P = (y.M + bp - 1) / bp;
+                int rec = 0;
+                { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }
+                if (fuse) fused_P = rec;
                 c->dA_cur ^= 1;
                 if (l == 0)   // the stack's input gradient leaves in fp32 NHWC, loss scale divided out
                     HIPCHK(launch_cast_to_f32(c->dtype, dA[c->dA_cur], c->dinput, (size_t)y.M, y.cin, y.cin, s, inv_gs));
