@@ -10,10 +10,12 @@
 //     workgroup, which walks a contiguous run of pixel tiles: no filter traffic and no prologue per tile;
 //   * the tiles run LINEARLY over the bordered pixel space (common.h: pitch W + 1, shared zero borders), like the
 //     K loop of wgrad9.hip: output q reads inputs q + (kh-1)*pitch + (kw-1), so the input of a run is ONE
-//     contiguous stream, staged by LDS-DMA into a three-slot ring of BP-row groups, each input pixel once per
+//     contiguous stream, staged by LDS-DMA into a four-slot ring of BP-row groups, each input pixel once per
 //     workgroup; border positions are computed and dropped (pitch / W - 1 = 0.5 % more work at 208);
-//   * the group for the next tile is in flight while the epilogue of the current one runs, and two workgroups
-//     per CU in different phases keep the matrix pipe busy through each other's epilogues.
+//   * the group two tiles ahead is in flight through a whole tile (counted vmcnt: LDS-DMA pieces and the epilogue's
+//     stores retire in issue order, so every lane stores every sweep -- masked rows to the slack row behind y --
+//     and every stage issues its full piece count), and two workgroups per CU in different phases keep the matrix
+//     pipe busy through each other's epilogues.
 // Epilogue = conv_epilogue.h's: bias, rounding, wave-private [pixel][cout] patch, full-line stores, batch-norm
 // partials of the values as stored from the matrix pipe (S1 = ones x y, S2 = diag(y y^T)); here a record covers
 // the valid pixels of one BP-position tile (border rows of the patch are written as zeros), and the
@@ -31,22 +33,29 @@ struct RfGeom {
     int qmax;                // readable bordered rows (bbody_pixels)
 };
 
-template <typename T, int C, int NCT, int WP, int TP>
+// PR = pixel rows of the wave's epilogue patch (16 where two workgroups must share a CU's LDS, else 32)
+template <typename T, int C, int NCT, int WP, int TP, int PR>
 struct RfCfg {
     static constexpr int SZ = sizeof(T);
     static constexpr int NW = WP, NT = NW * 64;
     static constexpr int ROWB = C * SZ, LPR = ROWB / 16, RPI = 64 / LPR, RPB = 256 / ROWB;
     static constexpr int G = C * SZ / 32, KGT = 9 * G;       // 32-byte k-groups per tap / in all
     static constexpr int BP = WP * TP * 32, BC = NCT * 32;
-    static constexpr int R = 3 * BP, RINGB = R * ROWB;
-    static constexpr int EROW = BC * SZ + 16, PATCHB = 32 * EROW;
+    static constexpr int NSLOT = 4, R = NSLOT * BP, RINGB = R * ROWB;
+    static constexpr int EROW = BC * SZ + 16, PATCHB = PR * EROW;
     static constexpr int SCR = (2 * BC + 4) * 4;             // per wave: S1[BC], S2[BC], count
     static constexpr int LDS = RINGB + NW * PATCHB + NW * SCR + BC * 4;   // + the bias slice
+    static constexpr int PW = BP / RPI / NW;                 // LDS-DMA pieces per wave and group
+    static constexpr int CPR = BC / 8, NIT = PR * CPR / 64;  // 16-byte chunks per patch row; store sweeps per patch
+    static constexpr int NST = TP * (32 / PR) * NIT;         // store instructions per wave and tile
+    static_assert((R & (R - 1)) == 0, "ring rows: power of two");
+    static_assert(BP % (RPI * NW) == 0 && (PR * CPR) % 64 == 0, "even split of the pieces / patch chunks over lanes");
+    static_assert(PW + NST < 63, "counted vmcnt");
 };
 
-template <typename T, int C, int NCT, int WP, int TP>
+template <typename T, int C, int NCT, int WP, int TP, int PR>
 __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom gm) {
-    typedef RfCfg<T, C, NCT, WP, TP> Cfg;
+    typedef RfCfg<T, C, NCT, WP, TP, PR> Cfg;
     typedef typename Elem<T>::frag frag_t;
     constexpr int SZ = Cfg::SZ, NW = Cfg::NW, ROWB = Cfg::ROWB, LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB;
     constexpr int G = Cfg::G, KGT = Cfg::KGT, BP = Cfg::BP, BC = Cfg::BC, R = Cfg::R, EROW = Cfg::EROW;
@@ -77,19 +86,21 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
     }
     float* const biasl = scr_all + NW * (Cfg::SCR / 4);   // registers are for the filters: the bias slice waits in LDS
     if (tid < BC) biasl[tid] = (a.bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
+    wait_vmcnt<0>();    // the filter fetch must not sit in the counted waits below
 
-    // ---- LDS-DMA of one BP-row group into its ring slot (rows below 0 / past the tensor only feed dropped outputs)
+    // ---- LDS-DMA of one BP-row group into its ring slot: ALWAYS Cfg::PW pieces per wave (the waits below count
+    // them).  Rows below 0 / past the tensor only feed dropped outputs: their pieces re-read an in-range row.
     const int lrow = lane / LPR, lslot = lane % LPR;
     auto stage = [&](int gi) {
-        if (gi < 0) return;
-        const int slot = gi % 3;
-        const char* xs = (const char*)a.x + (size_t)gi * BP * ROWB;
+        const int slot = gi & (Cfg::NSLOT - 1);
         char* dst = ring + slot * BP * ROWB;
-        for (int i = w; i < BP / RPI; i += NW) {
-            if (gi * BP + i * RPI >= gm.qmax) break;
-            const int row = i * RPI + lrow;
-            const int rr = slot * BP + row;
-            glds16(xs + (size_t)row * ROWB + ((lslot ^ ((rr / RPB) % LPR)) * 16), dst + i * 1024);
+#pragma unroll
+        for (int k = 0; k < Cfg::PW; ++k) {
+            const int i = k * NW + w;
+            int row0 = gi * BP + i * RPI;
+            row0 = row0 < 0 ? 0 : (row0 + RPI > gm.qmax ? gm.qmax - RPI : row0);
+            const int rr = slot * BP + i * RPI + lrow;
+            glds16((const char*)a.x + (size_t)(row0 + lrow) * ROWB + ((lslot ^ ((rr / RPB) % LPR)) * 16), dst + i * 1024);
         }
     };
 
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int q = T0 * BP + (w * TP + j) * 32 + r32;
-        qm[j] = q % R;
+        qm[j] = q & (R - 1);
         const int rowi = q / pitch;
         pcol[j] = q - rowi * pitch;
         pimg[j] = rowi / gm.rows_img;
@@ -111,34 +122,40 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
     const bool stats = a.part_mean != nullptr;
     const bool chk = a.nonfinite != nullptr;
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;   // transposed patch reads (statistics)
+    char* const ydump = (char*)a.y + (size_t)a.M * a.ldy * SZ;   // the slack row behind y: target of the masked stores
+
+    auto emit_record = [&](int rec) {     // tid < BC: one (count, mean, M2) record from the four waves' sums
+        double S1 = 0.0, S2 = 0.0;
+        float cnt = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const float* q = scr_all + k * (Cfg::SCR / 4);
+            S1 += (double)q[tid];
+            S2 += (double)q[BC + tid];
+            cnt += q[2 * BC];
+        }
+        const int co = n0 + tid;
+        if (co < a.ldy) {
+            const double md = cnt > 0.f ? S1 / (double)cnt : 0.0;
+            const double m2 = S2 - S1 * md;
+            a.part_mean[(size_t)rec * a.ldy + co] = (float)md;
+            a.part_m2[(size_t)rec * a.ldy + co] = (float)(m2 > 0.0 ? m2 : 0.0);
+        }
+        if (tid == 0 && blockIdx.y == 0) a.part_cnt[rec] = cnt;
+    };
 
     stage(T0 - 1);
     stage(T0);
     stage(T0 + 1);
+    stage(T0 + 2);
     for (int tile = T0; tile < T1; ++tile) {
-        wait_vmcnt<0>();
+        // groups tile-1 .. tile+1 have landed when all but the youngest group (and the stores behind it) are done
+        if (tile == T0) wait_vmcnt<Cfg::PW>();
+        else wait_vmcnt<Cfg::PW + Cfg::NST>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // the record of the previous tile, from the scratch its epilogue filled before this barrier
-        if (stats && tile > T0 && tid < BC) {
-            double S1 = 0.0, S2 = 0.0;
-            float cnt = 0.f;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) {
-                const float* q = scr_all + k * (Cfg::SCR / 4);
-                S1 += (double)q[tid];
-                S2 += (double)q[BC + tid];
-                cnt += q[2 * BC];
-            }
-            const int co = n0 + tid;
-            if (co < a.ldy) {
-                const double md = cnt > 0.f ? S1 / (double)cnt : 0.0;
-                const double m2 = S2 - S1 * md;
-                a.part_mean[(size_t)(tile - 1) * a.ldy + co] = (float)md;
-                a.part_m2[(size_t)(tile - 1) * a.ldy + co] = (float)(m2 > 0.0 ? m2 : 0.0);
-            }
-            if (tid == 0 && blockIdx.y == 0) a.part_cnt[tile - 1] = cnt;
-        }
+        if (stats && tile > T0 && tid < BC) emit_record(tile - 1);
 
         f32x16 acc[NCT][TP];
 #pragma unroll
@@ -153,9 +170,7 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
             const int t = s / G, g = s % G;
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                int rr = qm[j] + sh[t];
-                rr = rr < 0 ? rr + R : rr;
-                rr = rr >= R ? rr - R : rr;
+                const int rr = (qm[j] + sh[t]) & (R - 1);
                 f[j] = *(const frag_t*)(ring + rr * ROWB + (((2 * g + hh) ^ ((rr / RPB) % LPR)) * 16));
             }
         };
@@ -170,11 +185,11 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
                 for (int j = 0; j < TP; ++j) mma32(acc[i][j], wreg[i][s], fa[s & 1][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_barrier();          // every wave is done with the oldest group: its slot takes the group of tile + 2
+        __builtin_amdgcn_s_barrier();          // every wave is done with the oldest group: its slot takes group tile + 3
         asm volatile("" ::: "memory");
-        if (tile + 1 < T1) stage(tile + 2);
+        stage(tile + 3);
 
-        // ---- epilogue, one 32-pixel sub-tile at a time through the wave's own patch
+        // ---- epilogue, PR pixel rows at a time through the wave's own patch
         float S1w[NCT], S2w[NCT];
 #pragma unroll
         for (int i = 0; i < NCT; ++i) S1w[i] = S2w[i] = 0.f;
@@ -184,61 +199,67 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
         for (int j = 0; j < TP; ++j) {
             const bool valid = pcol[j] >= 1 && prow_[j] >= 1 && pimg[j] < a.N;
             const int p = valid ? (pimg[j] * a.H + prow_[j] - 1) * a.W + pcol[j] - 1 : -1;
-#pragma unroll
-            for (int i = 0; i < NCT; ++i)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    T o[4];
-                    const f32x4 b4 = *(const f32x4*)(biasl + i * 32 + 8 * q4 + 4 * hh);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        o[k] = valid ? Elem<T>::from_f32(acc[i][j][4 * q4 + k] + b4[k]) : (T)0.f;
-                    *(u32x2*)(patch + r32 * EROW + (i * 32 + 8 * q4 + 4 * hh) * SZ) = *(const u32x2*)o;
-                }
             cntw += __popcll(__ballot(valid && hh == 0));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            constexpr int EPC = 8, CPR = BC / EPC, RPIe = 64 / CPR, NIT = 32 / RPIe;
-            const int ch = lane % CPR, prow0 = lane / CPR;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int prow = it * RPIe + prow0;
-                const int pr = __shfl(p, prow, 64);
-                Chunk<T> c = ld_chunk<T>(patch + prow * EROW + ch * 16);
-                const int cch = n0 + ch * EPC;
-                if (pr >= 0 && cch < a.ldy) {
-                    st_chunk<T>((char*)a.y + ((size_t)pr * a.ldy + cch) * SZ, c);
-                    if (chk) {
+            for (int hp = 0; hp < 32 / PR; ++hp) {
+                if (PR == 32 || (r32 / PR) == hp) {
+#pragma unroll
+                    for (int i = 0; i < NCT; ++i)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            T o[4];
+                            const f32x4 b4 = *(const f32x4*)(biasl + i * 32 + 8 * q4 + 4 * hh);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                o[k] = valid ? Elem<T>::from_f32(acc[i][j][4 * q4 + k] + b4[k]) : (T)0.f;
+                            *(u32x2*)(patch + (r32 % PR) * EROW + (i * 32 + 8 * q4 + 4 * hh) * SZ) = *(const u32x2*)o;
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                constexpr int EPC = 8, CPR = Cfg::CPR, RPIe = 64 / CPR;
+                const int ch = lane % CPR, prow0 = lane / CPR;
+#pragma unroll
+                for (int it = 0; it < Cfg::NIT; ++it) {
+                    const int prow = it * RPIe + prow0;
+                    const int pr = __shfl(p, hp * PR + prow, 64);
+                    Chunk<T> c = ld_chunk<T>(patch + prow * EROW + ch * 16);
+                    const int cch = n0 + ch * EPC;
+                    const bool st = pr >= 0 && cch < a.ldy;
+                    // every lane stores (the tile's store count is part of the counted waits): masked rows go to the slack row
+                    char* dstp = st ? (char*)a.y + ((size_t)pr * a.ldy + cch) * SZ : ydump + (ch % (a.ldy / EPC)) * 16;
+                    st_chunk<T>(dstp, c);
+                    if (chk && st) {
 #pragma unroll
                         for (int e = 0; e < EPC; ++e)
                             bad |= (__float_as_uint(Elem<T>::to_f32(c.v[e])) & 0x7F800000u) == 0x7F800000u;
                     }
                 }
-            }
-            if (stats) {
-                frag_t ones;
+                if (stats) {
+                    frag_t ones;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ones[k] = (T)1.0f;
+                    for (int k = 0; k < 8; ++k) ones[k] = (T)1.0f;
 #pragma unroll
-                for (int i = 0; i < NCT; ++i) {
-                    f32x16 q1, q2;
+                    for (int i = 0; i < NCT; ++i) {
+                        f32x16 q1, q2;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) q1[q] = q2[q] = 0.f;
-                    const char* pb = patch + (8 * hh + qq) * EROW + (i * 32 + 16 * g1 + 4 * pp) * 2;
+                        for (int q = 0; q < 16; ++q) q1[q] = q2[q] = 0.f;
+                        const char* pb = patch + (8 * hh + qq) * EROW + (i * 32 + 16 * g1 + 4 * pp) * 2;
 #pragma unroll
-                    for (int kg = 0; kg < 2; ++kg) {
-                        const char* p0 = pb + kg * 16 * EROW;
-                        const frag_t f = tr_frag<T>(p0, p0 + 4 * EROW);
-                        mma32(q1, ones, f);
-                        mma32(q2, f, f);
+                        for (int kg = 0; kg < PR / 16; ++kg) {
+                            const char* p0 = pb + kg * 16 * EROW;
+                            const frag_t f = tr_frag<T>(p0, p0 + 4 * EROW);
+                            mma32(q1, ones, f);
+                            mma32(q2, f, f);
+                        }
+                        float dg = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) dg += (acc_row(q, hh) == r32) ? q2[q] : 0.f;
+                        S1w[i] += q1[0];
+                        S2w[i] += dg + __shfl_xor(dg, 32, 64);
                     }
-                    float dg = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) dg += (acc_row(q, hh) == r32) ? q2[q] : 0.f;
-                    S1w[i] += q1[0];
-                    S2w[i] += dg + __shfl_xor(dg, 32, 64);
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is rewritten by the next pass
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the patch is rewritten by the next sub-tile
         }
         if (chk && __any(bad) && lane == 0) atomicOr(a.nonfinite, 1u);
         if (stats) {
@@ -254,40 +275,23 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
         // ---- next tile: BP positions on
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
-            qm[j] += BP;
-            qm[j] = qm[j] >= R ? qm[j] - R : qm[j];
+            qm[j] = (qm[j] + BP) & (R - 1);
             pcol[j] += BP;
             while (pcol[j] >= pitch) { pcol[j] -= pitch; ++prow_[j]; }
             while (prow_[j] >= gm.rows_img) { prow_[j] -= gm.rows_img; ++pimg[j]; }
         }
     }
+    wait_vmcnt<0>();      // the ring's last fills must not outlive the workgroup's LDS
     if (stats) {
         __syncthreads();
-        if (tid < BC) {
-            double S1 = 0.0, S2 = 0.0;
-            float cnt = 0.f;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) {
-                const float* q = scr_all + k * (Cfg::SCR / 4);
-                S1 += (double)q[tid];
-                S2 += (double)q[BC + tid];
-                cnt += q[2 * BC];
-            }
-            const int co = n0 + tid;
-            if (co < a.ldy) {
-                const double md = cnt > 0.f ? S1 / (double)cnt : 0.0;
-                const double m2 = S2 - S1 * md;
-                a.part_mean[(size_t)(T1 - 1) * a.ldy + co] = (float)md;
-                a.part_m2[(size_t)(T1 - 1) * a.ldy + co] = (float)(m2 > 0.0 ? m2 : 0.0);
-            }
-            if (tid == 0 && blockIdx.y == 0) a.part_cnt[T1 - 1] = cnt;
-        }
+        if (tid < BC) emit_record(T1 - 1);
     }
 }
 
-template <typename T, int C, int NCT, int WP, int TP>
+template <typename T, int C, int NCT, int WP, int TP, int PR>
 static hipError_t rf_launch(const ConvArgs& a, hipStream_t s, int* bp, int* records) {
-    typedef RfCfg<T, C, NCT, WP, TP> Cfg;
+    typedef RfCfg<T, C, NCT, WP, TP, PR> Cfg;
+    if (a.ldy > 128 || a.ldy % 8 != 0) return hipErrorInvalidValue;   // masked stores land in y's 256-byte slack row
     RfGeom g{};
     g.pitch = a.W + 1;
     g.rows_img = a.H + 1;
@@ -299,7 +303,7 @@ static hipError_t rf_launch(const ConvArgs& a, hipStream_t s, int* bp, int* reco
     if (nblk > g.ntiles) nblk = g.ntiles;
     g.tiles_per_block = (g.ntiles + nblk - 1) / nblk;
     nblk = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
-    auto kern = conv_rf_kernel<T, C, NCT, WP, TP>;
+    auto kern = conv_rf_kernel<T, C, NCT, WP, TP, PR>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -313,7 +317,7 @@ static hipError_t rf_launch(const ConvArgs& a, hipStream_t s, int* bp, int* reco
 }
 
 // 0: not this form (16-bit launches only: row_bytes = input channels * 2).
-//   1: 32 -> 64 on 208-wide maps (forward of the second layer)      4 waves x 64 pixels x 64 couts, two workgroups per CU
+//   1: 32 -> 64 on 208-wide maps (forward of the second layer)      8 waves x 32 pixels x 64 couts, one workgroup per CU
 //   2: 64 -> 32 on 208-wide maps (its dgrad)                        8 waves x 32 pixels x 32 couts, one workgroup per CU
 int conv_rf_config(int taps, int W, int row_bytes, int Cout, int M) {
     static const bool off = getenv("Y2_NO_CONV_RF") != nullptr;
@@ -325,8 +329,8 @@ int conv_rf_config(int taps, int W, int row_bytes, int Cout, int M) {
 
 template <typename T>
 static hipError_t rf_T(int cfg, const ConvArgs& a, hipStream_t s, int* bp, int* records) {
-    if (cfg == 1) return rf_launch<T, 32, 2, 4, 2>(a, s, bp, records);
-    if (cfg == 2) return rf_launch<T, 64, 1, 8, 1>(a, s, bp, records);
+    if (cfg == 1) return rf_launch<T, 32, 2, 8, 1, 32>(a, s, bp, records);
+    if (cfg == 2) return rf_launch<T, 64, 1, 8, 1, 32>(a, s, bp, records);
     return hipErrorInvalidValue;
 }
 hipError_t launch_conv_rf(int dtype, const ConvArgs& a, hipStream_t s, int* bp, int* records) {
