@@ -342,9 +342,9 @@ static int dev_rule(int W, int Cout) {
 // 0: K-contiguous rows (conv_halo / conv_igemm); 1: 32-row MFMA fragments (conv_haloq, 32x32x16 tiles);
 // 2: 16-row fragments (conv_haloq on 16x16x32 tiles: the 384 x 128 tile class up to 26x26, +3-4 %).
 // row_bytes = input channels * element size of the launch (forward: cin_s, dgrad: ldy).
-int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M) {
+int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad) {
     if (taps != 9) return 0;
-    if (conv_rf_config(taps, W, row_bytes, Cout, M)) return 0;    // register-resident filters: fetched from K-contiguous rows
+    if (conv_rf_config(taps, W, row_bytes, Cout, M) || conv_rfn_config(taps, W, row_bytes, Cout, M, dgrad)) return 0;    // register-resident filters: fetched from K-contiguous rows
     if (!(W <= 26 || (W > 52 && W <= 104) || (W > 104 && Cout <= 32))) return 0;
     const bool narrow = ((M + 383) / 384) * ((Cout + 127) / 128) < 160;
     if (W <= 26 && Cout > 64 && M >= 384 * 8 && (row_bytes % 128) == 0 && !narrow) return 2;
@@ -359,14 +359,16 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M) {
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels, int* records) {
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
-    if (dtype != 0 && !a.bw_psum && conv_rf_config(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M)) {
+    const int rowb = a.C * (int)dtype_size(dtype);
+    if (dtype != 0 && !a.bw_psum &&
+        (conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M) || conv_rfn_config(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad))) {
         int rec = 0;
         e = launch_conv_rf(dtype, a, s, &bp, &rec);
         if (block_pixels) *block_pixels = bp;
         if (records) *records = rec;
         return e;
     }
-    if (conv_filter_layout(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M)) e = launch_conv_haloq(dtype, a, s, &bp);
+    if (conv_filter_layout(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad)) e = launch_conv_haloq(dtype, a, s, &bp);
 #ifdef Y2_DEV
     else if (a.taps == 9 && dtype == 1 && dev_rule(a.W, a.Cout) >= 0)
         e = launch_conv_halo_variant(dev_rule(a.W, a.Cout), a, s, &bp);

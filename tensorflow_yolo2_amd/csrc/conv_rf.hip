@@ -152,6 +152,7 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
         // groups tile-1 .. tile+1 have landed when all but the youngest group (and the stores behind it) are done
         if (tile == T0) wait_vmcnt<Cfg::PW>();
         else wait_vmcnt<Cfg::PW + Cfg::NST>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // the record of the previous tile, from the scratch its epilogue filled before this barrier
@@ -316,6 +317,265 @@ static hipError_t rf_launch(const ConvArgs& a, hipStream_t s, int* bp, int* reco
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Same scheme with the couts spread over WN waves (one 32-cout slice each, the pixel fragments shared through the
+// LDS ring) for the 128-cout layers: the workgroup's output tile goes through ONE [pixel][cout] patch so the stores
+// are whole 256-byte rows; statistics from the matrix pipe as above, each wave over its own columns and rows.
+// ---------------------------------------------------------------------------
+template <typename T, int C, int WP, int WN, int TP>
+struct RfnCfg {
+    static constexpr int SZ = sizeof(T);
+    static constexpr int NW = WP * WN, NT = NW * 64;
+    static constexpr int ROWB = C * SZ, LPR = ROWB / 16, RPI = 64 / LPR, RPB = 256 / ROWB;
+    static constexpr int G = C * SZ / 32, KGT = 9 * G;
+    static constexpr int BP = WP * TP * 32, BC = WN * 32;
+    static constexpr int NSLOT = 4, R = NSLOT * BP, RINGB = R * ROWB;
+    static constexpr int EROW = BC * SZ + 16, PATCHB = BP * EROW;
+    static constexpr int SCRF = WP * 2 * BC + 8;             // floats: per pixel-wave group S1[BC], S2[BC]; counts
+    static constexpr int LDS = RINGB + PATCHB + SCRF * 4 + BP * 4 + BC * 4;   // + row table + bias slice
+    static constexpr int PW = BP / RPI / NW;
+    static constexpr int CPR = BC / 8, NIT = BP * CPR / NT;
+    static constexpr int NST = NIT;
+    static_assert((R & (R - 1)) == 0, "ring rows: power of two");
+    static_assert(BP % (RPI * NW) == 0 && (BP * CPR) % NT == 0 && NT % CPR == 0, "even split over lanes");
+    static_assert(PW + NST < 63, "counted vmcnt");
+};
+
+template <typename T, int C, int WP, int WN, int TP>
+__global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, RfGeom gm) {
+    typedef RfnCfg<T, C, WP, WN, TP> Cfg;
+    typedef typename Elem<T>::frag frag_t;
+    constexpr int SZ = Cfg::SZ, NW = Cfg::NW, NT = Cfg::NT, ROWB = Cfg::ROWB, LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB;
+    constexpr int G = Cfg::G, KGT = Cfg::KGT, BP = Cfg::BP, BC = Cfg::BC, R = Cfg::R, EROW = Cfg::EROW, CPR = Cfg::CPR;
+    static_assert(SZ == 2, "16-bit element types");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const ring = smem;
+    char* const patch = smem + Cfg::RINGB;
+    float* const scr = (float*)(patch + Cfg::PATCHB);          // [WP][2][BC], then WP counts
+    int* const ptab = (int*)(scr + Cfg::SCRF);                 // NHWC pixel of every patch row, -1: border position
+    float* const biasl = (float*)(ptab + BP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w / WN, wn = w % WN;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int pitch = gm.pitch;
+
+    const int T0 = blockIdx.x * gm.tiles_per_block;
+    int T1 = T0 + gm.tiles_per_block;
+    if (T1 > gm.ntiles) T1 = gm.ntiles;
+    if (T0 >= T1) return;
+
+    const int n0 = blockIdx.y * BC;
+    frag_t wreg[KGT];
+    {
+        const char* wr = (const char*)a.w + (size_t)(n0 + wn * 32 + r32) * 9 * ROWB + hh * 16;
+#pragma unroll
+        for (int s = 0; s < KGT; ++s) wreg[s] = *(const frag_t*)(wr + s * 32);
+    }
+    if (tid < BC) biasl[tid] = (a.bias && n0 + tid < a.Cout) ? a.bias[n0 + tid] : 0.f;
+    wait_vmcnt<0>();
+
+    const int lrow = lane / LPR, lslot = lane % LPR;
+    auto stage = [&](int gi) {
+        const int slot = gi & (Cfg::NSLOT - 1);
+        char* dst = ring + slot * BP * ROWB;
+#pragma unroll
+        for (int k = 0; k < Cfg::PW; ++k) {
+            const int i = k * NW + w;
+            int row0 = gi * BP + i * RPI;
+            row0 = row0 < 0 ? 0 : (row0 + RPI > gm.qmax ? gm.qmax - RPI : row0);
+            const int rr = slot * BP + i * RPI + lrow;
+            glds16((const char*)a.x + (size_t)(row0 + lrow) * ROWB + ((lslot ^ ((rr / RPB) % LPR)) * 16), dst + i * 1024);
+        }
+    };
+
+    int qm[TP], pcol[TP], prow_[TP], pimg[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const int q = T0 * BP + (wp * TP + j) * 32 + r32;
+        qm[j] = q & (R - 1);
+        const int rowi = q / pitch;
+        pcol[j] = q - rowi * pitch;
+        pimg[j] = rowi / gm.rows_img;
+        prow_[j] = rowi - pimg[j] * gm.rows_img;
+    }
+    int sh[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sh[t] = (t / 3 - 1) * pitch + (t % 3 - 1);
+
+    const bool stats = a.part_mean != nullptr;
+    const bool chk = a.nonfinite != nullptr;
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+    char* const ydump = (char*)a.y + (size_t)a.M * a.ldy * SZ;
+
+    auto emit_record = [&](int rec) {     // tid < BC
+        double S1 = 0.0, S2 = 0.0;
+        float cnt = 0.f;
+#pragma unroll
+        for (int k = 0; k < WP; ++k) {
+            S1 += (double)scr[k * 2 * BC + tid];
+            S2 += (double)scr[k * 2 * BC + BC + tid];
+            cnt += scr[WP * 2 * BC + k];
+        }
+        const int co = n0 + tid;
+        if (co < a.ldy) {
+            const double md = cnt > 0.f ? S1 / (double)cnt : 0.0;
+            const double m2 = S2 - S1 * md;
+            a.part_mean[(size_t)rec * a.ldy + co] = (float)md;
+            a.part_m2[(size_t)rec * a.ldy + co] = (float)(m2 > 0.0 ? m2 : 0.0);
+        }
+        if (tid == 0 && blockIdx.y == 0) a.part_cnt[rec] = cnt;
+    };
+
+    stage(T0 - 1);
+    stage(T0);
+    stage(T0 + 1);
+    stage(T0 + 2);
+    for (int tile = T0; tile < T1; ++tile) {
+        if (tile == T0) wait_vmcnt<Cfg::PW>();
+        else wait_vmcnt<Cfg::PW + Cfg::NST>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (stats && tile > T0 && tid < BC) emit_record(tile - 1);
+
+        f32x16 acc[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
+        frag_t fa[2][TP];
+        auto load_frags = [&](int s, frag_t (&f)[TP]) {
+            const int t = s / G, g = s % G;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int rr = (qm[j] + sh[t]) & (R - 1);
+                f[j] = *(const frag_t*)(ring + rr * ROWB + (((2 * g + hh) ^ ((rr / RPB) % LPR)) * 16));
+            }
+        };
+        load_frags(0, fa[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KGT; ++s) {
+            if (s + 1 < KGT) load_frags(s + 1, fa[(s + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < TP; ++j) mma32(acc[j], wreg[s], fa[s & 1][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage(tile + 3);
+
+        // ---- the wave's 32-cout columns of its rows into the workgroup's patch
+        int cntw = 0;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const bool valid = pcol[j] >= 1 && prow_[j] >= 1 && pimg[j] < a.N;
+            const int p = valid ? (pimg[j] * a.H + prow_[j] - 1) * a.W + pcol[j] - 1 : -1;
+            const int row = (wp * TP + j) * 32 + r32;
+            if (wn == 0 && hh == 0) ptab[row] = p;
+            cntw += __popcll(__ballot(valid && hh == 0));
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                T o[4];
+                const f32x4 b4 = *(const f32x4*)(biasl + wn * 32 + 8 * q4 + 4 * hh);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = valid ? Elem<T>::from_f32(acc[j][4 * q4 + k] + b4[k]) : (T)0.f;
+                *(u32x2*)(patch + row * EROW + (wn * 32 + 8 * q4 + 4 * hh) * SZ) = *(const u32x2*)o;
+            }
+        }
+        if (stats) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // own columns, own rows: no barrier needed
+            frag_t ones;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ones[k] = (T)1.0f;
+            f32x16 q1, q2;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) q1[q] = q2[q] = 0.f;
+            const char* pb = patch + (wp * TP * 32 + 8 * hh + qq) * EROW + (wn * 32 + 16 * g1 + 4 * pp) * 2;
+#pragma unroll
+            for (int kg = 0; kg < TP * 2; ++kg) {
+                const char* p0 = pb + kg * 16 * EROW;
+                const frag_t f = tr_frag<T>(p0, p0 + 4 * EROW);
+                mma32(q1, ones, f);
+                mma32(q2, f, f);
+            }
+            float dg = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) dg += (acc_row(q, hh) == r32) ? q2[q] : 0.f;
+            dg += __shfl_xor(dg, 32, 64);
+            if (hh == 0) {
+                scr[wp * 2 * BC + wn * 32 + r32] = q1[0];
+                scr[wp * 2 * BC + BC + wn * 32 + r32] = dg;
+            }
+            if (wn == 0 && lane == 0) scr[WP * 2 * BC + wp] = (float)cntw;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // patch and row table complete
+        asm volatile("" ::: "memory");
+        // ---- whole rows out: lane = (row, 16-byte chunk), consecutive lanes along a row
+        bool bad = false;
+#pragma unroll
+        for (int it = 0; it < Cfg::NIT; ++it) {
+            const int idx = it * NT + tid;
+            const int row = idx / CPR, ch = idx % CPR;
+            const int pr = ptab[row];
+            Chunk<T> c = ld_chunk<T>(patch + row * EROW + ch * 16);
+            const int cch = n0 + ch * 8;
+            const bool st = pr >= 0 && cch < a.ldy;
+            char* dstp = st ? (char*)a.y + ((size_t)pr * a.ldy + cch) * SZ : ydump + (ch % (a.ldy / 8)) * 16;
+            st_chunk<T>(dstp, c);
+            if (chk && st) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    bad |= (__float_as_uint(Elem<T>::to_f32(c.v[e])) & 0x7F800000u) == 0x7F800000u;
+            }
+        }
+        if (chk && __any(bad) && lane == 0) atomicOr(a.nonfinite, 1u);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            qm[j] = (qm[j] + BP) & (R - 1);
+            pcol[j] += BP;
+            while (pcol[j] >= pitch) { pcol[j] -= pitch; ++prow_[j]; }
+            while (prow_[j] >= gm.rows_img) { prow_[j] -= gm.rows_img; ++pimg[j]; }
+        }
+    }
+    wait_vmcnt<0>();
+    if (stats) {
+        __syncthreads();
+        if (tid < BC) emit_record(T1 - 1);
+    }
+}
+
+template <typename T, int C, int WP, int WN, int TP>
+static hipError_t rfn_launch(const ConvArgs& a, hipStream_t s, int* bp, int* records) {
+    typedef RfnCfg<T, C, WP, WN, TP> Cfg;
+    if (a.ldy > 128 || a.ldy % 8 != 0) return hipErrorInvalidValue;
+    RfGeom g{};
+    g.pitch = a.W + 1;
+    g.rows_img = a.H + 1;
+    if (g.pitch + 1 > Cfg::BP) return hipErrorInvalidValue;     // the halo must stay inside the neighbouring groups
+    const long qtot = (long)a.N * g.rows_img * g.pitch;
+    g.ntiles = (int)((qtot + Cfg::BP - 1) / Cfg::BP);
+    g.qmax = (int)bbody_pixels(a.N, a.H, a.W);
+    const int nct = (a.Cout + Cfg::BC - 1) / Cfg::BC;
+    int nblk = (Cfg::LDS <= 80 * 1024 ? 512 : 256) / nct;
+    if (nblk > g.ntiles) nblk = g.ntiles;
+    g.tiles_per_block = (g.ntiles + nblk - 1) / nblk;
+    nblk = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
+    auto kern = conv_rfn_kernel<T, C, WP, WN, TP>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk, nct), dim3(Cfg::NT), Cfg::LDS, s, a, g);
+    if (bp) *bp = Cfg::BP;
+    if (records) *records = g.ntiles;
+    return hipGetLastError();
+}
+
 // 0: not this form (16-bit launches only: row_bytes = input channels * 2).
 //   1: 32 -> 64 on 208-wide maps (forward of the second layer)      8 waves x 32 pixels x 64 couts, one workgroup per CU
 //   2: 64 -> 32 on 208-wide maps (its dgrad)                        8 waves x 32 pixels x 32 couts, one workgroup per CU
@@ -326,15 +586,24 @@ int conv_rf_config(int taps, int W, int row_bytes, int Cout, int M) {
     if (row_bytes == 128 && Cout <= 32) return 2;
     return 0;
 }
+// the 128-cout form: dgrad launches with the fused BN-backward reduce are not covered yet (fwd = 1: forward)
+int conv_rfn_config(int taps, int W, int row_bytes, int Cout, int M, int dgrad) {
+    static const bool off = getenv("Y2_NO_CONV_RF") != nullptr;
+    if (off || dgrad || taps != 9 || W <= 52 || W + 2 > 128 || M < 128 * 1024) return 0;
+    if (row_bytes == 128 && Cout > 64 && Cout <= 128) return 3;
+    return 0;
+}
 
 template <typename T>
 static hipError_t rf_T(int cfg, const ConvArgs& a, hipStream_t s, int* bp, int* records) {
     if (cfg == 1) return rf_launch<T, 32, 2, 8, 1, 32>(a, s, bp, records);
     if (cfg == 2) return rf_launch<T, 64, 1, 8, 1, 32>(a, s, bp, records);
+    if (cfg == 3) return rfn_launch<T, 64, 2, 4, 2>(a, s, bp, records);
     return hipErrorInvalidValue;
 }
 hipError_t launch_conv_rf(int dtype, const ConvArgs& a, hipStream_t s, int* bp, int* records) {
-    const int cfg = conv_rf_config(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M);
+    int cfg = conv_rf_config(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M);
+    if (!cfg) cfg = conv_rfn_config(a.taps, a.W, a.C * (int)dtype_size(dtype), a.Cout, a.M, a.is_dgrad);
     if (dtype == 1) return rf_T<half_t>(cfg, a, s, bp, records);
     if (dtype == 2) return rf_T<bf16_t>(cfg, a, s, bp, records);
     return hipErrorInvalidValue;

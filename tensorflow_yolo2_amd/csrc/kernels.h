@@ -34,15 +34,17 @@ struct ConvArgs {
     // non-null (plain-store launches): set to 1 when a stored value is inf / NaN -- the early overflow guard of
     // y2_backward_adam / _momentum watches the dgrad that feeds the first layer this way
     unsigned* nonfinite = nullptr;
+    int is_dgrad = 0;       // the launch computes an input gradient (filters from the dgrad copy): kernel policy only
 };
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
 hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels); // + filters via registers
-int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M);   // filter layout launch_conv expects (0/1/2)
+int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad = 0);   // filter layout launch_conv expects (0/1/2)
 // policy; *records = rows of the BN partial list written (one per pixel tile)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels = nullptr, int* records = nullptr);
 // 3x3, filters resident in registers, persistent workgroups over the bordered pixel space (conv_rf.hip)
 int conv_rf_config(int taps, int W, int row_bytes, int Cout, int M);   // 0: not this form
+int conv_rfn_config(int taps, int W, int row_bytes, int Cout, int M, int dgrad);
 hipError_t launch_conv_rf(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels, int* records);
 int conv_block_pixels(int Cout);
 int conv_block_couts(int Cout);

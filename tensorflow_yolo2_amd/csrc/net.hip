@@ -471,7 +471,7 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
         p.taps = y.k * y.k; p.Cin = y.cin; p.Cout = y.cout; p.Cout_pad = y.cout_pad; p.Kc = y.cin_s;
         p.Cin_pad = y.cin_pad; p.Cdy = y.ldy;
         p.wf_frag = conv_filter_layout(p.taps, y.W, y.cin_s * (int)c->sz(), y.cout, y.M);   // forward launch
-        p.wd_frag = conv_filter_layout(p.taps, y.W, y.ldy * (int)c->sz(), y.cin, y.M);      // dgrad launch: Cout = cin
+        p.wd_frag = conv_filter_layout(p.taps, y.W, y.ldy * (int)c->sz(), y.cin, y.M, 1);   // dgrad launch: Cout = cin
         pack_layer_plan(p, nb, (int)c->sz());
         nb += p.wf_blocks + p.wd_blocks;
         p.opt_first = ntile;
@@ -812,6 +812,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
                 a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.ldy; a.M = y.M; a.Cout = y.cin; a.ldy = y.cin;
                 a.taps = y.k * y.k;
+                a.is_dgrad = 1;
                 int bp = 0;
                 const Layer& z = c->L[l > 0 ? l - 1 : 0];
                 // the BN-backward reduce of the layer below rides in this dgrad's epilogue (it needs that layer's
@@ -1161,10 +1162,11 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
     HIPCHK(launch_pack_act(dtype, dy, dyp, N, H, W, Cout, p.Cdy, s));
     if (dx) {
         HIPCHK(launch_pack_weights(dtype, w, nullptr, ws + p.wd, k * k, Cin, Cout, 0, 0, p.Cin_pad, p.Cdy,
-                                   conv_filter_layout(k * k, W, p.Cdy * (int)sz, p.Cin_p, N * H * W), s));
+                                   conv_filter_layout(k * k, W, p.Cdy * (int)sz, p.Cin_p, N * H * W, 1), s));
         ConvArgs a{};
         a.x = dyp; a.w = ws + p.wd; a.y = ws + p.dx;
         a.N = N; a.H = H; a.W = W; a.C = p.Cdy; a.M = N * H * W; a.Cout = p.Cin_p; a.ldy = p.Cin_p; a.taps = k * k;
+        a.is_dgrad = 1;
         HIPCHK(launch_conv(dtype, a, s));
         HIPCHK(launch_cast_to_f32(dtype, ws + p.dx, dx, (size_t)N * H * W, Cin, p.Cin_p, s));
     }
