@@ -20,7 +20,13 @@ static hipError_t run_variant(int variant, const ConvArgs& a, hipStream_t s, int
     return launch_conv_igemm_variant(variant, a, s, bp, bc);
 }
 }
+namespace y2 { hipError_t rf_read_stamps(unsigned long long* dst); }
 using namespace y2;
+
+extern "C" __attribute__((visibility("default"))) int y2dev_rf_stamps(unsigned long long* dst) {
+    return rf_read_stamps(dst) == hipSuccess ? 0 : -1;
+}
+
 
 extern "C" __attribute__((visibility("default"))) int y2dev_bench_wgrad(int N, int H, int W, int Cin, int Cout, int k, int variant, int splitk, int iters,
                                  float* ms_out) {

@@ -55,6 +55,18 @@ template <> struct Elem<bf16_t> {
     static Y2_DEV bf16_t from_f32(float v) { return (bf16_t)v; }
 };
 
+// two floats -> one dword of two T (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32: round to nearest even, as the scalar casts)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+template <typename T> Y2_DEV uint32_t pack2(float a, float b);
+template <> Y2_DEV uint32_t pack2<half_t>(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, f16x2));
+}
+template <> Y2_DEV uint32_t pack2<bf16_t>(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+
 // acc[rows(regs)][cols(lanes)] += A(rows x k) * B(k x cols)
 // C/D layout (all dtypes): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 Y2_DEV void mma32(f32x16& acc, const f32x4& a, const f32x4& b) {

@@ -27,6 +27,22 @@
 
 namespace y2 {
 
+#ifdef Y2_DEV
+// diagnostic build only: s_memtime deltas per phase of the 128-cout kernel (workgroup 0; [wave][phase])
+__device__ unsigned long long g_rf_stamps[8][8];
+#define RF_STAMP(k)                                                                                  \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        unsigned long long t_;                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        ph[k] += t_ - tlast;                                                                         \
+        tlast = t_;                                                                                  \
+    } while (0)
+#else
+#define RF_STAMP(k)
+#endif
+
 struct RfGeom {
     int pitch, rows_img;     // W + 1, H + 1
     int ntiles, tiles_per_block;
@@ -53,7 +69,7 @@ struct RfCfg {
     static_assert(PW + NST < 63, "counted vmcnt");
 };
 
-template <typename T, int C, int NCT, int WP, int TP, int PR>
+template <typename T, int C, int NCT, int WP, int TP, int PR, int PD>
 __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom gm) {
     typedef RfCfg<T, C, NCT, WP, TP, PR> Cfg;
     typedef typename Elem<T>::frag frag_t;
@@ -158,15 +174,22 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
         // the record of the previous tile, from the scratch its epilogue filled before this barrier
         if (stats && tile > T0 && tid < BC) emit_record(tile - 1);
 
+        // the accumulators start at the bias (rows = couts): no add in the epilogue
         f32x16 acc[NCT][TP];
 #pragma unroll
         for (int i = 0; i < NCT; ++i)
 #pragma unroll
-            for (int j = 0; j < TP; ++j)
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 b4 = *(const f32x4*)(biasl + i * 32 + 8 * q4 + 4 * hh);
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[i][j][4 * q4 + k] = b4[k];
+            }
 
-        frag_t fa[2][TP];
+        // pixel fragments PD steps ahead of their MFMAs (a step is only NCT * TP MFMAs long: one step of lead
+        // does not cover the LDS latency with two waves per SIMD)
+        frag_t fa[PD + 1][TP];
         auto load_frags = [&](int s, frag_t (&f)[TP]) {
             const int t = s / G, g = s % G;
 #pragma unroll
@@ -175,15 +198,16 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
                 f[j] = *(const frag_t*)(ring + rr * ROWB + (((2 * g + hh) ^ ((rr / RPB) % LPR)) * 16));
             }
         };
-        load_frags(0, fa[0]);
+#pragma unroll
+        for (int s = 0; s < PD; ++s) load_frags(s, fa[s]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KGT; ++s) {
-            if (s + 1 < KGT) load_frags(s + 1, fa[(s + 1) & 1]);
+            if (s + PD < KGT) load_frags(s + PD, fa[(s + PD) % (PD + 1)]);
 #pragma unroll
             for (int i = 0; i < NCT; ++i)
 #pragma unroll
-                for (int j = 0; j < TP; ++j) mma32(acc[i][j], wreg[i][s], fa[s & 1][j]);
+                for (int j = 0; j < TP; ++j) mma32(acc[i][j], wreg[i][s], fa[s % (PD + 1)][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_barrier();          // every wave is done with the oldest group: its slot takes group tile + 3
@@ -204,17 +228,22 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
 #pragma unroll
             for (int hp = 0; hp < 32 / PR; ++hp) {
                 if (PR == 32 || (r32 / PR) == hp) {
+                    // border positions are rare: everything is converted and written, then their rows are cleared
 #pragma unroll
                     for (int i = 0; i < NCT; ++i)
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {
-                            T o[4];
-                            const f32x4 b4 = *(const f32x4*)(biasl + i * 32 + 8 * q4 + 4 * hh);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                o[k] = valid ? Elem<T>::from_f32(acc[i][j][4 * q4 + k] + b4[k]) : (T)0.f;
-                            *(u32x2*)(patch + (r32 % PR) * EROW + (i * 32 + 8 * q4 + 4 * hh) * SZ) = *(const u32x2*)o;
+                            const u32x2 o = {pack2<T>(acc[i][j][4 * q4], acc[i][j][4 * q4 + 1]),
+                                             pack2<T>(acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3])};
+                            *(u32x2*)(patch + (r32 % PR) * EROW + (i * 32 + 8 * q4 + 4 * hh) * SZ) = o;
                         }
+                    if (!valid) {
+#pragma unroll
+                        for (int i = 0; i < NCT; ++i)
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4)
+                                *(u32x2*)(patch + (r32 % PR) * EROW + (i * 32 + 8 * q4 + 4 * hh) * SZ) = u32x2{0u, 0u};
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 constexpr int EPC = 8, CPR = Cfg::CPR, RPIe = 64 / CPR;
@@ -289,7 +318,7 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
     }
 }
 
-template <typename T, int C, int NCT, int WP, int TP, int PR>
+template <typename T, int C, int NCT, int WP, int TP, int PR, int PD>
 static hipError_t rf_launch(const ConvArgs& a, hipStream_t s, int* bp, int* records) {
     typedef RfCfg<T, C, NCT, WP, TP, PR> Cfg;
     if (a.ldy > 128 || a.ldy % 8 != 0) return hipErrorInvalidValue;   // masked stores land in y's 256-byte slack row
@@ -304,7 +333,7 @@ static hipError_t rf_launch(const ConvArgs& a, hipStream_t s, int* bp, int* reco
     if (nblk > g.ntiles) nblk = g.ntiles;
     g.tiles_per_block = (g.ntiles + nblk - 1) / nblk;
     nblk = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
-    auto kern = conv_rf_kernel<T, C, NCT, WP, TP, PR>;
+    auto kern = conv_rf_kernel<T, C, NCT, WP, TP, PR, PD>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -322,28 +351,30 @@ static hipError_t rf_launch(const ConvArgs& a, hipStream_t s, int* bp, int* reco
 // LDS ring) for the 128-cout layers: the workgroup's output tile goes through ONE [pixel][cout] patch so the stores
 // are whole 256-byte rows; statistics from the matrix pipe as above, each wave over its own columns and rows.
 // ---------------------------------------------------------------------------
-template <typename T, int C, int WP, int WN, int TP>
+// NSLOT ring slots of BP rows; AH = groups of halo on each side (1: pitch + 1 <= BP, 2: <= 2 BP); the NSLOT - 2 AH - 1
+// youngest groups may still be in flight when a tile starts
+template <typename T, int C, int WP, int WN, int TP, int NSLOT_, int AH_>
 struct RfnCfg {
     static constexpr int SZ = sizeof(T);
     static constexpr int NW = WP * WN, NT = NW * 64;
     static constexpr int ROWB = C * SZ, LPR = ROWB / 16, RPI = 64 / LPR, RPB = 256 / ROWB;
     static constexpr int G = C * SZ / 32, KGT = 9 * G;
     static constexpr int BP = WP * TP * 32, BC = WN * 32;
-    static constexpr int NSLOT = 4, R = NSLOT * BP, RINGB = R * ROWB;
+    static constexpr int NSLOT = NSLOT_, AH = AH_, DF = NSLOT - 2 * AH - 1, R = NSLOT * BP, RINGB = R * ROWB;
     static constexpr int EROW = BC * SZ + 16, PATCHB = BP * EROW;
     static constexpr int SCRF = WP * 2 * BC + 8;             // floats: per pixel-wave group S1[BC], S2[BC]; counts
     static constexpr int LDS = RINGB + PATCHB + SCRF * 4 + BP * 4 + BC * 4;   // + row table + bias slice
     static constexpr int PW = BP / RPI / NW;
     static constexpr int CPR = BC / 8, NIT = BP * CPR / NT;
     static constexpr int NST = NIT;
-    static_assert((R & (R - 1)) == 0, "ring rows: power of two");
+    static_assert(DF >= 1, "one group ahead at least");
     static_assert(BP % (RPI * NW) == 0 && (BP * CPR) % NT == 0 && NT % CPR == 0, "even split over lanes");
-    static_assert(PW + NST < 63, "counted vmcnt");
+    static_assert(DF * (PW + NST) < 63, "counted vmcnt");
 };
 
-template <typename T, int C, int WP, int WN, int TP>
+template <typename T, int C, int WP, int WN, int TP, int PD, int NSLOT, int AH>
 __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, RfGeom gm) {
-    typedef RfnCfg<T, C, WP, WN, TP> Cfg;
+    typedef RfnCfg<T, C, WP, WN, TP, NSLOT, AH> Cfg;
     typedef typename Elem<T>::frag frag_t;
     constexpr int SZ = Cfg::SZ, NW = Cfg::NW, NT = Cfg::NT, ROWB = Cfg::ROWB, LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB;
     constexpr int G = Cfg::G, KGT = Cfg::KGT, BP = Cfg::BP, BC = Cfg::BC, R = Cfg::R, EROW = Cfg::EROW, CPR = Cfg::CPR;
@@ -377,7 +408,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 
     const int lrow = lane / LPR, lslot = lane % LPR;
     auto stage = [&](int gi) {
-        const int slot = gi & (Cfg::NSLOT - 1);
+        const int slot = (gi + 4 * NSLOT) % NSLOT;
         char* dst = ring + slot * BP * ROWB;
 #pragma unroll
         for (int k = 0; k < Cfg::PW; ++k) {
@@ -393,7 +424,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         const int q = T0 * BP + (wp * TP + j) * 32 + r32;
-        qm[j] = q & (R - 1);
+        qm[j] = q % R;
         const int rowi = q / pitch;
         pcol[j] = q - rowi * pitch;
         pimg[j] = rowi / gm.rows_img;
@@ -427,44 +458,63 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         if (tid == 0 && blockIdx.y == 0) a.part_cnt[rec] = cnt;
     };
 
-    stage(T0 - 1);
-    stage(T0);
-    stage(T0 + 1);
-    stage(T0 + 2);
+#pragma unroll
+    for (int g = 0; g < NSLOT; ++g) stage(T0 - AH + g);
+#ifdef Y2_DEV
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+#endif
     for (int tile = T0; tile < T1; ++tile) {
-        if (tile == T0) wait_vmcnt<Cfg::PW>();
-        else wait_vmcnt<Cfg::PW + Cfg::NST>();
+        {   // groups tile - AH .. tile + AH have landed when all but the DF youngest (and the stores between them) are done
+            const int done = tile - T0;
+            wait_vmcnt_dyn(Cfg::DF * Cfg::PW + (done < Cfg::DF ? done : Cfg::DF) * Cfg::NST);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RF_STAMP(0);    // wait for the groups
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        RF_STAMP(1);    // barrier A
         if (stats && tile > T0 && tid < BC) emit_record(tile - 1);
 
-        f32x16 acc[TP];
+        f32x16 acc[TP];     // start at the bias (rows = couts)
 #pragma unroll
-        for (int j = 0; j < TP; ++j)
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 b4 = *(const f32x4*)(biasl + wn * 32 + 8 * q4 + 4 * hh);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-        frag_t fa[2][TP];
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[j][4 * q4 + k] = b4[k];
+        }
+        frag_t fa[PD + 1][TP];
         auto load_frags = [&](int s, frag_t (&f)[TP]) {
             const int t = s / G, g = s % G;
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                const int rr = (qm[j] + sh[t]) & (R - 1);
+                int rr = qm[j] + sh[t];
+                if ((R & (R - 1)) == 0) {
+                    rr &= R - 1;
+                } else {
+                    rr = rr < 0 ? rr + R : rr;
+                    rr = rr >= R ? rr - R : rr;
+                }
                 f[j] = *(const frag_t*)(ring + rr * ROWB + (((2 * g + hh) ^ ((rr / RPB) % LPR)) * 16));
             }
         };
-        load_frags(0, fa[0]);
+#pragma unroll
+        for (int s = 0; s < PD; ++s) load_frags(s, fa[s]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KGT; ++s) {
-            if (s + 1 < KGT) load_frags(s + 1, fa[(s + 1) & 1]);
+            if (s + PD < KGT) load_frags(s + PD, fa[(s + PD) % (PD + 1)]);
 #pragma unroll
-            for (int j = 0; j < TP; ++j) mma32(acc[j], wreg[s], fa[s & 1][j]);
+            for (int j = 0; j < TP; ++j) mma32(acc[j], wreg[s], fa[s % (PD + 1)][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        RF_STAMP(2);    // record + K loop
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        stage(tile + 3);
+        RF_STAMP(3);    // barrier B
+        stage(tile - AH + NSLOT);
 
         // ---- the wave's 32-cout columns of its rows into the workgroup's patch
         int cntw = 0;
@@ -477,11 +527,13 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
             cntw += __popcll(__ballot(valid && hh == 0));
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
-                T o[4];
-                const f32x4 b4 = *(const f32x4*)(biasl + wn * 32 + 8 * q4 + 4 * hh);
+                const u32x2 o = {pack2<T>(acc[j][4 * q4], acc[j][4 * q4 + 1]), pack2<T>(acc[j][4 * q4 + 2], acc[j][4 * q4 + 3])};
+                *(u32x2*)(patch + row * EROW + (wn * 32 + 8 * q4 + 4 * hh) * SZ) = o;
+            }
+            if (!valid) {     // border positions are rare: their rows are cleared after the fact
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = valid ? Elem<T>::from_f32(acc[j][4 * q4 + k] + b4[k]) : (T)0.f;
-                *(u32x2*)(patch + row * EROW + (wn * 32 + 8 * q4 + 4 * hh) * SZ) = *(const u32x2*)o;
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *(u32x2*)(patch + row * EROW + (wn * 32 + 8 * q4 + 4 * hh) * SZ) = u32x2{0u, 0u};
             }
         }
         if (stats) {
@@ -511,8 +563,10 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
             if (wn == 0 && lane == 0) scr[WP * 2 * BC + wp] = (float)cntw;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RF_STAMP(4);    // stage + patch + statistics
         __builtin_amdgcn_s_barrier();          // patch and row table complete
         asm volatile("" ::: "memory");
+        RF_STAMP(5);    // barrier C
         // ---- whole rows out: lane = (row, 16-byte chunk), consecutive lanes along a row
         bool bad = false;
 #pragma unroll
@@ -532,29 +586,41 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
             }
         }
         if (chk && __any(bad) && lane == 0) atomicOr(a.nonfinite, 1u);
+        RF_STAMP(6);    // sweep
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
-            qm[j] = (qm[j] + BP) & (R - 1);
+            qm[j] += BP;
+            qm[j] = qm[j] >= R ? qm[j] - R : qm[j];
             pcol[j] += BP;
             while (pcol[j] >= pitch) { pcol[j] -= pitch; ++prow_[j]; }
             while (prow_[j] >= gm.rows_img) { prow_[j] -= gm.rows_img; ++pimg[j]; }
         }
     }
     wait_vmcnt<0>();
+#ifdef Y2_DEV
+    if (blockIdx.x == 0 && lane == 0)
+        for (int k2 = 0; k2 < 8; ++k2) g_rf_stamps[w][k2] = ph[k2];
+#endif
     if (stats) {
         __syncthreads();
         if (tid < BC) emit_record(T1 - 1);
     }
 }
 
-template <typename T, int C, int WP, int WN, int TP>
+#ifdef Y2_DEV
+hipError_t rf_read_stamps(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
+
+template <typename T, int C, int WP, int WN, int TP, int PD, int NSLOT, int AH>
 static hipError_t rfn_launch(const ConvArgs& a, hipStream_t s, int* bp, int* records) {
-    typedef RfnCfg<T, C, WP, WN, TP> Cfg;
+    typedef RfnCfg<T, C, WP, WN, TP, NSLOT, AH> Cfg;
     if (a.ldy > 128 || a.ldy % 8 != 0) return hipErrorInvalidValue;
     RfGeom g{};
     g.pitch = a.W + 1;
     g.rows_img = a.H + 1;
-    if (g.pitch + 1 > Cfg::BP) return hipErrorInvalidValue;     // the halo must stay inside the neighbouring groups
+    if (g.pitch + 1 > Cfg::AH * Cfg::BP) return hipErrorInvalidValue;     // the halo must stay inside the AH neighbouring groups
     const long qtot = (long)a.N * g.rows_img * g.pitch;
     g.ntiles = (int)((qtot + Cfg::BP - 1) / Cfg::BP);
     g.qmax = (int)bbody_pixels(a.N, a.H, a.W);
@@ -563,7 +629,7 @@ static hipError_t rfn_launch(const ConvArgs& a, hipStream_t s, int* bp, int* rec
     if (nblk > g.ntiles) nblk = g.ntiles;
     g.tiles_per_block = (g.ntiles + nblk - 1) / nblk;
     nblk = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
-    auto kern = conv_rfn_kernel<T, C, WP, WN, TP>;
+    auto kern = conv_rfn_kernel<T, C, WP, WN, TP, PD, NSLOT, AH>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -596,9 +662,16 @@ int conv_rfn_config(int taps, int W, int row_bytes, int Cout, int M, int dgrad) 
 
 template <typename T>
 static hipError_t rf_T(int cfg, const ConvArgs& a, hipStream_t s, int* bp, int* records) {
-    if (cfg == 1) return rf_launch<T, 32, 2, 8, 1, 32>(a, s, bp, records);
-    if (cfg == 2) return rf_launch<T, 64, 1, 8, 1, 32>(a, s, bp, records);
-    if (cfg == 3) return rfn_launch<T, 64, 2, 4, 2>(a, s, bp, records);
+    // measured (scripts/profile_layers.py): the lead of the fragment reads (1..4 steps) does not matter -- two waves
+    // per SIMD cover each other's LDS latency; two 4-wave workgroups per CU (64-position tiles, six-slot ring) are 5 %
+    // SLOWER than one 8-wave workgroup on the 128-cout layers (a lone wave cannot keep the matrix pipe busy)
+    if (cfg == 1) return rf_launch<T, 32, 2, 8, 1, 32, 2>(a, s, bp, records);
+    if (cfg == 2) return rf_launch<T, 64, 1, 8, 1, 32, 3>(a, s, bp, records);
+#ifdef Y2_DEV
+    static const int alt = getenv("Y2DEV_RF_ALT") ? atoi(getenv("Y2DEV_RF_ALT")) : 0;
+    if (cfg == 3 && alt == 1) return rfn_launch<T, 64, 1, 4, 2, 2, 6, 2>(a, s, bp, records);
+#endif
+    if (cfg == 3) return rfn_launch<T, 64, 2, 4, 2, 2, 4, 1>(a, s, bp, records);
     return hipErrorInvalidValue;
 }
 hipError_t launch_conv_rf(int dtype, const ConvArgs& a, hipStream_t s, int* bp, int* records) {

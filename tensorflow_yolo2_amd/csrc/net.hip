@@ -49,7 +49,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
 
 static inline size_t part_rows_bound(int N, int H, int W, int cout) {
-    const size_t bp = conv_block_pixels(cout);
+    size_t bp = conv_block_pixels(cout);
+    if (bp > 64) bp = 64;     // the smallest pixel tile of any kernel form (conv_rf.hip: 64 bordered positions)
     return ((size_t)N * (H + 1) * (W + 1) + bp - 1) / bp;
 }
 
