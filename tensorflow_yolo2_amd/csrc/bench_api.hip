@@ -10,6 +10,7 @@ namespace y2 {
 hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc);
 hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp);
 hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s);
+hipError_t launch_wgrad_variant(int variant, const WgradArgs& a, hipStream_t s);
 hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp);
 static hipError_t run_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc) {
     if (variant == 100) return launch_conv(1, a, s, bp);   // the product policy
@@ -48,7 +49,11 @@ extern "C" __attribute__((visibility("default"))) int y2dev_bench_wgrad(int N, i
     g.x = (char*)x + (size_t)(W + 3) * Cin * sz; g.dy = (char*)dy + (size_t)(W + 3) * Cout * sz; g.dW = dw;
     g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = Cin; g.Cdy = Cout; g.Cout = Cout; g.taps = k * k;
     g.splitk = splitk; g.scale = 1.f;
-    auto run = [&]() { return variant >= 2 ? launch_wgrad9_variant(variant, g, 0) : (variant == 1 ? launch_wgrad9(1, g, 0) : launch_wgrad(1, g, 0)); };
+    g.xcd = getenv("Y2_XCD_WGRAD") ? atoi(getenv("Y2_XCD_WGRAD")) : 1;
+    auto run = [&]() {
+        if (variant >= 100) return launch_wgrad_variant(variant, g, 0);
+        return variant >= 2 ? launch_wgrad9_variant(variant, g, 0) : (variant == 1 ? launch_wgrad9(1, g, 0) : launch_wgrad(1, g, 0));
+    };
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 2; ++i)

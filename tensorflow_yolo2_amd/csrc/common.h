@@ -55,6 +55,15 @@ template <> struct Elem<bf16_t> {
     static Y2_DEV bf16_t from_f32(float v) { return (bf16_t)v; }
 };
 
+// XCD-aware block index (8 XCDs, each with its own L2; the dispatcher deals consecutive workgroups round-robin over
+// them): workgroup b -> logical index such that each XCD works on ONE contiguous run of the logical grid, so the
+// tiles that share an operand panel meet in one L2.  Bijective for any grid size.  mode 0: identity.
+Y2_DEV int xcd_block(int b, int n, int mode) {
+    if (!mode) return b;
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
 // two floats -> one dword of two T (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32: round to nearest even, as the scalar casts)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

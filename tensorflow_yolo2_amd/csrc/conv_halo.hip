@@ -48,7 +48,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_halo_kernel(ConvArgs a, int 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / WC, wc = w % WC;
     const int nCT = (a.Cout + BC - 1) / BC;
-    const int ct = blockIdx.x % nCT, pt = blockIdx.x / nCT;
+    const int bx = xcd_block(blockIdx.x, gridDim.x, a.xcd);
+    const int ct = bx % nCT, pt = bx / nCT;
     const int m0 = pt * BP, n0 = ct * BC;
     const int pitch = a.W + 1, hw = a.H * a.W;
     const int Ktot = 9 * a.C;
@@ -356,7 +357,11 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgra
 //   3x3, rows of 52                                        : conv_halo  (halo image + LDS filter ring)
 //   3x3 208-wide forward, and every 1x1                    : conv_igemm (per-tap staging)
 // *block_pixels receives the pixel-tile size used (= rows per BN partial record)
-hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels, int* records) {
+hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_pixels, int* records) {
+    // XCD-aware workgroup order: measured +1..4 % on every 3x3 layer up to 104x104 (common.h xcd_block)
+    static const int xcd_mode = getenv("Y2_XCD_CONV") ? atoi(getenv("Y2_XCD_CONV")) : 1;
+    ConvArgs a = a0;
+    a.xcd = xcd_mode;
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
     const int rowb = a.C * (int)dtype_size(dtype);

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / WC, wc = w % WC;
     const int nCT = (a.Cout + BC - 1) / BC;
-    const int ct = blockIdx.x % nCT, pt = blockIdx.x / nCT;
+    const int bx = xcd_block(blockIdx.x, gridDim.x, a.xcd);
+    const int ct = bx % nCT, pt = bx / nCT;
     const int m0 = pt * BP, n0 = ct * BC;
     const int pitch = a.W + 1, hw = a.H * a.W;
     const char* __restrict__ xg = (const char*)a.x;
@@ -179,7 +180,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / WC, wc = w % WC;
     const int nCT = (a.Cout + BC - 1) / BC;
-    const int ct = blockIdx.x % nCT, pt = blockIdx.x / nCT;
+    const int bx = xcd_block(blockIdx.x, gridDim.x, a.xcd);
+    const int ct = bx % nCT, pt = bx / nCT;
     const int m0 = pt * BP, n0 = ct * BC;
     const int pitch = a.W + 1, hw = a.H * a.W;
     const char* __restrict__ xg = (const char*)a.x;

@@ -34,6 +34,7 @@ struct ConvArgs {
     // non-null (plain-store launches): set to 1 when a stored value is inf / NaN -- the early overflow guard of
     // y2_backward_adam / _momentum watches the dgrad that feeds the first layer this way
     unsigned* nonfinite = nullptr;
+    int xcd = 0;            // XCD-aware workgroup order (common.h xcd_block)
     int is_dgrad = 0;       // the launch computes an input gradient (filters from the dgrad copy): kernel policy only
 };
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
@@ -156,6 +157,7 @@ struct WgradArgs {
     int taps;
     int splitk;
     float scale;
+    int xcd = 0;        // XCD-aware workgroup order (common.h xcd_block)
 };
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);       // one tap per block
 hipError_t launch_wgrad9(int dtype, const WgradArgs& a, hipStream_t s);      // 3x3: nine taps per block

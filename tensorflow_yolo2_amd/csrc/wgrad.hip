@@ -13,12 +13,17 @@
 // shifted reads in finite memory.
 // Split-K over blocks; partial tiles are accumulated into the fp32 HWIO
 // gradient with float atomics (256-byte row segments per wave-instruction).
+#include <stdlib.h>
 #include "common.h"
+#include "conv_epilogue.h"
 #include "kernels.h"
 
 namespace y2 {
 
-template <typename T, int WI, int WO, int TI, int TO>
+// NS = LDS stages: NS - 1 K steps of LDS-DMA stay in flight across the raw barrier (counted vmcnt).  The 1x1
+// layers run one workgroup per CU (split-K atomics cost as much as the reads): there a step's 16 MFMAs per wave
+// cannot cover the latency of the next step's fetch, and two stages leave the kernel latency-bound.
+template <typename T, int WI, int WO, int TI, int TO, int NS = 2>
 struct WgCfg {
     static constexpr int NW = WI * WO, NT = NW * 64;
     static constexpr int SZ = sizeof(T);
@@ -31,7 +36,7 @@ struct WgCfg {
     static constexpr int IPWX = NIX / NW, IPWY = NIY / NW;
     static constexpr int XS = BKP * ROWX, YS = BKP * ROWY;
     static constexpr int STAGE = XS + YS;
-    static constexpr int LDS = 2 * STAGE;
+    static constexpr int LDS = NS * STAGE;
     static_assert(NIX % NW == 0 && NIY % NW == 0, "staging must split evenly over waves");
 };
 
@@ -45,9 +50,9 @@ Y2_DEV int wg_swz(int row) {
     return 0;
 }
 
-template <typename T, int WI, int WO, int TI, int TO>
+template <typename T, int WI, int WO, int TI, int TO, int NS>
 __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
-    typedef WgCfg<T, WI, WO, TI, TO> Cfg;
+    typedef WgCfg<T, WI, WO, TI, TO, NS> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
     const int wi = w / WO, wo = w % WO;
 
     const int nIT = (a.Cin + BI - 1) / BI, nOT = (a.Cout + BO - 1) / BO;
-    int b = blockIdx.x;
+    int b = xcd_block(blockIdx.x, gridDim.x, a.xcd);
     const int ot = b % nOT; b /= nOT;
     const int it = b % nIT; b /= nIT;
     const int tap = b % a.taps;
@@ -118,13 +123,20 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
     // transposed-read lane constants (f16/bf16)
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
 
-    if (nsteps > 0) {
-        stage(0, 0);
-        __syncthreads();
-    }
+    constexpr int lps = Cfg::IPWX + Cfg::IPWY;     // LDS-DMA pieces per wave and stage
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nsteps) stage(s0, s0);
+    int cbuf = 0, ibuf = NS - 1;
     for (int st = 0; st < nsteps; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nsteps) stage(st + 1, buf ^ 1);
+        if (st + NS - 2 < nsteps) wait_vmcnt_dyn((NS - 2) * lps);
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();      // step st has landed for every wave; everyone is done with step st - 1's buffer
+        asm volatile("" ::: "memory");
+        if (st + NS - 1 < nsteps) stage(st + NS - 1, ibuf);
+        const int buf = cbuf;
+        cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
+        ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
         const char* xs = smem + buf * Cfg::STAGE;
         const char* ys = xs + Cfg::XS;
         if constexpr (SZ == 2) {
@@ -166,7 +178,6 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();
     }
     // ---- accumulate into fp32 HWIO gradient
 #pragma unroll
@@ -183,10 +194,11 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
         }
 }
 
-template <typename T, int WI, int WO, int TI, int TO>
-static hipError_t wg_launch(WgradArgs a, hipStream_t s) {
-    typedef WgCfg<T, WI, WO, TI, TO> Cfg;
-    auto kern = wgrad_kernel<T, WI, WO, TI, TO>;
+template <typename T, int WI, int WO, int TI, int TO, int NS = 2>
+static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
+    typedef WgCfg<T, WI, WO, TI, TO, NS> Cfg;
+    static_assert(Cfg::LDS <= 160 * 1024, "LDS");
+    auto kern = wgrad_kernel<T, WI, WO, TI, TO, NS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
@@ -200,7 +212,7 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s) {
     if (a.splitk <= 0) {
         // 1x1: the fp32 atomics of the split-K partial tiles cost as much as the streaming reads --
         // one block per CU is the measured optimum (scripts/bench_wgrad.py); 3x3 fallback: ~6 per CU
-        const int target = a.taps == 1 ? 256 : 1536;
+        const int target = a.taps == 1 ? target1 : 1536;
         long sk = (target + tiles - 1) / tiles;
         const long maxsk = (ksteps + 7) / 8;         // at least 8 K steps per block
         if (sk > maxsk) sk = maxsk;
@@ -226,6 +238,24 @@ static hipError_t wg_T(const WgradArgs& a, hipStream_t s) {
     if (bi == 32 && bo == 32) return wg_launch<T, 1, 1, 1, 1>(a, s);
     return hipErrorInvalidValue;
 }
+
+#ifdef Y2_DEV
+// development variants (f16, 128 x 128 tiles): stages x blocks target of the 1x1 form
+hipError_t launch_wgrad_variant(int variant, const WgradArgs& a, hipStream_t s) {
+    typedef half_t T;
+    switch (variant) {
+        case 100: return wg_launch<T, 2, 2, 2, 2, 2>(a, s, 256);
+        case 101: return wg_launch<T, 2, 2, 2, 2, 3>(a, s, 256);
+        case 102: return wg_launch<T, 2, 2, 2, 2, 4>(a, s, 256);
+        case 103: return wg_launch<T, 2, 2, 2, 2, 2>(a, s, 512);
+        case 104: return wg_launch<T, 2, 2, 2, 2, 3>(a, s, 512);
+        case 105: return wg_launch<T, 2, 2, 2, 2, 5>(a, s, 256);
+        case 106: return wg_launch<T, 2, 2, 2, 2, 4>(a, s, 128);
+        case 107: return wg_launch<T, 2, 2, 2, 2, 2>(a, s, 768);
+    }
+    return hipErrorInvalidValue;
+}
+#endif
 
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
     if (a.Cin % 32 != 0 || (a.Cin > 128 && a.Cin % 128 != 0)) return hipErrorInvalidValue;

@@ -59,7 +59,9 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
     const int pitch = a.W + 1;
 
     const int nIT = (a.Cin + BI - 1) / BI, nOT = (a.Cout + BO - 1) / BO;
-    int b = blockIdx.x;
+    // split-K launches: the slices of one K range meet in one XCD's L2 (measured +2..7 %); without a split the plain
+    // order already gives every XCD a fixed set of co tiles
+    int b = xcd_block(blockIdx.x, gridDim.x, a.xcd && a.splitk > 1);
     const int ot = b % nOT; b /= nOT;
     const int it = b % nIT;
     const int split = b / nIT;
@@ -269,7 +271,9 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
     if (lbase & maskB) __builtin_trap();   // the wrap ORs the column bits into the masked row offset
 
     const int nIT = (a.Cin + BI - 1) / BI, nOT = (a.Cout + BO - 1) / BO;
-    int b = blockIdx.x;
+    // split-K launches: the slices of one K range meet in one XCD's L2 (measured +2..7 %); without a split the plain
+    // order already gives every XCD a fixed set of co tiles
+    int b = xcd_block(blockIdx.x, gridDim.x, a.xcd && a.splitk > 1);
     const int ot = b % nOT; b /= nOT;
     const int it = b % nIT;
     const int split = b / nIT;
@@ -610,7 +614,10 @@ hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s)
 }
 #endif  // Y2_DEV
 
-hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a, hipStream_t s) {
+hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a0, hipStream_t s) {
+    static const int xcd_mode = getenv("Y2_XCD_WGRAD") ? atoi(getenv("Y2_XCD_WGRAD")) : 1;
+    WgradArgs a = a0;
+    a.xcd = xcd_mode;
     // measured per shape (scripts/bench_wgrad.py): nine-tap blocks win on every 3x3 layer
     if (a.taps == 9) {
         hipError_t e = launch_wgrad9(dtype, a, s);
