@@ -317,7 +317,7 @@ def main():
         # forward, dgrad and wgrad launches of layers 1..L-1 (the 3 -> 32 first layer has its own kernels)
         igemm_flops = fwd_igemm * (1.0 if args.forward_only else 3.0)
         roof = {"bound": "mfma", "achieved": None, "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                "frac": None, "traffic": None, "kernel": "MFMA implicit-GEMM convolution: forward, dgrad and wgrad launches (conv_haloq / conv_halo / conv_igemm / wgrad9 / wgrad); time = union of the launch intervals"}
+                "frac": None, "traffic": None, "kernel": "MFMA implicit-GEMM convolution: forward, dgrad and wgrad launches (conv_haloq / conv_halo / conv_igemm / conv_rf / wgrad9 / wgrad); time = union of the launch intervals"}
         kernels = None
         if prof is not None:
             if busy is not None and busy[1] > 0:      # the bracketed steps of the timed region
@@ -341,7 +341,8 @@ def main():
         # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction), bytes per launch
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
-            sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k or "wgrad9" in k or "wgrad_kernel" in k]
+            sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k or "conv_rf" in k or
+                   "wgrad9" in k or "wgrad_kernel" in k]
             nl = sum(v["launches"] for v in sel)
             if nl and not args.forward_only and bs == 64 and size == 416 and args.dtype == "f16":
                 roof["traffic"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in sel) / nl

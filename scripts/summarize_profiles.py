@@ -72,8 +72,8 @@ def pmc(fd, wd, out):
     print("wrote", out, len(res), "kernels")
 
 
-MFMA_KERNELS = ("conv_haloq", "conv_halo_kernel", "conv_igemm_kernel", "wgrad9", "wgrad_kernel", "gemm1x1",
-                "conv_big", "wgrad1x1")
+MFMA_KERNELS = ("conv_haloq", "conv_halo_kernel", "conv_igemm_kernel", "conv_rf_kernel", "conv_rfn_kernel", "wgrad9",
+                "wgrad_kernel", "gemm1x1", "conv_big", "wgrad1x1")
 
 
 def is_mfma_conv(name):

@@ -10,6 +10,7 @@ src/yolo2_nets/darknet.py builds, and the autodiff graph of
 src/pascal/pascal_train_darknet.py:49-51.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -372,7 +373,7 @@ class AdamOptimizer:
         of the layers above the first one overlapped with the first layer's gradient kernel (single-process
         training; the data-parallel trainers reduce between backward() and step())."""
         n = self.net
-        if not (self.fused_pack and n.training):
+        if not (self.fused_pack and n.training) or os.environ.get("Y2_NO_FUSED_TRAIN_OP"):
             n.backward(dout)
             return self.step(grad_mult)
         self.t += 1
@@ -429,7 +430,7 @@ class MomentumOptimizer:
     def backward_step(self, dout, grad_mult=1.0):
         """see AdamOptimizer.backward_step"""
         n = self.net
-        if not (self.fused_pack and n.training):
+        if not (self.fused_pack and n.training) or os.environ.get("Y2_NO_FUSED_TRAIN_OP"):
             n.backward(dout)
             return self.step(grad_mult)
         ctrl = _ptr(self.scaler.ctrl) if self.guard else C.c_void_p(0)
