@@ -158,10 +158,18 @@ struct WgradArgs {
     int splitk;
     float scale;
     int xcd = 0;        // XCD-aware workgroup order (common.h xcd_block)
+    // split-K partial tiles: with a slab of at least splitk * taps*Cin*Cout floats the splits store their partials
+    // there (plain stores) and wgrad_split_finish sums them in a fixed order into dW -- deterministic, and no
+    // zero-fill of dW; without one they are added into a zeroed dW with float atomics (≈1.3 TB/s chip-wide)
+    float* slab = nullptr;
+    size_t slab_floats = 0;
 };
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);       // one tap per block
 hipError_t launch_wgrad9(int dtype, const WgradArgs& a, hipStream_t s);      // 3x3: nine taps per block
 hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a, hipStream_t s);
+// around a split-K launch (a.splitk resolved): chooses slab or atomics (zero-filling dW for the latter) / sums the slab
+hipError_t wgrad_split_prepare(WgradArgs& a, hipStream_t s);
+hipError_t wgrad_split_finish(const WgradArgs& a, hipStream_t s);
 
 // ---- packing
 hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H, int W, hipStream_t s);

@@ -108,7 +108,8 @@ struct y2_ctx {
     // pooled 3-channel first layer, training: the linear form of its backward pass (conv1_wgrad.hip) -- its conv
     // output is never stored
     bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
-    size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0;
+    size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0, o_slab = 0;
+    size_t slab_floats = 0;     // split-K partial tiles of the weight gradients (WgradArgs::slab)
     int n_chkranges = 0, n_smallranges = 0, opt_tile_blocks = 0;
     // both range tables list the layers above the first one first: the optimizer step fused into the backward pass
     // (y2_backward_adam / _momentum) checks and updates that part while the first layer's gradient is still
@@ -233,6 +234,9 @@ static void plan(y2_ctx* c) {
         psum_floats = std::max(psum_floats, rows * 2 * (size_t)c->L[l - 1].ldy);
     }
     c->o_psum = take(psum_floats * sizeof(float));
+    // split-K partials of one weight-gradient launch: at most ~1,000 workgroups x one 64 x 32 x 9 (or 128 x 128) tile
+    c->slab_floats = (size_t)1024 * 18432;
+    c->o_slab = take(c->slab_floats * sizeof(float));
     c->o_dA0 = take(max_dA * sz + 256);
     c->o_dA1 = take(max_dA * sz + 256);
     c->o_dh32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
@@ -697,8 +701,8 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         c->dA_cur = 0;
         PROF(CAT_MISC);
         HIPCHK(launch_convert_grad(c->dtype, src, dA[0], y.M, y.cout, y.ldy, c->grad_scale, s));
-        // weight/bias gradients are accumulated with atomics: clear the whole flat buffer once per step
-        HIPCHK(hipMemsetAsync(c->grads, 0, c->nparams * sizeof(float), s));
+        // every gradient element is written with a plain store each step (split-K partials go through the slab
+        // and a fixed-order sum: wgrad.hip); the kernels that still add with atomics zero their own target
     }
     float* psum = (float*)(c->ws + c->o_psum);
     bool forked = false;
@@ -788,17 +792,20 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             g.scale = b.scale; g.shift = b.shift; g.coef = b.coef;
             g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.inv_grad_scale = inv_gs;
+            HIPCHK(hipMemsetAsync(g.dW, 0, (size_t)27 * y.cout * sizeof(float), s));     // atomics
             { PROF(CAT_CONV1_WGRAD); HIPCHK(launch_conv1_wgrad_fused(c->dtype, g, s)); }
         } else if (y.first3) {
             Conv1WgradArgs g{};
             g.x4 = xin; g.dy = dyp; g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M; g.scale = inv_gs;
+            HIPCHK(hipMemsetAsync(g.dW, 0, (size_t)27 * y.cout * sizeof(float), s));     // atomics
             { PROF(CAT_CONV1_WGRAD); HIPCHK(launch_conv1_wgrad(c->dtype, g, s)); }
         } else {
             WgradArgs g{};
             g.x = xin; g.dy = dyp; g.dW = c->grads + y.pW;
             g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M;
             g.Cin = y.cin_s; g.Cdy = y.ldy; g.Cout = y.cout; g.taps = y.k * y.k; g.splitk = 0; g.scale = inv_gs;
+            g.slab = (float*)(c->ws + c->o_slab); g.slab_floats = c->slab_floats;
             hipStream_t ws_ = s;
             if (c->overlap_wgrad && l > 0 && c->prof != 1) {
                 // fork: the filter gradient only reads x and dY; it fills the bubbles of the dgrad beside it

@@ -188,8 +188,12 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int ci = ci0 + (wi * TI + i) * 32 + acc_row(q, hh);
-                if (ci < a.Cin && co < a.Cout)
-                    atomicAdd(a.dW + ((size_t)tap * a.Cin + ci) * a.Cout + co, acc[i][j][q] * a.scale);
+                if (ci < a.Cin && co < a.Cout) {
+                    const size_t o = ((size_t)tap * a.Cin + ci) * a.Cout + co;
+                    if (a.splitk == 1) a.dW[o] = acc[i][j][q] * a.scale;
+                    else if (a.slab) a.slab[(size_t)split * a.taps * a.Cin * a.Cout + o] = acc[i][j][q];
+                    else atomicAdd(a.dW + o, acc[i][j][q] * a.scale);
+                }
             }
         }
 }
@@ -219,8 +223,11 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
         if (sk < 1) sk = 1;
         a.splitk = (int)sk;
     }
+    hipError_t e = wgrad_split_prepare(a, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS, s, a);
-    return hipGetLastError();
+    e = hipGetLastError();
+    return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 
 template <typename T>
@@ -237,6 +244,62 @@ static hipError_t wg_T(const WgradArgs& a, hipStream_t s) {
     if (bi == 32 && bo == 64) return wg_launch<T, 1, 2, 1, 1>(a, s);
     if (bi == 32 && bo == 32) return wg_launch<T, 1, 1, 1, 1>(a, s);
     return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// Split-K partials: slab[split][taps*Cin*Cout] -> dW = scale * sum over the splits, in split order (deterministic).
+// SL = 1: a thread owns four consecutive elements and walks the splits (few splits, large dW);
+// SL = 16: 16 lanes share a column group and take every 16th split (hundreds of splits of a tiny dW), LDS add.
+// ---------------------------------------------------------------------------
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, size_t n4,
+                                                           int sk, size_t stride4, float scale) {
+    constexpr int COLS = 256 / SL;
+    __shared__ f32x4 red[SL > 1 ? 256 : 1];
+    const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+    const size_t i = (size_t)blockIdx.x * COLS + col;
+    const f32x4* p = (const f32x4*)slab;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+        int s = sl;
+        for (; s + 3 * SL < sk; s += 4 * SL) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += p[(size_t)(s + u * SL) * stride4 + i];
+        }
+        for (; s < sk; s += SL) acc[0] += p[(size_t)s * stride4 + i];
+    }
+    f32x4 t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    if (SL > 1) {
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (sl == 0) {
+#pragma unroll
+            for (int k = 1; k < SL; ++k) t += red[k * COLS + col];
+        }
+    }
+    if (sl == 0 && i < n4) ((f32x4*)dW)[i] = t * scale;
+}
+
+hipError_t wgrad_split_prepare(WgradArgs& a, hipStream_t s) {
+    if (a.splitk <= 1) return hipSuccess;
+    const size_t n = (size_t)a.taps * a.Cin * a.Cout;
+    if (a.slab && (n & 3) == 0 && (size_t)a.splitk * n <= a.slab_floats) return hipSuccess;
+    a.slab = nullptr;      // atomics into a zeroed dW
+    return hipMemsetAsync(a.dW, 0, n * sizeof(float), s);
+}
+hipError_t wgrad_split_finish(const WgradArgs& a, hipStream_t s) {
+    if (a.splitk <= 1 || !a.slab) return hipSuccess;
+    const size_t n4 = (size_t)a.taps * a.Cin * a.Cout / 4;
+    if (a.splitk <= 8) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.slab, a.dW, n4,
+                           a.splitk, n4, a.scale);
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, a.slab, a.dW, n4,
+                           a.splitk, n4, a.scale);
+    }
+    return hipGetLastError();
 }
 
 #ifdef Y2_DEV

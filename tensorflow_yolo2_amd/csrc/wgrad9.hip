@@ -214,9 +214,10 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
             for (int q = 0; q < 16; ++q) {
                 const int ci = ci0 + wi * 32 + acc_row(q, hh);
                 if (ci < a.Cin) {
-                    float* dst = a.dW + ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
-                    if (a.splitk == 1) *dst = acc[t][j][q] * a.scale;
-                    else atomicAdd(dst, acc[t][j][q] * a.scale);
+                    const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
+                    if (a.splitk == 1) a.dW[o] = acc[t][j][q] * a.scale;
+                    else if (a.slab) a.slab[(size_t)split * 9 * a.Cin * a.Cout + o] = acc[t][j][q];
+                    else atomicAdd(a.dW + o, acc[t][j][q] * a.scale);
                 }
             }
     }
@@ -390,9 +391,10 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
             for (int q = 0; q < 16; ++q) {
                 const int ci = ci0 + wi * 32 + acc_row(q, hh);
                 if (ci < a.Cin) {
-                    float* dst = a.dW + ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
-                    if (a.splitk == 1) *dst = acc[t][q] * a.scale;
-                    else atomicAdd(dst, acc[t][q] * a.scale);
+                    const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
+                    if (a.splitk == 1) a.dW[o] = acc[t][q] * a.scale;
+                    else if (a.slab) a.slab[(size_t)split * 9 * a.Cin * a.Cout + o] = acc[t][q];
+                    else atomicAdd(a.dW + o, acc[t][q] * a.scale);
                 }
             }
     }
@@ -447,8 +449,11 @@ static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0)
         if (e != hipSuccess) return e;
         attr = lds;
     }
+    hipError_t e = wgrad_split_prepare(a, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), lds, s, a, lgR, G);
-    return hipGetLastError();
+    e = hipGetLastError();
+    return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 
 template <typename T, int WI, int WO, int NS, int TG = 1, int KS = 1, int CW = 1>
@@ -487,8 +492,11 @@ static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s, int blocks_target = 
         if (e != hipSuccess) return e;
         attr = lds;
     }
+    hipError_t e = wgrad_split_prepare(a, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), lds, s, a, wrows);
-    return hipGetLastError();
+    e = hipGetLastError();
+    return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 // deepest ring that fits (4 stages where the window is small)
 template <typename T, int WI, int WO>

@@ -341,6 +341,26 @@ def test_fused_train_op_equals_backward_then_step(dtype):
     assert torch.equal(a.net.params, b.net.params) and torch.equal(ma.accum, mb.accum)
 
 
+def test_backward_is_bit_reproducible():
+    """split-K partial tiles of the weight gradients go through a slab and a fixed-order sum (no float atomics on the
+    C4 path), the first layer's partials are added in a fixed order: two backward passes over the same forward state
+    give bit-identical gradient buffers"""
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.trainer import DetectorTrainer
+    n, size = 8, 416
+    tr = DetectorTrainer(n, size, dtype="f16", seed=2)
+    x = dev(synthetic.images(n, size, 5))
+    lab = dev(synthetic.det_labels(n, size, size // 32, 6))
+    _, (loss, ious, mask, dnet) = tr.forward_loss(x, lab, True, True)
+    tr.net.backward(dnet)
+    g0 = tr.net.grads.clone()
+    tr.net.grads.fill_(float("nan"))            # nothing may rely on a pre-zeroed buffer either
+    tr.net.backward(dnet)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.net.grads).all()
+    assert torch.equal(tr.net.grads, g0)
+
+
 # ---------------------------------------------------------------- snapshots with optimizer slots
 def test_snapshot_restores_adam_slots_and_rejects_shape_mismatch(tmp_path):
     from tensorflow_yolo2_amd import engine as E
