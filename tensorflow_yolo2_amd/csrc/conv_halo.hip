@@ -365,8 +365,8 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
     const int rowb = a.C * (int)dtype_size(dtype);
-    if (dtype != 0 && !a.bw_psum &&
-        (conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M) || conv_rfn_config(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad))) {
+    if (dtype != 0 && ((!a.bw_psum && conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M)) ||
+                       conv_rfn_config(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad))) {
         int rec = 0;
         e = launch_conv_rf(dtype, a, s, &bp, &rec);
         if (block_pixels) *block_pixels = bp;

@@ -362,8 +362,11 @@ struct RfnCfg {
     static constexpr int BP = WP * TP * 32, BC = WN * 32;
     static constexpr int NSLOT = NSLOT_, AH = AH_, DF = NSLOT - 2 * AH - 1, R = NSLOT * BP, RINGB = R * ROWB;
     static constexpr int EROW = BC * SZ + 16, PATCHB = BP * EROW;
-    static constexpr int SCRF = WP * 2 * BC + 8;             // floats: per pixel-wave group S1[BC], S2[BC]; counts
+    static constexpr int SCRF = NW * 2 * BC + 8;             // floats: statistics: per pixel-wave group S1[BC], S2[BC], counts;
+                                                             // dgrad with the fused BN-backward reduce: per wave S1[BC], S2[BC]
+    static constexpr int YTILE = BP * BC * SZ;               // that mode's tile of the layer below's conv output
     static constexpr int LDS = RINGB + PATCHB + SCRF * 4 + BP * 4 + BC * 4;   // + row table + bias slice
+    static constexpr int LDS_BW = LDS + YTILE + 2 * BC * 4;
     static constexpr int PW = BP / RPI / NW;
     static constexpr int CPR = BC / 8, NIT = BP * CPR / NT;
     static constexpr int NST = NIT;
@@ -372,7 +375,7 @@ struct RfnCfg {
     static_assert(DF * (PW + NST) < 63, "counted vmcnt");
 };
 
-template <typename T, int C, int WP, int WN, int TP, int PD, int NSLOT, int AH>
+template <typename T, int C, int WP, int WN, int TP, int PD, int NSLOT, int AH, bool BW>
 __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, RfGeom gm) {
     typedef RfnCfg<T, C, WP, WN, TP, NSLOT, AH> Cfg;
     typedef typename Elem<T>::frag frag_t;
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
     float* const scr = (float*)(patch + Cfg::PATCHB);          // [WP][2][BC], then WP counts
     int* const ptab = (int*)(scr + Cfg::SCRF);                 // NHWC pixel of every patch row, -1: border position
     float* const biasl = (float*)(ptab + BP);
+    char* const ybuf = (char*)(biasl + BC);                    // bw mode only (the launcher sizes the LDS for it)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / WN, wn = w % WN;
@@ -434,11 +438,34 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 #pragma unroll
     for (int t = 0; t < 9; ++t) sh[t] = (t / 3 - 1) * pitch + (t % 3 - 1);
 
-    const bool stats = a.part_mean != nullptr;
+    const bool stats = !BW && a.part_mean != nullptr;
     const bool chk = a.nonfinite != nullptr;
+    constexpr bool bw = BW;                    // dgrad: BN-backward reduce of the layer below (ConvArgs::bw_*)
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+    // bw mode: scale / shift of the layer below wait in LDS (behind the y tile), registers are for the filters
+    float* const bwtab = (float*)(ybuf + Cfg::YTILE);
+    if (bw) {
+        if (tid < BC) {
+            bwtab[tid] = n0 + tid < a.ldy ? a.bw_scale[n0 + tid] : 0.f;
+            bwtab[BC + tid] = n0 + tid < a.ldy ? a.bw_shift[n0 + tid] : 0.f;
+        }
+        wait_vmcnt<0>();
+    }
     char* const ydump = (char*)a.y + (size_t)a.M * a.ldy * SZ;
 
+    auto emit_bw = [&](int rec) {         // tid < BC: the tile's S1 / S2 from the waves' sums, fixed order
+        float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            S1 += scr[k * 2 * BC + tid];
+            S2 += scr[k * 2 * BC + BC + tid];
+        }
+        const int co = n0 + tid;
+        if (co < a.ldy) {
+            a.bw_psum[((size_t)rec * 2 + 0) * a.ldy + co] = S1;
+            a.bw_psum[((size_t)rec * 2 + 1) * a.ldy + co] = S2;
+        }
+    };
     auto emit_record = [&](int rec) {     // tid < BC
         double S1 = 0.0, S2 = 0.0;
         float cnt = 0.f;
@@ -475,6 +502,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         asm volatile("" ::: "memory");
         RF_STAMP(1);    // barrier A
         if (stats && tile > T0 && tid < BC) emit_record(tile - 1);
+        if (bw && tile > T0 && tid < BC) emit_bw(tile - 1);
 
         f32x16 acc[TP];     // start at the bias (rows = couts)
 #pragma unroll
@@ -514,7 +542,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         RF_STAMP(3);    // barrier B
-        stage(tile - AH + NSLOT);
+        if (!bw) stage(tile - AH + NSLOT);
 
         // ---- the wave's 32-cout columns of its rows into the workgroup's patch
         int cntw = 0;
@@ -569,20 +597,82 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         RF_STAMP(5);    // barrier C
         // ---- whole rows out: lane = (row, 16-byte chunk), consecutive lanes along a row
         bool bad = false;
+        if (!bw) {
 #pragma unroll
-        for (int it = 0; it < Cfg::NIT; ++it) {
-            const int idx = it * NT + tid;
-            const int row = idx / CPR, ch = idx % CPR;
-            const int pr = ptab[row];
-            Chunk<T> c = ld_chunk<T>(patch + row * EROW + ch * 16);
-            const int cch = n0 + ch * 8;
-            const bool st = pr >= 0 && cch < a.ldy;
-            char* dstp = st ? (char*)a.y + ((size_t)pr * a.ldy + cch) * SZ : ydump + (ch % (a.ldy / 8)) * 16;
-            st_chunk<T>(dstp, c);
-            if (chk && st) {
+            for (int it = 0; it < Cfg::NIT; ++it) {
+                const int idx = it * NT + tid;
+                const int row = idx / CPR, ch = idx % CPR;
+                const int pr = ptab[row];
+                Chunk<T> c = ld_chunk<T>(patch + row * EROW + ch * 16);
+                const int cch = n0 + ch * 8;
+                const bool st = pr >= 0 && cch < a.ldy;
+                char* dstp = st ? (char*)a.y + ((size_t)pr * a.ldy + cch) * SZ : ydump + (ch % (a.ldy / 8)) * 16;
+                st_chunk<T>(dstp, c);
+                if (chk && st) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    bad |= (__float_as_uint(Elem<T>::to_f32(c.v[e])) & 0x7F800000u) == 0x7F800000u;
+                    for (int e = 0; e < 8; ++e)
+                        bad |= (__float_as_uint(Elem<T>::to_f32(c.v[e])) & 0x7F800000u) == 0x7F800000u;
+                }
+            }
+        } else {
+            // the layer below's conv output at this tile's pixels comes in by LDS-DMA too (an ordinary load would make
+            // the compiler drain the ring's DMA at its first use): issued BEFORE the ring's next group, waited for with
+            // a count that leaves that group in flight; a wave reads back only its own pieces
+            int prv[Cfg::NIT];
+#pragma unroll
+            for (int it = 0; it < Cfg::NIT; ++it) {
+                const int idx = it * NT + tid;
+                prv[it] = ptab[idx / CPR];
+                const int cch = n0 + (idx % CPR) * 8;
+                const size_t src = ((size_t)(prv[it] < 0 ? 0 : prv[it]) * a.ldy + (cch < a.ldy ? cch : 0)) * SZ;
+                glds16((const char*)a.bw_y + src, ybuf + (it * NT + w * 64) * 16);
+            }
+            stage(tile - AH + NSLOT);
+            wait_vmcnt<Cfg::PW>();
+            float s1[8], s2[8], bsc[8], bsh[8];     // this lane's chunk column is fixed (NT % CPR == 0)
+#pragma unroll
+            for (int e = 0; e < 8; e += 4) {
+                const f32x4 v1 = *(const f32x4*)(bwtab + (tid % CPR) * 8 + e), v2 = *(const f32x4*)(bwtab + BC + (tid % CPR) * 8 + e);
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) { bsc[e + k2] = v1[k2]; bsh[e + k2] = v2[k2]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+            for (int it = 0; it < Cfg::NIT; ++it) {
+                const int idx = it * NT + tid;
+                const int row = idx / CPR, ch = idx % CPR;
+                const int pr = prv[it];
+                Chunk<T> c = ld_chunk<T>(patch + row * EROW + ch * 16);
+                Chunk<T> yv = ld_chunk<T>(ybuf + idx * 16);
+                const int cch = n0 + ch * 8;
+                const bool st = pr >= 0 && cch < a.ldy;
+                char* dstp = st ? (char*)a.y + ((size_t)pr * a.ldy + cch) * SZ : ydump + (ch % (a.ldy / 8)) * 16;
+                st_chunk<T>(dstp, c);
+                if (st) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float yf = Elem<T>::to_f32(yv.v[e]);
+                        const float g = Elem<T>::to_f32(c.v[e]) * leaky01_slope(fmaf(yf, bsc[e], bsh[e]));
+                        s1[e] += g;
+                        s2[e] = fmaf(g, yf, s2[e]);
+                    }
+                }
+            }
+            // lanes l, l+16, l+32, l+48 share a chunk column: add them, lanes 0-15 hold the wave's sums
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1[e] += __shfl_xor(s1[e], 16, 64);
+                s1[e] += __shfl_xor(s1[e], 32, 64);
+                s2[e] += __shfl_xor(s2[e], 16, 64);
+                s2[e] += __shfl_xor(s2[e], 32, 64);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 4) {
+                    *(f32x4*)(scr + w * 2 * BC + lane * 8 + e) = f32x4{s1[e], s1[e + 1], s1[e + 2], s1[e + 3]};
+                    *(f32x4*)(scr + w * 2 * BC + BC + lane * 8 + e) = f32x4{s2[e], s2[e + 1], s2[e + 2], s2[e + 3]};
+                }
             }
         }
         if (chk && __any(bad) && lane == 0) atomicOr(a.nonfinite, 1u);
@@ -601,9 +691,10 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
     if (blockIdx.x == 0 && lane == 0)
         for (int k2 = 0; k2 < 8; ++k2) g_rf_stamps[w][k2] = ph[k2];
 #endif
-    if (stats) {
+    if (stats || bw) {
         __syncthreads();
-        if (tid < BC) emit_record(T1 - 1);
+        if (stats && tid < BC) emit_record(T1 - 1);
+        if (bw && tid < BC) emit_bw(T1 - 1);
     }
 }
 
@@ -625,18 +716,21 @@ static hipError_t rfn_launch(const ConvArgs& a, hipStream_t s, int* bp, int* rec
     g.ntiles = (int)((qtot + Cfg::BP - 1) / Cfg::BP);
     g.qmax = (int)bbody_pixels(a.N, a.H, a.W);
     const int nct = (a.Cout + Cfg::BC - 1) / Cfg::BC;
-    int nblk = (Cfg::LDS <= 80 * 1024 ? 512 : 256) / nct;
+    const int lds = a.bw_psum ? Cfg::LDS_BW : Cfg::LDS;
+    if (lds > 160 * 1024) return hipErrorOutOfMemory;
+    int nblk = (lds <= 80 * 1024 ? 512 : 256) / nct;
     if (nblk > g.ntiles) nblk = g.ntiles;
     g.tiles_per_block = (g.ntiles + nblk - 1) / nblk;
     nblk = (g.ntiles + g.tiles_per_block - 1) / g.tiles_per_block;
-    auto kern = conv_rfn_kernel<T, C, WP, WN, TP, PD, NSLOT, AH>;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    auto kern = a.bw_psum ? conv_rfn_kernel<T, C, WP, WN, TP, PD, NSLOT, AH, true>
+                          : conv_rfn_kernel<T, C, WP, WN, TP, PD, NSLOT, AH, false>;
+    static int attr[2] = {0, 0};
+    if (lds > attr[a.bw_psum ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr = true;
+        attr[a.bw_psum ? 1 : 0] = lds;
     }
-    hipLaunchKernelGGL(kern, dim3(nblk, nct), dim3(Cfg::NT), Cfg::LDS, s, a, g);
+    hipLaunchKernelGGL(kern, dim3(nblk, nct), dim3(Cfg::NT), lds, s, a, g);
     if (bp) *bp = Cfg::BP;
     if (records) *records = g.ntiles;
     return hipGetLastError();
@@ -652,10 +746,13 @@ int conv_rf_config(int taps, int W, int row_bytes, int Cout, int M) {
     if (row_bytes == 128 && Cout <= 32) return 2;
     return 0;
 }
-// the 128-cout form: dgrad launches with the fused BN-backward reduce are not covered yet (fwd = 1: forward)
+// the 128-cout form: forward (with statistics) by default.  Its dgrad mode with the fused BN-backward reduce works
+// (Y2_CONV_RFN_DGRAD=1) but does not pay: 167 vs 177 us for the 104x104 dgrad, +22 us in the finalize of the layer
+// below, which then merges one record per 128 positions instead of per 256 pixels.
 int conv_rfn_config(int taps, int W, int row_bytes, int Cout, int M, int dgrad) {
     static const bool off = getenv("Y2_NO_CONV_RF") != nullptr;
-    if (off || dgrad || taps != 9 || W <= 52 || W + 2 > 128 || M < 128 * 1024) return 0;
+    static const bool dg = getenv("Y2_CONV_RFN_DGRAD") != nullptr;
+    if (off || (dgrad && !dg) || taps != 9 || W <= 52 || W + 2 > 128 || M < 128 * 1024) return 0;
     if (row_bytes == 128 && Cout > 64 && Cout <= 128) return 3;
     return 0;
 }

@@ -230,7 +230,8 @@ static void plan(y2_ctx* c) {
     // of the dgrad above when the reduce is fused into that dgrad's epilogue
     size_t psum_floats = (size_t)2048 * 2 * max_ld;
     for (size_t l = 1; l < c->L.size(); ++l) {
-        const size_t rows = ((size_t)c->L[l].M + 127) / 128;
+        // one record per 128+ position tile; the persistent form tiles the bordered positions (conv_rf.hip)
+        const size_t rows = ((size_t)c->N * (c->L[l].H + 1) * (c->L[l].W + 1) + 127) / 128;
         psum_floats = std::max(psum_floats, rows * 2 * (size_t)c->L[l - 1].ldy);
     }
     c->o_psum = take(psum_floats * sizeof(float));
