@@ -59,7 +59,7 @@ struct RfCfg {
     static constexpr int BP = WP * TP * 32, BC = NCT * 32;
     static constexpr int NSLOT = 4, R = NSLOT * BP, RINGB = R * ROWB;
     static constexpr int EROW = BC * SZ + 16, PATCHB = PR * EROW;
-    static constexpr int SCR = (2 * BC + 4) * 4;             // per wave: S1[BC], S2[BC], count
+    static constexpr int SCR = (2 * BC + 2) * 8;             // per wave: S1[BC], S2[BC], count (doubles)
     static constexpr int LDS = RINGB + NW * PATCHB + NW * SCR + BC * 4;   // + the bias slice
     static constexpr int PW = BP / RPI / NW;                 // LDS-DMA pieces per wave and group
     static constexpr int CPR = BC / 8, NIT = PR * CPR / 64;  // 16-byte chunks per patch row; store sweeps per patch
@@ -140,15 +140,22 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;   // transposed patch reads (statistics)
     char* const ydump = (char*)a.y + (size_t)a.M * a.ldy * SZ;   // the slack row behind y: target of the masked stores
 
-    auto emit_record = [&](int rec) {     // tid < BC: one (count, mean, M2) record from the four waves' sums
+    // ONE (count, mean, M2) record per workgroup: the per-tile sums (fp32, from the matrix pipe) are added over the
+    // workgroup's tiles in double, so the record is as exact as per-tile records merged in double -- and the merge
+    // kernel sees a few hundred records instead of ten thousand
+    double S1d[NCT], S2d[NCT];
+#pragma unroll
+    for (int i = 0; i < NCT; ++i) S1d[i] = S2d[i] = 0.0;
+    int cntd = 0;
+    auto emit_record = [&](int rec) {     // tid < BC: from the waves' sums
         double S1 = 0.0, S2 = 0.0;
         float cnt = 0.f;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const float* q = scr_all + k * (Cfg::SCR / 4);
-            S1 += (double)q[tid];
-            S2 += (double)q[BC + tid];
-            cnt += q[2 * BC];
+            const double* q = (const double*)(scr_all + k * (Cfg::SCR / 4));
+            S1 += q[tid];
+            S2 += q[BC + tid];
+            cnt += (float)q[2 * BC];
         }
         const int co = n0 + tid;
         if (co < a.ldy) {
@@ -171,8 +178,6 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // the record of the previous tile, from the scratch its epilogue filled before this barrier
-        if (stats && tile > T0 && tid < BC) emit_record(tile - 1);
 
         // the accumulators start at the bias (rows = couts): no add in the epilogue
         f32x16 acc[NCT][TP];
@@ -293,14 +298,12 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
         }
         if (chk && __any(bad) && lane == 0) atomicOr(a.nonfinite, 1u);
         if (stats) {
-            if (hh == 0) {
 #pragma unroll
-                for (int i = 0; i < NCT; ++i) {
-                    scr[i * 32 + r32] = S1w[i];
-                    scr[BC + i * 32 + r32] = S2w[i];
-                }
+            for (int i = 0; i < NCT; ++i) {
+                S1d[i] += (double)S1w[i];
+                S2d[i] += (double)S2w[i];
             }
-            if (lane == 0) scr[2 * BC] = (float)cntw;
+            cntd += cntw;
         }
         // ---- next tile: BP positions on
 #pragma unroll
@@ -313,8 +316,17 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
     }
     wait_vmcnt<0>();      // the ring's last fills must not outlive the workgroup's LDS
     if (stats) {
+        double* sd = (double*)scr;
+        if (hh == 0) {
+#pragma unroll
+            for (int i = 0; i < NCT; ++i) {
+                sd[i * 32 + r32] = S1d[i];
+                sd[BC + i * 32 + r32] = S2d[i];
+            }
+        }
+        if (lane == 0) sd[2 * BC] = (double)cntd;
         __syncthreads();
-        if (tid < BC) emit_record(T1 - 1);
+        if (tid < BC) emit_record(blockIdx.x);
     }
 }
 
@@ -342,7 +354,7 @@ static hipError_t rf_launch(const ConvArgs& a, hipStream_t s, int* bp, int* reco
     }
     hipLaunchKernelGGL(kern, dim3(nblk, nct), dim3(Cfg::NT), Cfg::LDS, s, a, g);
     if (bp) *bp = Cfg::BP;
-    if (records) *records = g.ntiles;
+    if (records) *records = nblk;          // one record per workgroup
     return hipGetLastError();
 }
 
@@ -362,8 +374,7 @@ struct RfnCfg {
     static constexpr int BP = WP * TP * 32, BC = WN * 32;
     static constexpr int NSLOT = NSLOT_, AH = AH_, DF = NSLOT - 2 * AH - 1, R = NSLOT * BP, RINGB = R * ROWB;
     static constexpr int EROW = BC * SZ + 16, PATCHB = BP * EROW;
-    static constexpr int SCRF = NW * 2 * BC + 8;             // floats: statistics: per pixel-wave group S1[BC], S2[BC], counts;
-                                                             // dgrad with the fused BN-backward reduce: per wave S1[BC], S2[BC]
+    static constexpr int SCRF = 2 * (NW * 2 * BC + NW);      // floats (= NW x {S1[BC], S2[BC]} + NW counts as doubles)
     static constexpr int YTILE = BP * BC * SZ;               // that mode's tile of the layer below's conv output
     static constexpr int LDS = RINGB + PATCHB + SCRF * 4 + BP * 4 + BC * 4;   // + row table + bias slice
     static constexpr int LDS_BW = LDS + YTILE + 2 * BC * 4;
@@ -453,17 +464,26 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
     }
     char* const ydump = (char*)a.y + (size_t)a.M * a.ldy * SZ;
 
-    auto emit_bw = [&](int rec) {         // tid < BC: the tile's S1 / S2 from the waves' sums, fixed order
-        float S1 = 0.f, S2 = 0.f;
+    // ONE record per workgroup (see conv_rf_kernel): the tiles' sums are added in double, statistics in registers,
+    // the BN-backward sums of the dgrad mode in the wave's own LDS slots
+    double* const scrd = (double*)scr;     // [NW][2][BC] doubles, then NW counts
+    double S1d = 0.0, S2d = 0.0;
+    int cntd = 0;
+    if (bw && lane < 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) scrd[w * 2 * BC + lane * 8 + e] = scrd[w * 2 * BC + BC + lane * 8 + e] = 0.0;
+    }
+    auto emit_bw = [&](int rec) {         // tid < BC: the workgroup's S1 / S2 from the waves' sums, fixed order
+        double S1 = 0.0, S2 = 0.0;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            S1 += scr[k * 2 * BC + tid];
-            S2 += scr[k * 2 * BC + BC + tid];
+            S1 += scrd[k * 2 * BC + tid];
+            S2 += scrd[k * 2 * BC + BC + tid];
         }
         const int co = n0 + tid;
         if (co < a.ldy) {
-            a.bw_psum[((size_t)rec * 2 + 0) * a.ldy + co] = S1;
-            a.bw_psum[((size_t)rec * 2 + 1) * a.ldy + co] = S2;
+            a.bw_psum[((size_t)rec * 2 + 0) * a.ldy + co] = (float)S1;
+            a.bw_psum[((size_t)rec * 2 + 1) * a.ldy + co] = (float)S2;
         }
     };
     auto emit_record = [&](int rec) {     // tid < BC
@@ -471,9 +491,9 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         float cnt = 0.f;
 #pragma unroll
         for (int k = 0; k < WP; ++k) {
-            S1 += (double)scr[k * 2 * BC + tid];
-            S2 += (double)scr[k * 2 * BC + BC + tid];
-            cnt += scr[WP * 2 * BC + k];
+            S1 += scrd[(k * WN) * 2 * BC + tid];
+            S2 += scrd[(k * WN) * 2 * BC + BC + tid];
+            cnt += (float)scrd[NW * 2 * BC + k];
         }
         const int co = n0 + tid;
         if (co < a.ldy) {
@@ -501,8 +521,6 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         RF_STAMP(1);    // barrier A
-        if (stats && tile > T0 && tid < BC) emit_record(tile - 1);
-        if (bw && tile > T0 && tid < BC) emit_bw(tile - 1);
 
         f32x16 acc[TP];     // start at the bias (rows = couts)
 #pragma unroll
@@ -584,11 +602,9 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 #pragma unroll
             for (int q = 0; q < 16; ++q) dg += (acc_row(q, hh) == r32) ? q2[q] : 0.f;
             dg += __shfl_xor(dg, 32, 64);
-            if (hh == 0) {
-                scr[wp * 2 * BC + wn * 32 + r32] = q1[0];
-                scr[wp * 2 * BC + BC + wn * 32 + r32] = dg;
-            }
-            if (wn == 0 && lane == 0) scr[WP * 2 * BC + wp] = (float)cntw;
+            S1d += (double)q1[0];
+            S2d += (double)dg;
+            cntd += cntw;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RF_STAMP(4);    // stage + patch + statistics
@@ -669,9 +685,9 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
             }
             if (lane < 16) {
 #pragma unroll
-                for (int e = 0; e < 8; e += 4) {
-                    *(f32x4*)(scr + w * 2 * BC + lane * 8 + e) = f32x4{s1[e], s1[e + 1], s1[e + 2], s1[e + 3]};
-                    *(f32x4*)(scr + w * 2 * BC + BC + lane * 8 + e) = f32x4{s2[e], s2[e + 1], s2[e + 2], s2[e + 3]};
+                for (int e = 0; e < 8; ++e) {
+                    scrd[w * 2 * BC + lane * 8 + e] += (double)s1[e];
+                    scrd[w * 2 * BC + BC + lane * 8 + e] += (double)s2[e];
                 }
             }
         }
@@ -692,11 +708,19 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         for (int k2 = 0; k2 < 8; ++k2) g_rf_stamps[w][k2] = ph[k2];
 #endif
     if (stats || bw) {
+        if (stats) {      // rows (wp, wn = 0 .. WN-1) hold the wave's 32 columns at their place in a BC-wide row of wave wp * WN
+            if (hh == 0) {
+                scrd[(wp * WN) * 2 * BC + wn * 32 + r32] = S1d;
+                scrd[(wp * WN) * 2 * BC + BC + wn * 32 + r32] = S2d;
+            }
+            if (wn == 0 && lane == 0) scrd[NW * 2 * BC + wp] = (double)cntd;
+        }
         __syncthreads();
-        if (stats && tid < BC) emit_record(T1 - 1);
-        if (bw && tid < BC) emit_bw(T1 - 1);
+        if (stats && tid < BC) emit_record(blockIdx.x);
+        if (bw && tid < BC) emit_bw(blockIdx.x);
     }
 }
+
 
 #ifdef Y2_DEV
 hipError_t rf_read_stamps(unsigned long long* dst) {
@@ -732,7 +756,7 @@ static hipError_t rfn_launch(const ConvArgs& a, hipStream_t s, int* bp, int* rec
     }
     hipLaunchKernelGGL(kern, dim3(nblk, nct), dim3(Cfg::NT), lds, s, a, g);
     if (bp) *bp = Cfg::BP;
-    if (records) *records = g.ntiles;
+    if (records) *records = nblk;          // one record per workgroup
     return hipGetLastError();
 }
 
@@ -746,13 +770,11 @@ int conv_rf_config(int taps, int W, int row_bytes, int Cout, int M) {
     if (row_bytes == 128 && Cout <= 32) return 2;
     return 0;
 }
-// the 128-cout form: forward (with statistics) by default.  Its dgrad mode with the fused BN-backward reduce works
-// (Y2_CONV_RFN_DGRAD=1) but does not pay: 167 vs 177 us for the 104x104 dgrad, +22 us in the finalize of the layer
-// below, which then merges one record per 128 positions instead of per 256 pixels.
+// the 128-cout form: forward (with statistics), plain, and dgrad with the fused BN-backward reduce
 int conv_rfn_config(int taps, int W, int row_bytes, int Cout, int M, int dgrad) {
     static const bool off = getenv("Y2_NO_CONV_RF") != nullptr;
-    static const bool dg = getenv("Y2_CONV_RFN_DGRAD") != nullptr;
-    if (off || (dgrad && !dg) || taps != 9 || W <= 52 || W + 2 > 128 || M < 128 * 1024) return 0;
+    static const bool nodg = getenv("Y2_NO_CONV_RFN_DGRAD") != nullptr;
+    if (off || (dgrad && nodg) || taps != 9 || W <= 52 || W + 2 > 128 || M < 128 * 1024) return 0;
     if (row_bytes == 128 && Cout > 64 && Cout <= 128) return 3;
     return 0;
 }
