@@ -45,7 +45,11 @@ extern "C" __attribute__((visibility("default"))) int y2dev_bench_wgrad(int N, i
     hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
     hipMemcpy(dy, hy.data(), hy.size() * 2, hipMemcpyHostToDevice);
     hipMemset(dw, 0, (size_t)k * k * Cin * Cout * 4);
+    float* slab = nullptr;
+    const size_t slab_floats = (size_t)1024 * 18432 * 2;
+    if (!getenv("Y2DEV_NO_SLAB") && hipMalloc(&slab, slab_floats * 4) != hipSuccess) return -1;
     WgradArgs g{};
+    g.slab = slab; g.slab_floats = slab ? slab_floats : 0;
     g.x = (char*)x + (size_t)(W + 3) * Cin * sz; g.dy = (char*)dy + (size_t)(W + 3) * Cout * sz; g.dW = dw;
     g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = Cin; g.Cdy = Cout; g.Cout = Cout; g.taps = k * k;
     g.splitk = splitk; g.scale = 1.f;
@@ -65,7 +69,7 @@ extern "C" __attribute__((visibility("default"))) int y2dev_bench_wgrad(int N, i
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
     *ms_out = ms / iters;
-    hipFree(x); hipFree(dy); hipFree(dw);
+    hipFree(x); hipFree(dy); hipFree(dw); if (slab) hipFree(slab);
     hipEventDestroy(e0); hipEventDestroy(e1);
     return 0;
 }

@@ -214,9 +214,10 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
     const int tiles = a.taps * nIT * nOT;
     if (a.splitk <= 0) {
-        // 1x1: the fp32 atomics of the split-K partial tiles cost as much as the streaming reads --
-        // one block per CU is the measured optimum (scripts/bench_wgrad.py); 3x3 fallback: ~6 per CU
-        const int target = a.taps == 1 ? target1 : 1536;
+        // 1x1: with float atomics the partial tiles cost as much as the streaming reads and one block per CU was
+        // the optimum; through the slab two per CU are (scripts/bench_wgrad.py: 38 -> 33.5 us at 26x26 / 13x13);
+        // 3x3 fallback: ~6 per CU
+        const int target = a.taps == 1 ? (a.slab && target1 == 256 ? 512 : target1) : 1536;
         long sk = (target + tiles - 1) / tiles;
         const long maxsk = (ksteps + 7) / 8;         // at least 8 K steps per block
         if (sk > maxsk) sk = maxsk;
