@@ -266,6 +266,162 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Short partial lists (the 26x26 / 13x13 layers: P <= 128 records): the merge rides in the apply pass.  A block owns
+// a 64-channel slab (grid.y) and a pixel range (grid.x); it first merges the P records of ITS 64 channels (4 slices
+// x 64 channels, the shifted-sum merge of bn_finalize_kernel in double, fixed order: every block of a slab gets the
+// same bits), the blocks with blockIdx.x == 0 also write scale / shift / mean / invstd / variance and the moving
+// statistics for the backward pass; then the slab's pixels as in bn_act_kernel.  One launch and ~6 us of critical
+// path less per layer than merge + apply.
+// ---------------------------------------------------------------------------
+constexpr int kSlab = 64;
+Y2_DEV void fin_slab_merge(const BnFinalizeArgs& f, int cbase, double (*red)[kSlab][3], float* s_sc, float* s_sh, bool writer) {
+    const int c = threadIdx.x & (kSlab - 1), sl = threadIdx.x >> 6;   // 256 threads: 4 slices
+    const int cc = cbase + c;
+    const bool cv = cc < f.C;
+    const int ci = cv ? cc : 0;
+    const double sft = f.P > 0 ? (double)f.part_mean[ci] : 0.0;
+    double n = 0.0, A = 0.0, B = 0.0;
+    for (int p = sl; p < f.P; p += 4) {
+        const size_t q = (size_t)p * f.ldp + ci;
+        const double k = f.part_cnt[p];
+        const double d = (double)f.part_mean[q] - sft;
+        n += k;
+        A += k * d;
+        B += (double)f.part_m2[q] + k * d * d;
+    }
+    red[sl][c][0] = n; red[sl][c][1] = A; red[sl][c][2] = B;
+    __syncthreads();
+    if (sl == 0) {
+        double nt = 0.0, at = 0.0, bt = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { nt += red[k][c][0]; at += red[k][c][1]; bt += red[k][c][2]; }
+        const double mean = nt > 0 ? sft + at / nt : 0.0;
+        double mt = nt > 0 ? bt - at * at / nt : 0.0;
+        if (mt < 0) mt = 0;
+        const float var = (float)(nt > 0 ? mt / nt : 0.0);
+        const float meanf = (float)mean;
+        const float inv = 1.0f / sqrtf(var + f.eps);
+        const float sc = cv ? f.gamma[ci] * inv : 0.f;
+        const float sh = cv ? f.beta[ci] - meanf * sc : 0.f;
+        s_sc[c] = sc;
+        s_sh[c] = sh;
+        if (writer && cv) {
+            f.scale[cc] = sc;
+            f.shift[cc] = sh;
+            f.mean[cc] = meanf;
+            f.invstd[cc] = inv;
+            float vu = var;
+            if (f.bessel && nt > 1.0) vu = (float)(mt / (nt - 1.0));
+            if (f.var) f.var[cc] = vu;
+            if (f.update_moving) {
+                const float dec = 1.0f - f.momentum;
+                f.moving_mean[cc] -= (f.moving_mean[cc] - meanf) * dec;
+                f.moving_var[cc] -= (f.moving_var[cc] - vu) * dec;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalizeArgs f) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int CPB = kSlab / EPC;        // chunks per block row
+    constexpr int rows = 256 / CPB;
+    __shared__ double red[4][kSlab][3];
+    __shared__ float s_sc[kSlab], s_sh[kSlab];
+    const int cbase = blockIdx.y * kSlab;
+    fin_slab_merge(f, cbase, red, s_sc, s_sh, blockIdx.x == 0);
+    const int Ho = POOL ? (a.H + 1) / 2 : a.H, Wo = POOL ? (a.W + 1) / 2 : a.W;
+    const uint32_t mout = (uint32_t)a.N * Ho * Wo;
+    const int tid = threadIdx.x;
+    const int ch = tid % CPB, row = tid / CPB;
+    const int c0 = cbase + ch * EPC;
+    if (c0 >= a.C) return;
+    const uint32_t per_blk = (mout + gridDim.x - 1) / gridDim.x;
+    const uint32_t p_begin = blockIdx.x * per_blk;
+    uint32_t p_end = p_begin + per_blk;
+    if (p_end > mout) p_end = mout;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = s_sc[ch * EPC + e];
+        sh[e] = s_sh[ch * EPC + e];
+    }
+    int wo, ho, n;
+    {
+        const uint32_t p0 = p_begin + row;
+        wo = (int)(p0 % (uint32_t)Wo);
+        const uint32_t q = p0 / (uint32_t)Wo;
+        ho = (int)(q % (uint32_t)Ho);
+        n = (int)(q / (uint32_t)Ho);
+    }
+    const int drow = rows / Wo, dcol = rows % Wo;
+    for (uint32_t po = p_begin + row; po < p_end; po += rows, wo += dcol, ho += drow) {
+        if (wo >= Wo) { wo -= Wo; ++ho; }
+        while (ho >= Ho) { ho -= Ho; ++n; }
+        float r[EPC];
+        if (POOL) {
+            Chunk<T> ys;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
+                if (hi < a.H && wi < a.W) {
+                    Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float act = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+                        if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
+                    }
+                }
+            }
+            if (a.ysel) st_chunk<T>((char*)a.ysel + ((size_t)po * a.ldy + c0) * sizeof(T), ys);
+        } else {
+            Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) r[e] = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(r[e]);
+        const size_t off = (bpix(n, ho, wo, Ho, Wo) * a.C + c0) * sizeof(T);
+        st_chunk<T>((char*)a.out + off, o);
+    }
+}
+
+bool bn_fin_act_ok(const BnActArgs& a, const BnFinalizeArgs& f) {
+    return f.P > 0 && f.P <= 128 && !a.out_f32 && a.ldy % kSlab == 0 && a.C == a.ldy && f.ldp == a.ldy;
+}
+template <typename T>
+static hipError_t bn_fin_act_T(const BnActArgs& a, const BnFinalizeArgs& f, hipStream_t s) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int Ho = a.pool ? (a.H + 1) / 2 : a.H, Wo = a.pool ? (a.W + 1) / 2 : a.W;
+    const size_t mout = (size_t)a.N * Ho * Wo;
+    if (mout >= (1ull << 31)) return hipErrorInvalidValue;
+    const int rows = 256 / (kSlab / EPC);
+    const int ny = a.ldy / kSlab;
+    size_t nx = (mout + (size_t)rows * 4 - 1) / ((size_t)rows * 4);
+    const size_t cap = (size_t)(4096 / ny) > 0 ? (size_t)(4096 / ny) : 1;
+    if (nx > cap) nx = cap;
+    if (nx == 0) nx = 1;
+    dim3 g((unsigned)nx, (unsigned)ny), b(256);
+    if (a.pool) hipLaunchKernelGGL((bn_fin_act_kernel<T, true>), g, b, 0, s, a, f);
+    else hipLaunchKernelGGL((bn_fin_act_kernel<T, false>), g, b, 0, s, a, f);
+    return hipGetLastError();
+}
+hipError_t launch_bn_fin_act(int dtype, const BnActArgs& a, const BnFinalizeArgs& f, hipStream_t s) {
+    if (!bn_fin_act_ok(a, f)) return hipErrorInvalidValue;
+    switch (dtype) {
+        case 0: return bn_fin_act_T<float>(a, f, s);
+        case 1: return bn_fin_act_T<half_t>(a, f, s);
+        case 2: return bn_fin_act_T<bf16_t>(a, f, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <typename T>
 static hipError_t bn_act_T(const BnActArgs& a, hipStream_t s) {
     constexpr int EPC = 16 / sizeof(T);
@@ -503,6 +659,175 @@ __global__ __launch_bounds__(SLN * kFinCh) void bn_bwd_finalize_kernel(BnBwdArgs
         a.coef[a.ldy + c] = (float)kb;
         if (a.dbias) a.dbias[c] = (float)(sc * (t[0] - m * (double)c1) * a.inv_grad_scale);
     }
+}
+
+// ---------------------------------------------------------------------------
+// Short partial lists (P <= 128: the 26x26 / 13x13 layers, whose sums come from the dgrad epilogue above): the
+// finalize rides in the apply pass, as in bn_fin_act_kernel -- a block owns a 64-channel slab, sums the P records of
+// its channels in double (4 slices, fixed order), forms ka / kb, and the blocks with blockIdx.x == 0 write dbeta,
+// dgamma, dbias and coef.
+// ---------------------------------------------------------------------------
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int CPB = kSlab / EPC;
+    constexpr int rows = 256 / CPB;
+    __shared__ double red[4][kSlab][2];
+    __shared__ float s_nka[kSlab], s_nkb[kSlab];
+    const int cbase = blockIdx.y * kSlab;
+    {
+        const int c = threadIdx.x & (kSlab - 1), sl = threadIdx.x >> 6;
+        const int cc = cbase + c;
+        const bool cv = cc < a.C;
+        const int ci = cv ? cc : 0;
+        double t0 = 0.0, t1 = 0.0;
+        for (int p = sl; p < a.P; p += 4) {
+            t0 += (double)a.psum[((size_t)p * 2 + 0) * a.ldy + ci];
+            t1 += (double)a.psum[((size_t)p * 2 + 1) * a.ldy + ci];
+        }
+        red[sl][c][0] = t0; red[sl][c][1] = t1;
+        __syncthreads();
+        if (sl == 0) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s0 += red[k][c][0]; s1 += red[k][c][1]; }
+            const double m = (double)a.N * a.H * a.W;
+            const double mu = a.mean[ci], is = a.invstd[ci], sc = a.scale[ci];
+            const double dgam = is * (s1 - mu * s0);
+            const float c1 = a.training ? (float)(s0 / m) : 0.f;
+            const float c2 = a.training ? (float)(dgam / m) : 0.f;
+            const double kb = sc * (double)c2 * is;
+            const float ka = (float)(sc * (double)c1 - kb * mu);
+            s_nka[c] = cv ? -ka : 0.f;
+            s_nkb[c] = cv ? -(float)kb : 0.f;
+            if (blockIdx.x == 0 && cv) {
+                a.dbeta[cc] = (float)(s0 * a.inv_grad_scale);
+                a.dgamma[cc] = (float)(dgam * a.inv_grad_scale);
+                a.coef[cc] = ka;
+                a.coef[a.ldy + cc] = (float)kb;
+                if (a.dbias) a.dbias[cc] = (float)(sc * (s0 - m * (double)c1) * a.inv_grad_scale);
+            }
+        }
+        __syncthreads();
+    }
+    const int Ho = POOL ? (a.H + 1) / 2 : a.H, Wo = POOL ? (a.W + 1) / 2 : a.W;
+    const uint32_t mout = (uint32_t)a.N * Ho * Wo;
+    const int tid = threadIdx.x;
+    const int ch = tid % CPB, row = tid / CPB;
+    const int c0 = cbase + ch * EPC;
+    if (c0 >= a.ldy) return;
+    const uint32_t per_blk = (mout + gridDim.x - 1) / gridDim.x;
+    const uint32_t p_begin = blockIdx.x * per_blk;
+    uint32_t p_end = p_begin + per_blk;
+    if (p_end > mout) p_end = mout;
+    float sc[EPC], sh[EPC], nka[EPC], nkb[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = a.scale[c0 + e];
+        sh[e] = a.shift[c0 + e];
+        nka[e] = s_nka[ch * EPC + e];
+        nkb[e] = s_nkb[ch * EPC + e];
+    }
+    int wo, ho, n;
+    {
+        const uint32_t p0 = p_begin + row;
+        wo = (int)(p0 % (uint32_t)Wo);
+        const uint32_t q = p0 / (uint32_t)Wo;
+        ho = (int)(q % (uint32_t)Ho);
+        n = (int)(q / (uint32_t)Ho);
+    }
+    const int drow = rows / Wo, dcol = rows % Wo;
+    for (uint32_t po = p_begin + row; po < p_end; po += rows, wo += dcol, ho += drow) {
+        if (wo >= Wo) { wo -= Wo; ++ho; }
+        while (ho >= Ho) { ho -= Ho; ++n; }
+        Chunk<T> dav = ld_chunk<T>((const char*)a.dA + ((size_t)po * a.ldd + c0) * sizeof(T));
+        if (POOL) {
+            Chunk<T> yc[4];
+            bool valid[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
+                valid[d] = hi < a.H && wi < a.W;
+                if (valid[d])
+                    yc[d] = ld_chunk<T>((const char*)a.y + (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
+            }
+            int arg[EPC];
+            float amax[EPC], yb[EPC], gz[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                arg[e] = 0;
+                amax[e] = -INFINITY;
+                yb[e] = 0.f;
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (valid[d]) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float yv = Elem<T>::to_f32(yc[d].v[e]);
+                        const float act = leaky01(fmaf(yv, sc[e], sh[e]));
+                        if (act > amax[e]) {
+                            amax[e] = act;
+                            yb[e] = yv;
+                            arg[e] = d;
+                        }
+                    }
+                }
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yb[e], sc[e], sh[e]));
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (!valid[d]) continue;
+                const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float t = fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
+                    o.v[e] = Elem<T>::from_f32((arg[e] == d) ? fmaf(sc[e], gz[e], t) : t);
+                }
+                const size_t off = (bpix(n, hi, wi, a.H, a.W) * a.ldy + c0) * sizeof(T);
+                st_chunk<T>((char*)a.dyp + off, o);
+            }
+        } else {
+            Chunk<T> v = ld_chunk<T>((const char*)a.y + ((size_t)po * a.ldy + c0) * sizeof(T));
+            Chunk<T> o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float yv = Elem<T>::to_f32(v.v[e]);
+                const float gz = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yv, sc[e], sh[e]));
+                o.v[e] = Elem<T>::from_f32(fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e])));
+            }
+            const size_t off = (bpix(n, ho, wo, a.H, a.W) * a.ldy + c0) * sizeof(T);
+            st_chunk<T>((char*)a.dyp + off, o);
+        }
+    }
+}
+
+bool bn_bwd_fin_apply_ok(const BnBwdArgs& a) { return a.P > 0 && a.P <= 128 && a.ldy % kSlab == 0 && a.C == a.ldy; }
+template <typename T>
+static hipError_t bn_bwd_fin_apply_T(const BnBwdArgs& a, hipStream_t s) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int Ho = a.pool ? (a.H + 1) / 2 : a.H, Wo = a.pool ? (a.W + 1) / 2 : a.W;
+    const size_t mout = (size_t)a.N * Ho * Wo;
+    const int rows = 256 / (kSlab / EPC);
+    const int ny = a.ldy / kSlab;
+    size_t nx = (mout + (size_t)rows * 8 - 1) / ((size_t)rows * 8);
+    const size_t cap = (size_t)(2048 / ny) > 0 ? (size_t)(2048 / ny) : 1;
+    if (nx > cap) nx = cap;
+    if (nx == 0) nx = 1;
+    dim3 g((unsigned)nx, (unsigned)ny), b(256);
+    if (a.pool) hipLaunchKernelGGL((bn_bwd_fin_apply_kernel<T, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((bn_bwd_fin_apply_kernel<T, false>), g, b, 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_bn_bwd_fin_apply(int dtype, const BnBwdArgs& a, hipStream_t s) {
+    if (!bn_bwd_fin_apply_ok(a)) return hipErrorInvalidValue;
+    switch (dtype) {
+        case 0: return bn_bwd_fin_apply_T<float>(a, s);
+        case 1: return bn_bwd_fin_apply_T<half_t>(a, s);
+        case 2: return bn_bwd_fin_apply_T<bf16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
 }
 
 template <typename T>

@@ -253,6 +253,9 @@ struct BnActArgs {
                           // what the BN-backward reduce needs of y (fused into the dgrad epilogue above this layer)
 };
 hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t s);
+// merge of a short partial list (P <= 128) + apply in one launch (64-channel slabs); bn_fin_act_ok says whether it applies
+bool bn_fin_act_ok(const BnActArgs& a, const BnFinalizeArgs& f);
+hipError_t launch_bn_fin_act(int dtype, const BnActArgs& a, const BnFinalizeArgs& f, hipStream_t s);
 
 struct BnBwdArgs {
     const void* dA;       // grad wrt layer output [M_out][ldd] of T (scaled by grad_scale)
@@ -277,6 +280,9 @@ int bn_bwd_partials(const BnBwdArgs& a);
 hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s);
 hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s);
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s);
+// finalize of a short partial list (P <= 128) + apply in one launch (64-channel slabs)
+bool bn_bwd_fin_apply_ok(const BnBwdArgs& a);
+hipError_t launch_bn_bwd_fin_apply(int dtype, const BnBwdArgs& a, hipStream_t s);
 
 // ---- loss / heads
 struct LossArgs {

@@ -609,8 +609,8 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             P = rec;
         }
         PROF(CAT_BN_FWD);
+        BnFinalizeArgs f{};
         if (training) {
-            BnFinalizeArgs f{};
             f.part_cnt = part_cnt; f.part_mean = part_mean; f.part_m2 = part_m2;
             f.P = P; f.C = y.cout; f.ldp = y.first3 ? 32 : y.ldy;
             f.gamma = c->params + y.pg; f.beta = c->params + y.pbeta;
@@ -619,7 +619,17 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             f.var = stat + 6 * y.ldy;
             f.scratch = (float*)(c->ws + c->o_part_scratch);
             f.eps = kBnEps; f.momentum = kBnMomentum; f.update_moving = update_moving ? 1 : 0; f.bessel = c->bessel;
-            HIPCHK(launch_bn_finalize(f, s));
+        }
+        // short partial lists: the merge rides in the apply pass (bn.hip bn_fin_act_kernel)
+        static const bool no_fin_fuse = getenv("Y2_NO_BN_FIN_FUSE") != nullptr;
+        bool fin_fused = false;
+        if (training && !pool1 && !no_fin_fuse && l + 1 < nl) {
+            BnActArgs t{};
+            t.C = y.cout; t.ldy = y.ldy; t.out_f32 = 0;
+            fin_fused = bn_fin_act_ok(t, f);
+        }
+        if (training) {
+            if (!fin_fused) HIPCHK(launch_bn_finalize(f, s));
         } else {
             HIPCHK(launch_bn_infer_prepare(c->params + y.pg, c->params + y.pbeta, c->state + y.smm, c->state + y.smv,
                                            scale, shift, mean, invstd, y.cout, kBnEps, s));
@@ -648,7 +658,8 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             b.out_f32 = 1;
         }
         if (y.pool && c->bound_training && y.ysel) b.ysel = c->ws + y.ysel;
-        HIPCHK(launch_bn_act(c->dtype, b, s));
+        if (fin_fused) HIPCHK(launch_bn_fin_act(c->dtype, b, f, s));
+        else HIPCHK(launch_bn_act(c->dtype, b, s));
     }
     if (c->tail == Y2_TAIL_AVGPOOL) {
         const Layer& y = c->L.back();
@@ -775,8 +786,14 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
             }
             fused_P = 0;
-            HIPCHK(launch_bn_bwd_finalize(b, s));
-            if (!fused1 && !lin1) HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
+            // short partial lists: the finalize rides in the apply pass (bn.hip bn_bwd_fin_apply_kernel)
+            static const bool no_fin_fuse = getenv("Y2_NO_BN_FIN_FUSE") != nullptr;
+            if (!fused1 && !lin1 && !no_fin_fuse && bn_bwd_fin_apply_ok(b)) {
+                HIPCHK(launch_bn_bwd_fin_apply(c->dtype, b, s));
+            } else {
+                HIPCHK(launch_bn_bwd_finalize(b, s));
+                if (!fused1 && !lin1) HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
+            }
         }
         char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
         if (lin1) {
