@@ -393,7 +393,8 @@ __global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalize
 }
 
 bool bn_fin_act_ok(const BnActArgs& a, const BnFinalizeArgs& f) {
-    return f.P > 0 && f.P <= 128 && !a.out_f32 && a.ldy % kSlab == 0 && a.C == a.ldy && f.ldp == a.ldy;
+    static const int pmax = getenv("Y2DEV_FIN_PMAX") ? atoi(getenv("Y2DEV_FIN_PMAX")) : 128;
+    return f.P > 0 && f.P <= pmax && !a.out_f32 && a.ldy % kSlab == 0 && a.C == a.ldy && f.ldp == a.ldy;
 }
 template <typename T>
 static hipError_t bn_fin_act_T(const BnActArgs& a, const BnFinalizeArgs& f, hipStream_t s) {
@@ -803,7 +804,9 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
     }
 }
 
-bool bn_bwd_fin_apply_ok(const BnBwdArgs& a) { return a.P > 0 && a.P <= 128 && a.ldy % kSlab == 0 && a.C == a.ldy; }
+bool bn_bwd_fin_apply_ok(const BnBwdArgs& a) {
+    static const int pmax = getenv("Y2DEV_FIN_PMAX") ? atoi(getenv("Y2DEV_FIN_PMAX")) : 128;
+    return a.P > 0 && a.P <= pmax && a.ldy % kSlab == 0 && a.C == a.ldy; }
 template <typename T>
 static hipError_t bn_bwd_fin_apply_T(const BnBwdArgs& a, hipStream_t s) {
     constexpr int EPC = 16 / sizeof(T);
