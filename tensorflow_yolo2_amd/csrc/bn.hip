@@ -837,6 +837,10 @@ template <typename T>
 static int bwd_blocks(const BnBwdArgs& a) {
     const BwdGeom g = bwd_geom<T>(a);
     size_t nb = (g.mout + (size_t)g.rows * 8 - 1) / ((size_t)g.rows * 8);  // >= 8 pixels per thread row
+    if (nb < 256) {      // small tensors (the 13x13 output layer: 21 blocks took 21 us): one pixel row group per block
+        nb = (g.mout + g.rows - 1) / g.rows;
+        if (nb > 256) nb = 256;
+    }
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     return (int)nb;
