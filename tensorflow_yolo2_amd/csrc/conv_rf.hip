@@ -167,17 +167,19 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
         if (tid == 0 && blockIdx.y == 0) a.part_cnt[rec] = cnt;
     };
 
+    // ONE workgroup barrier per tile: at the top of tile t every wave has left tile t-1's K loop, so group t-2 is dead
+    // and its ring slot takes group t+2 (needed at the top of t+1: a whole tile of lead); the epilogue is wave-private
     stage(T0 - 1);
     stage(T0);
     stage(T0 + 1);
-    stage(T0 + 2);
     for (int tile = T0; tile < T1; ++tile) {
-        // groups tile-1 .. tile+1 have landed when all but the youngest group (and the stores behind it) are done
-        if (tile == T0) wait_vmcnt<Cfg::PW>();
-        else wait_vmcnt<Cfg::PW + Cfg::NST>();
+        // groups tile-1 .. tile+1 have landed when only the last epilogue's stores (issued after them) are outstanding
+        if (tile == T0) wait_vmcnt<0>();
+        else wait_vmcnt<Cfg::NST>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        stage(tile + 2);
 
         // the accumulators start at the bias (rows = couts): no add in the epilogue
         f32x16 acc[NCT][TP];
@@ -215,10 +217,6 @@ __global__ __launch_bounds__(WP * 64, 2) void conv_rf_kernel(ConvArgs a, RfGeom 
                 for (int j = 0; j < TP; ++j) mma32(acc[i][j], wreg[i][s], fa[s % (PD + 1)][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_barrier();          // every wave is done with the oldest group: its slot takes group tile + 3
-        asm volatile("" ::: "memory");
-        stage(tile + 3);
-
         // ---- epilogue, PR pixel rows at a time through the wave's own patch
         float S1w[NCT], S2w[NCT];
 #pragma unroll
@@ -557,10 +555,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
             __builtin_amdgcn_sched_barrier(0);
         }
         RF_STAMP(2);    // record + K loop
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        RF_STAMP(3);    // barrier B
-        if (!bw) stage(tile - AH + NSLOT);
+        RF_STAMP(3);
 
         // ---- the wave's 32-cout columns of its rows into the workgroup's patch
         int cntw = 0;
@@ -610,10 +605,11 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         RF_STAMP(4);    // stage + patch + statistics
         __builtin_amdgcn_s_barrier();          // patch and row table complete
         asm volatile("" ::: "memory");
-        RF_STAMP(5);    // barrier C
+        RF_STAMP(5);    // barrier C: every wave has also left the K loop, the oldest group's slot is free
         // ---- whole rows out: lane = (row, 16-byte chunk), consecutive lanes along a row
         bool bad = false;
         if (!bw) {
+            stage(tile - AH + NSLOT);
 #pragma unroll
             for (int it = 0; it < Cfg::NIT; ++it) {
                 const int idx = it * NT + tid;
