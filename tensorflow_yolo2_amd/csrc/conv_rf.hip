@@ -450,6 +450,9 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
     const bool stats = !BW && a.part_mean != nullptr;
     const bool chk = a.nonfinite != nullptr;
     constexpr bool bw = BW;                    // dgrad: BN-backward reduce of the layer below (ConvArgs::bw_*)
+    // forward / plain launches on the four-slot ring: every wave stores its own 64-byte row segments (no patch barrier,
+    // no row table) and the ring slot is refilled at the top of the next tile: ONE workgroup barrier per tile
+    constexpr bool WPRIV = !BW && AH == 1 && NSLOT == 4;
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
     // bw mode: scale / shift of the layer below wait in LDS (behind the y tile), registers are for the filters
     float* const bwtab = (float*)(ybuf + Cfg::YTILE);
@@ -504,13 +507,16 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
     };
 
 #pragma unroll
-    for (int g = 0; g < NSLOT; ++g) stage(T0 - AH + g);
+    for (int g = 0; g < (WPRIV ? NSLOT - 1 : NSLOT); ++g) stage(T0 - AH + g);
 #ifdef Y2_DEV
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
 #endif
     for (int tile = T0; tile < T1; ++tile) {
-        {   // groups tile - AH .. tile + AH have landed when all but the DF youngest (and the stores between them) are done
+        if (WPRIV) {   // only the last epilogue's stores (issued after every group this tile needs) may be outstanding
+            if (tile == T0) wait_vmcnt<0>();
+            else wait_vmcnt<Cfg::NST>();
+        } else {   // groups tile - AH .. tile + AH have landed when all but the DF youngest (and the stores between them) are done
             const int done = tile - T0;
             wait_vmcnt_dyn(Cfg::DF * Cfg::PW + (done < Cfg::DF ? done : Cfg::DF) * Cfg::NST);
         }
@@ -519,6 +525,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         RF_STAMP(1);    // barrier A
+        if (WPRIV) stage(tile + 2);     // every wave has left tile - 1's K loop: group tile - 2 is dead
 
         f32x16 acc[TP];     // start at the bias (rows = couts)
 #pragma unroll
@@ -559,12 +566,14 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 
         // ---- the wave's 32-cout columns of its rows into the workgroup's patch
         int cntw = 0;
+        int pj[TP];
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const bool valid = pcol[j] >= 1 && prow_[j] >= 1 && pimg[j] < a.N;
             const int p = valid ? (pimg[j] * a.H + prow_[j] - 1) * a.W + pcol[j] - 1 : -1;
             const int row = (wp * TP + j) * 32 + r32;
-            if (wn == 0 && hh == 0) ptab[row] = p;
+            if (!WPRIV && wn == 0 && hh == 0) ptab[row] = p;
+            pj[j] = p;
             cntw += __popcll(__ballot(valid && hh == 0));
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -603,12 +612,35 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RF_STAMP(4);    // stage + patch + statistics
+        bool bad = false;
+        if (WPRIV) {
+            // ---- the wave's own region out: 64-byte row segments (its 32 couts), lane = (row of 16, 16-byte chunk of 4)
+            static_assert(!WPRIV || Cfg::NST == TP * 2, "store count of the wave-private sweep");
+#pragma unroll
+            for (int it = 0; it < TP * 2; ++it) {
+                const int rloc = (it & 1) * 16 + (lane >> 2);              // row inside sub-tile it / 2
+                const int pr = __shfl(pj[it >> 1], rloc, 64);
+                const int row = (wp * TP + (it >> 1)) * 32 + rloc;
+                const int ch = wn * 4 + (lane & 3);
+                Chunk<T> c = ld_chunk<T>(patch + row * EROW + ch * 16);
+                const int cch = n0 + ch * 8;
+                const bool st = pr >= 0 && cch < a.ldy;
+                char* dstp = st ? (char*)a.y + ((size_t)pr * a.ldy + cch) * SZ : ydump + (ch % (a.ldy / 8)) * 16;
+                st_chunk<T>(dstp, c);
+                if (chk && st) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        bad |= (__float_as_uint(Elem<T>::to_f32(c.v[e])) & 0x7F800000u) == 0x7F800000u;
+                }
+            }
+        }
+        if (!WPRIV) {
         __builtin_amdgcn_s_barrier();          // patch and row table complete
         asm volatile("" ::: "memory");
+        }
         RF_STAMP(5);    // barrier C: every wave has also left the K loop, the oldest group's slot is free
         // ---- whole rows out: lane = (row, 16-byte chunk), consecutive lanes along a row
-        bool bad = false;
-        if (!bw) {
+        if (!bw && !WPRIV) {
             stage(tile - AH + NSLOT);
 #pragma unroll
             for (int it = 0; it < Cfg::NIT; ++it) {
@@ -626,7 +658,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
                         bad |= (__float_as_uint(Elem<T>::to_f32(c.v[e])) & 0x7F800000u) == 0x7F800000u;
                 }
             }
-        } else {
+        } else if (bw) {
             // the layer below's conv output at this tile's pixels comes in by LDS-DMA too (an ordinary load would make
             // the compiler drain the ring's DMA at its first use): issued BEFORE the ring's next group, waited for with
             // a count that leaves that group in flight; a wave reads back only its own pieces
