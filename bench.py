@@ -229,6 +229,8 @@ def main():
             # functional test only: two PROCESSES time-slicing one GPU, each with a side stream, stall on each
             # other's queue slices (measured 3 s per step); production is one process per GPU
             os.environ["Y2_NO_WGRAD_OVERLAP"] = "1"
+            if args.dist_backend == "nccl":
+                args.dist_backend = "gloo"      # RCCL refuses two ranks on one device
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
