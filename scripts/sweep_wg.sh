@@ -1,4 +1,4 @@
 #!/bin/bash
-# dev sweep: LDS stages of the nine-tap weight gradient (f16, N=64): 11 = 64x32 two stages, 14 = three stages, 50 = 128-pixel K steps
+# dev sweep: ring-form weight gradient of the 208x208 layer (f16, N=64): K-step size and workgroup count
 export Y2_DEV_LIB=1
-SHAPES="26,256,512,3;13,512,1024,3;13,1024,1024,3" python3 scripts/bench_wgrad.py 1:0,11:0,14:0,50:0
+SHAPES="208,32,64,3" python3 scripts/bench_wgrad.py 1:0,31:0,35:0,38:0,44:0,46:0,41:0,40:0

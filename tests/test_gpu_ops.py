@@ -363,3 +363,42 @@ def test_conv2d_random_shapes_forward_and_backward(dtype):
         gate("conv sweep y %s" % dtype, e_y, tol[0])
         gate("conv sweep dx %s" % dtype, e_dx, tol[1])
         gate("conv sweep dw %s" % dtype, e_dw, tol[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_conv_register_filter_forms_at_other_widths(dtype):
+    """conv_rf.hip (filters resident in registers, persistent workgroups over the bordered pixel space) takes the
+    few-channel 3x3 launches on wide maps once the tensor is large: the multi-scale schedule feeds it widths other
+    than 208 / 104 (160 ... 240, 80 ... 120), non-square maps and ragged last tiles.  Forward (with bias), dx and dW of
+    the single-op entry points against torch's CPU convolution; the element-wise gate catches a misplaced tile."""
+    import torch.nn.functional as F
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(77)
+    #        N   H    W   Cin Cout   form exercised
+    cases = [(11, 160, 160, 32, 64),    # 32 -> 64 forward (8 waves x 32 pixels x 64 couts) and its 64 -> 32 dgrad
+             (5, 240, 240, 32, 64),
+             (14, 120, 176, 32, 64),    # non-square
+             (22, 80, 80, 64, 128),     # 64 -> 128 forward (couts over four waves)
+             (10, 120, 120, 64, 128),
+             (16, 104, 88, 64, 128),
+             (22, 80, 80, 128, 64)]     # its plain dgrad (64 -> 128 on dy)
+    tol = {"f16": 8e-4, "bf16": 6e-3}[dtype]
+    for (n, h, w, ci, co) in cases:
+        x = rng.standard_normal((n, h, w, ci)).astype(np.float32)
+        wt = (rng.standard_normal((3, 3, ci, co)) / np.sqrt(9 * ci)).astype(np.float32)
+        b = rng.uniform(-0.5, 0.5, co).astype(np.float32)
+        dy = rng.standard_normal((n, h, w, co)).astype(np.float32)
+        xt = torch.as_tensor(x).permute(0, 3, 1, 2).requires_grad_(True)
+        wtt = torch.as_tensor(wt).permute(3, 2, 0, 1).requires_grad_(True)
+        ref = F.conv2d(xt, wtt, torch.as_tensor(b), padding=1)
+        ref.backward(torch.as_tensor(dy).permute(0, 3, 1, 2))
+        y = E.conv2d(dev(x), dev(wt), dev(b), dtype=dtype).cpu().numpy()
+        dx, dw = E.conv2d_backward(dev(x), dev(wt), dev(dy), dtype=dtype)
+        ry = ref.detach().permute(0, 2, 3, 1).numpy()
+        rdx = xt.grad.permute(0, 2, 3, 1).numpy()
+        gate("conv_rf y %s" % dtype, l2err(y, ry), tol)
+        gate("conv_rf dx %s" % dtype, l2err(dx.cpu().numpy(), rdx), tol)
+        gate("conv_rf dw %s" % dtype, l2err(dw.cpu().numpy(), wtt.grad.permute(2, 3, 1, 0).numpy()), tol)
+        # a misplaced or dropped tile is a large local error that an L2 norm over 10^7 values can hide
+        assert relerr(y, ry) < 20 * tol and relerr(dx.cpu().numpy(), rdx) < 20 * tol, (n, h, w, ci, co)
