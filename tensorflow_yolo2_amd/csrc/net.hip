@@ -825,8 +825,10 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             g.Cin = y.cin_s; g.Cdy = y.ldy; g.Cout = y.cout; g.taps = y.k * y.k; g.splitk = 0; g.scale = inv_gs;
             g.slab = (float*)(c->ws + c->o_slab); g.slab_floats = c->slab_floats;
             hipStream_t ws_ = s;
-            if (c->overlap_wgrad && l > 0 && c->prof != 1) {
-                // fork: the filter gradient only reads x and dY; it fills the bubbles of the dgrad beside it
+            if (c->overlap_wgrad && c->prof != 1) {
+                // fork: the filter gradient only reads x and dY; it fills the bubbles of the dgrad beside it.  The
+                // lowest layer forks too although nothing runs beside it: every weight gradient shares ONE split-K slab,
+                // so they must all queue on one stream (on the caller's stream it raced the side stream's sum kernel)
                 HIPCHK(hipEventRecord(c->ev_fork, s));
                 HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
                 ws_ = c->side;

@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 hipError_t wgrad_split_prepare(WgradArgs& a, hipStream_t s) {
     if (a.splitk <= 1) return hipSuccess;
     const size_t n = (size_t)a.taps * a.Cin * a.Cout;
-    if (a.slab && (n & 3) == 0 && (size_t)a.splitk * n <= a.slab_floats) return hipSuccess;
+    static const bool no_slab = getenv("Y2_NO_WGRAD_SLAB") != nullptr;      // A/B switch: float atomics instead
+    if (!no_slab && a.slab && (n & 3) == 0 && (size_t)a.splitk * n <= a.slab_floats) return hipSuccess;
     a.slab = nullptr;      // atomics into a zeroed dW
     return hipMemsetAsync(a.dW, 0, n * sizeof(float), s);
 }

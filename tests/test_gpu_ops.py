@@ -402,3 +402,41 @@ def test_conv_register_filter_forms_at_other_widths(dtype):
         gate("conv_rf dw %s" % dtype, l2err(dw.cpu().numpy(), wtt.grad.permute(2, 3, 1, 0).numpy()), tol)
         # a misplaced or dropped tile is a large local error that an L2 norm over 10^7 values can hide
         assert relerr(y, ry) < 20 * tol and relerr(dx.cpu().numpy(), rdx) < 20 * tol, (n, h, w, ci, co)
+
+
+RF_STACKS = [
+    # the second layer runs conv_rf's 32 -> 64 forward with statistics and, below a 3-channel pooled first layer
+    # (no fused reduce), its 64 -> 32 dgrad with the early overflow marker's plain epilogue; width 160
+    ("rf 32->64 @160", [(3, 3, 32, 1), (3, 32, 64, 1), (1, 64, 32, 0)], (11, 320, 320, 3)),
+    # the second layer's dgrad (dy 64 channels -> 128) runs conv_rfn with the fused BN-backward reduce of the first
+    ("rfn dgrad + reduce @104", [(1, 32, 128, 0), (3, 128, 64, 0), (1, 64, 32, 0)], (13, 104, 104, 32)),
+    # conv_rfn forward with statistics at a width other than 104 (ragged last tile, 89-position rows)
+    ("rfn fwd @88", [(3, 64, 128, 1), (1, 128, 32, 0)], (18, 88, 88, 64)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,spec,shape", RF_STACKS, ids=[s[0] for s in RF_STACKS])
+def test_register_filter_forms_in_network(name, spec, shape):
+    """The persistent register-filter kernels inside a network (f16): batch statistics from one record per
+    workgroup, BN + leaky + pool, and the backward pass through their dgrad modes -- forward output and every
+    parameter gradient against the float64 oracle with the same storage points quantised (as test_stack_backward)."""
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(31)
+    params = _rand_params(spec, rng)
+    x = rng.uniform(-1, 1, shape).astype(np.float32)
+    net = E.Network(spec, shape[0], shape[1], shape[2], dtype="f16", training=True)
+    net.load_params(params)
+    out = net.forward(dev(x), True, True)
+    q = R.quantizer("f16")
+    ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q)
+    gate("rf stack forward f16", l2err(out.cpu().numpy(), ref), 1e-3)
+    dout = rng.standard_normal(ref.shape).astype(np.float32)
+    net.backward(dev(dout))
+    _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,
+                                     grad_scale=net.grad_scale)
+    grads = net.export_grads()
+    errs = {(l, k): l2err(grads[l][k], rgrads[l][k]) for l in range(len(spec)) for k in ("W", "gamma", "beta")}
+    print("rf stack", name, {"%d%s" % lk: "%.1e" % v for lk, v in errs.items()})
+    for (l, k), v in errs.items():
+        gate("rf stack backward f16 %s" % name, v, 8e-3)     # observed 4.7e-3 (the same value with the kernels off)
