@@ -440,3 +440,10 @@ def test_register_filter_forms_in_network(name, spec, shape):
     print("rf stack", name, {"%d%s" % lk: "%.1e" % v for lk, v in errs.items()})
     for (l, k), v in errs.items():
         gate("rf stack backward f16 %s" % name, v, 8e-3)     # observed 4.7e-3 (the same value with the kernels off)
+    # the backward pass is deterministic (slab sums, no float atomics): repeated passes give the same bits -- a stream
+    # race between the weight gradients showed up exactly here (scripts/diag_race.py)
+    g0 = net.grads.clone()
+    for _ in range(8):
+        net.backward(dev(dout))
+        torch.cuda.synchronize()
+        assert torch.equal(net.grads, g0)
