@@ -347,7 +347,7 @@ def test_backward_is_bit_reproducible():
     give bit-identical gradient buffers"""
     from tensorflow_yolo2_amd import synthetic
     from tensorflow_yolo2_amd.trainer import DetectorTrainer
-    n, size = 8, 416
+    n, size = 16, 416       # large enough for every register-filter convolution form to be selected
     tr = DetectorTrainer(n, size, dtype="f16", seed=2)
     x = dev(synthetic.images(n, size, 5))
     lab = dev(synthetic.det_labels(n, size, size // 32, 6))
