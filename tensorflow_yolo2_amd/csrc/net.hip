@@ -593,7 +593,8 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2;
             a.N = c->N; a.H = y.H; a.W = y.W; a.M = y.M;
             int nb = (y.M + 127) / 128;
-            a.nblocks = nb > 2048 ? 2048 : nb;
+            static const int c1max = getenv("Y2DEV_CONV1_BLOCKS") ? atoi(getenv("Y2DEV_CONV1_BLOCKS")) : 1024;   // records of the first layer (1024 vs 2048: -4 us)
+            a.nblocks = nb > c1max ? c1max : nb;
             P = a.nblocks;
             a.stats_only = pool1 ? 1 : 0;
             if (!pool1 || training) { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
