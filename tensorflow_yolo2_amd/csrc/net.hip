@@ -593,8 +593,7 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
             a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2;
             a.N = c->N; a.H = y.H; a.W = y.W; a.M = y.M;
             int nb = (y.M + 127) / 128;
-            static const int c1max = getenv("Y2DEV_CONV1_BLOCKS") ? atoi(getenv("Y2DEV_CONV1_BLOCKS")) : 1024;   // records of the first layer (1024 vs 2048: -4 us)
-            a.nblocks = nb > c1max ? c1max : nb;
+            a.nblocks = nb > 1024 ? 1024 : nb;      // = statistics records (the plan reserves 2048 rows; 1024 vs 2048: -4 us)
             P = a.nblocks;
             a.stats_only = pool1 ? 1 : 0;
             if (!pool1 || training) { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
