@@ -83,6 +83,12 @@ int y2_params_changed(y2_ctx* ctx);
  * detect time, but nothing updates).  y2_update_moving_stats applies the skipped update afterwards, once. */
 int y2_forward(y2_ctx* ctx, const float* images, int is_training_core, int is_training_head, int update_moving,
                float* out, void* stream);
+/* y2_forward fed with what image_read holds BEFORE its float conversion (src/img_dataset/pascal_voc.py:60-67:
+ * cv2.imread + cv2.resize give uint8 BGR): images_u8 [N,H,W,3] uint8; the conversion
+ * image.astype(float32) / 255.0 * 2.0 - 1.0 (pascal_voc.py:63-64, same fp32 operation order) runs inside the
+ * input pack kernel -- a fed training loop uploads 1 byte per value instead of 4. */
+int y2_forward_u8(y2_ctx* ctx, const uint8_t* images_u8, int is_training_core, int is_training_head,
+                  int update_moving, float* out, void* stream);
 int y2_update_moving_stats(y2_ctx* ctx, void* stream);
 /* TF autodiff of the stack (tf.train.*Optimizer().minimize, pascal_train_darknet.py:49-51):
  * dout has the output's shape; gradients are written to the bound `grads` buffer
@@ -253,6 +259,11 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
               int Cout, int k, int dtype, void* workspace, void* stream);
 int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int N, int H,
                        int W, int Cin, int Cout, int k, int dtype, void* workspace, void* stream);
+
+/* ---- host utility: CRC-32C (Castagnoli) of a host buffer, continuing from `crc` (0 to start).  The checksum of
+ *      TensorFlow's V2 checkpoint files (tensor bundle + table blocks), which the reference reads and writes through
+ *      tf.train.Saver (src/yolo2_nets/net_utils.py:64-110); used by utils/tf_bundle.py on 100-MB tensors. */
+uint32_t y2_crc32c(const void* data, size_t n, uint32_t crc);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -42,6 +42,7 @@ SIGNATURES = {
     "y2_init_params": (_i, [_vp, _u64, _vp]),
     "y2_params_changed": (_i, [_vp]),
     "y2_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "y2_forward_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "y2_update_moving_stats": (_i, [_vp, _vp]),
     "y2_backward": (_i, [_vp, _vp, _i, _i, _vp]),
     "y2_backward_marks": (_i, [_vp, _vp, _i, _pi, _vp]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "y2_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "y2_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "y2_conv2d_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "y2_crc32c": (C.c_uint32, [_vp, _sz, C.c_uint32]),
 }
 
 

@@ -173,6 +173,8 @@ hipError_t wgrad_split_finish(const WgradArgs& a, hipStream_t s);
 
 // ---- packing
 hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H, int W, hipStream_t s);
+// same from uint8 pixels, with image_read's conversion x / 255 * 2 - 1 (src/img_dataset/pascal_voc.py:63-64) fused
+hipError_t launch_pack_input_u8(int dtype, const uint8_t* img, void* x4, int N, int H, int W, hipStream_t s);
 // fwd:  wf[co][t][ci] = W[t][ci][co]           rows co >= Cout zero (Cout_pad rows)
 // dgrad: wd[ci][t'][co] = W[8-t'][ci][co]       rows ci >= Cin zero, cols co >= Cout zero (Cdy cols)
 //   Kc = row length per tap of wf (>= Cin, zero beyond Cin)

@@ -561,10 +561,24 @@ static int pack_all_weights(y2_ctx* c, hipStream_t s) {
     return Y2_OK;
 }
 
+static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8, int train_core, int train_head,
+                        int update_moving, float* out, void* stream);
 int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, int update_moving, float* out,
                void* stream) {
+    if (!images) return fail(Y2_ERR_ARG, "null tensor");
+    return forward_impl(c, images, nullptr, train_core, train_head, update_moving, out, stream);
+}
+int y2_forward_u8(y2_ctx* c, const uint8_t* images_u8, int train_core, int train_head, int update_moving, float* out,
+                  void* stream) {
+    if (!images_u8) return fail(Y2_ERR_ARG, "null tensor");
+    if (c->L.empty() || !c->L[0].first3) return fail(Y2_ERR_ARG, "uint8 input needs the 3-channel image layer first");
+    if (((uintptr_t)images_u8 & 3) != 0) return fail(Y2_ERR_ARG, "uint8 images must be 4-byte aligned");
+    return forward_impl(c, nullptr, images_u8, train_core, train_head, update_moving, out, stream);
+}
+static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8, int train_core, int train_head,
+                        int update_moving, float* out, void* stream) {
     if (!c->ws) return fail(Y2_ERR_STATE, "bind buffers first");
-    if (!images || !out) return fail(Y2_ERR_ARG, "null tensor");
+    if (!out) return fail(Y2_ERR_ARG, "null tensor");
     hipStream_t s = (hipStream_t)stream;
     const size_t sz = c->sz();
     if (c->weights_dirty) {
@@ -587,7 +601,11 @@ int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, i
         // pooled first layer: statistics-only conv, then conv again fused with BN + leaky + pool
         const bool pool1 = y.first3 && l + 1 < nl && y.ldy == 32 && conv1_pool_ok(y.H, y.W, y.pool, y.cout);
         if (y.first3) {
-            { PROF(CAT_MISC); HIPCHK(launch_pack_input(c->dtype, images, xin, c->N, y.H, y.W, s)); }
+            {
+                PROF(CAT_MISC);
+                if (images_u8) HIPCHK(launch_pack_input_u8(c->dtype, images_u8, xin, c->N, y.H, y.W, s));
+                else HIPCHK(launch_pack_input(c->dtype, images, xin, c->N, y.H, y.W, s));
+            }
             Conv1Args a{};
             a.x4 = xin; a.w = c->ws + y.wf; a.y = c->ws + y.y; a.bias = c->params + y.pb;
             a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2;
@@ -1209,6 +1227,39 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
                                   (size_t)Cin * Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     return Y2_OK;
+}
+
+// CRC-32C of a host buffer: the crc32 instruction where the CPU has it, one table otherwise (host code only)
+static uint32_t crc32c_table(const unsigned char* p, size_t n, uint32_t c) {
+    static uint32_t tab[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t v = i;
+            for (int k = 0; k < 8; ++k) v = (v >> 1) ^ ((v & 1) ? 0x82F63B78u : 0u);
+            tab[i] = v;
+        }
+        init = true;
+    }
+    for (size_t i = 0; i < n; ++i) c = tab[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c;
+}
+#if defined(__x86_64__)
+__attribute__((target("sse4.2"))) static uint32_t crc32c_hw(const unsigned char* p, size_t n, uint32_t c) {
+    uint64_t c64 = c;
+    while (n && ((uintptr_t)p & 7)) { c64 = __builtin_ia32_crc32qi((uint32_t)c64, *p++); --n; }
+    for (; n >= 8; n -= 8, p += 8) c64 = __builtin_ia32_crc32di(c64, *(const uint64_t*)p);
+    while (n--) c64 = __builtin_ia32_crc32qi((uint32_t)c64, *p++);
+    return (uint32_t)c64;
+}
+#endif
+uint32_t y2_crc32c(const void* data, size_t n, uint32_t crc) {
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = crc ^ 0xFFFFFFFFu;
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("sse4.2")) return crc32c_hw(p, n, c) ^ 0xFFFFFFFFu;
+#endif
+    return crc32c_table(p, n, c) ^ 0xFFFFFFFFu;
 }
 
 }  // extern "C"

@@ -33,6 +33,70 @@ static hipError_t pack_input_T(const float* img, void* x4, int N, int H, int W, 
     hipLaunchKernelGGL(pack_input_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, img, (T*)x4, N, H, W);
     return hipGetLastError();
 }
+// uint8 pixels -> the same 4-channel bordered image: image.astype(np.float32) / 255.0 * 2.0 - 1.0 in fp32, in the
+// reference's operation order (src/img_dataset/pascal_voc.py:63-64; the division is IEEE-exact, x * 2 is exact, so
+// the result has the bits numpy produces).  Four pixels (12 bytes) per thread: three aligned dword loads.
+Y2_DEV float u8_to_unit(uint32_t b) {
+    float v = (float)b;
+    v = __fdiv_rn(v, 255.0f);
+    v = __fmul_rn(v, 2.0f);
+    return __fsub_rn(v, 1.0f);
+}
+template <typename T>
+__global__ void pack_input_u8_kernel(const uint8_t* __restrict__ img, T* __restrict__ x4, int N, int H, int W) {
+    const size_t total = (size_t)N * H * W;
+    const size_t quads = total / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t* s = (const uint32_t*)(img + q * 12);
+        const uint32_t w0 = s[0], w1 = s[1], w2 = s[2];
+        const uint32_t by[12] = {w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24,
+                                 w1 & 255u, (w1 >> 8) & 255u, (w1 >> 16) & 255u, w1 >> 24,
+                                 w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24};
+        size_t p = q * 4;
+        int w = (int)(p % W);
+        int h = (int)((p / W) % H);
+        int n = (int)(p / ((size_t)W * H));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            T* d = x4 + bpix(n, h, w, H, W) * 4;
+            T o[4] = {Elem<T>::from_f32(u8_to_unit(by[3 * j])), Elem<T>::from_f32(u8_to_unit(by[3 * j + 1])),
+                      Elem<T>::from_f32(u8_to_unit(by[3 * j + 2])), Elem<T>::from_f32(1.f)};
+            if (sizeof(T) == 2) *(u32x2*)d = *(const u32x2*)o;
+            else *(u32x4*)d = *(const u32x4*)o;
+            if (++w == W) { w = 0; if (++h == H) { h = 0; ++n; } }
+        }
+    }
+    // the 0..3 pixels behind the last whole quad
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(total - quads * 4)) {
+        const size_t p = quads * 4 + threadIdx.x;
+        const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
+        const uint8_t* s = img + p * 3;
+        T* d = x4 + bpix(n, h, w, H, W) * 4;
+        d[0] = Elem<T>::from_f32(u8_to_unit(s[0]));
+        d[1] = Elem<T>::from_f32(u8_to_unit(s[1]));
+        d[2] = Elem<T>::from_f32(u8_to_unit(s[2]));
+        d[3] = Elem<T>::from_f32(1.f);
+    }
+}
+template <typename T>
+static hipError_t pack_input_u8_T(const uint8_t* img, void* x4, int N, int H, int W, hipStream_t s) {
+    size_t quads = (size_t)N * H * W / 4;
+    size_t nb = (quads + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(pack_input_u8_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, img, (T*)x4, N, H, W);
+    return hipGetLastError();
+}
+hipError_t launch_pack_input_u8(int dtype, const uint8_t* img, void* x4, int N, int H, int W, hipStream_t s) {
+    if (((uintptr_t)img & 3) != 0) return hipErrorInvalidValue;   // dword loads
+    switch (dtype) {
+        case 0: return pack_input_u8_T<float>(img, x4, N, H, W, s);
+        case 1: return pack_input_u8_T<half_t>(img, x4, N, H, W, s);
+        case 2: return pack_input_u8_T<bf16_t>(img, x4, N, H, W, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H, int W, hipStream_t s) {
     switch (dtype) {
         case 0: return pack_input_T<float>(img, x4, N, H, W, s);

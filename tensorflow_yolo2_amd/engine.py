@@ -188,14 +188,18 @@ class Network:
 
     # ---- execution -------------------------------------------------------
     def forward(self, images, is_training_core=True, is_training_head=True, out=None, update_moving=False):
-        """update_moving: fold the BN moving-statistics update of the training-mode layers into this pass
+        """images: float32 NHWC in [-1, 1) (the reference's placeholder), or uint8 NHWC BGR pixels.
+        update_moving: fold the BN moving-statistics update of the training-mode layers into this pass
         (the train step: UPDATE_OPS under train_op, pascal_train_darknet.py:49-51); False leaves them alone,
         as a sess.run that fetches only the output or the loss does (update_moving_stats() applies it later)."""
-        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        assert images.is_cuda and images.is_contiguous() and images.dtype in (torch.float32, torch.uint8)
         assert tuple(images.shape[:3]) == (self.batch, self.height, self.width), images.shape
         out = self._out if out is None else out
-        check(self.lib.y2_forward(self.h, _ptr(images), int(bool(is_training_core)), int(bool(is_training_head)),
-                                  int(bool(update_moving)), _ptr(out), _stream()))
+        # uint8 BGR pixels (what cv2.imread + cv2.resize hand to image_read, pascal_voc.py:60-62): the conversion
+        # x / 255 * 2 - 1 runs in the input pack kernel
+        fwd = self.lib.y2_forward_u8 if images.dtype == torch.uint8 else self.lib.y2_forward
+        check(fwd(self.h, _ptr(images), int(bool(is_training_core)), int(bool(is_training_head)),
+                  int(bool(update_moving)), _ptr(out), _stream()))
         return out
 
     def update_moving_stats(self):

@@ -83,3 +83,126 @@ def image_read(image_bgr_u8, image_size, flipped=False):
     image = resize_bilinear_u8(image_bgr_u8, image_size, image_size).astype(np.float32)
     image = (image / 255.0) * 2.0 - 1.0
     return image[:, ::-1, :] if flipped else image
+
+
+def imread_bgr(path):
+    """cv2.imread(imname) (pascal_voc.py:61): uint8 [H,W,3] in BGR order.  Decoder: PIL (no OpenCV in this image);
+    libjpeg builds may differ by one level on some pixels, which is why the C1 fixture pins the DECODED input."""
+    from PIL import Image
+    with Image.open(path) as im:
+        rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def flip_label(label, image_size):
+    """the flipped copy of a label grid (pascal_voc.prepare, :74-84): columns mirrored, x -> image_size - 1 - x"""
+    out = label[:, ::-1, :].copy()
+    resp = out[:, :, 0] == 1
+    out[:, :, 1] = np.where(resp, image_size - 1 - out[:, :, 1], out[:, :, 1])
+    return out
+
+
+class pascal_voc(object):
+    """The batcher of src/img_dataset/pascal_voc.py:13-86 (`imdb.get()` feeds one sess.run per step,
+    pascal_train_darknet.py:96-102): VOC2007 devkit layout (ImageSets/Main/<image_set>.txt, JPEGImages/<i>.jpg,
+    Annotations/<i>.xml), images without objects dropped (:116-118), optional flip duplication (:72-85), one
+    shuffle at start and one at every wrap of the cursor (:55-57,86).
+
+    get() returns the reference's (images [B,size,size,3] float32 in [-1,1], labels [B,S,S,25]); get_u8() returns
+    the same batch with the images still uint8 BGR (resized, before / 255 * 2 - 1) for y2_forward_u8, which
+    applies that conversion on the device.  Decoded + resized images are kept in host memory after their first
+    use (cache_images; 520 KB per 416x416 image) -- the reference re-decodes every time."""
+
+    def __init__(self, image_set, batch_size=None, rebuild=False, devkit_path=None, image_size=None, cell_size=None,
+                 flipped=None, seed=0, cache_images=True):
+        import os
+        from .. import config as cfg
+        self.name = 'voc_2007'
+        self.devkit_path = devkit_path or os.path.join('data', 'VOCdevkit')
+        self.data_path = os.path.join(self.devkit_path, 'VOC2007')
+        self.batch_size = cfg.BATCH_SIZE if batch_size is None else batch_size
+        self.image_size = cfg.IMAGE_SIZE if image_size is None else image_size
+        self.cell_size = (self.image_size // 32) if cell_size is None else cell_size
+        self.classes = CLASSES
+        self.num_class = len(CLASSES)
+        self.class_to_ind = dict(zip(self.classes, range(self.num_class)))
+        self.flipped = bool(getattr(cfg, "FLIPPED", False)) if flipped is None else bool(flipped)
+        self.image_set = image_set
+        self.cursor = 0
+        self.rng = np.random.default_rng(seed)
+        self.cache_images = cache_images
+        self._cache = {}
+        assert os.path.exists(self.data_path), 'Path does not exist: {}'.format(self.data_path)
+        self.gt_labels = self.prepare()
+
+    # ---- pascal_voc.py:69-124
+    def load_labels(self):
+        import os
+        txtname = os.path.join(self.data_path, 'ImageSets', 'Main', self.image_set + '.txt')
+        assert os.path.exists(txtname), 'Path does not exist: {}'.format(txtname)
+        with open(txtname) as f:
+            self.image_index = [x.strip() for x in f.readlines() if x.strip()]
+        gt_labels = []
+        for index in self.image_index:
+            imname = os.path.join(self.data_path, 'JPEGImages', index + '.jpg')
+            xml = os.path.join(self.data_path, 'Annotations', index + '.xml')
+            # the reference reads the JPEG for its shape (:131-134); the header is enough
+            from PIL import Image
+            with Image.open(imname) as im:
+                w, h = im.size
+            label, num = load_pascal_annotation(xml, self.image_size, self.cell_size, im_shape=(h, w))
+            if num == 0:
+                continue
+            gt_labels.append({'imname': imname, 'label': label, 'flipped': False})
+        return gt_labels
+
+    def prepare(self):
+        gt_labels = self.load_labels()
+        if self.flipped:
+            gt_labels = gt_labels + [{'imname': g['imname'], 'label': flip_label(g['label'], self.image_size),
+                                      'flipped': True} for g in gt_labels]
+        self.rng.shuffle(gt_labels)
+        return gt_labels
+
+    # ---- pascal_voc.py:60-67
+    def image_read_u8(self, imname, flipped=False):
+        img = self._cache.get(imname)
+        if img is None:
+            img = resize_bilinear_u8(imread_bgr(imname), self.image_size, self.image_size)
+            if self.cache_images:
+                self._cache[imname] = img
+        return img[:, ::-1, :] if flipped else img
+
+    def image_read(self, imname, flipped=False):
+        image = self.image_read_u8(imname, flipped).astype(np.float32)
+        return (image / 255.0) * 2.0 - 1.0
+
+    # ---- pascal_voc.py:42-58
+    def _next(self):
+        g = self.gt_labels[self.cursor]
+        self.cursor += 1
+        if self.cursor >= len(self.gt_labels):
+            self.rng.shuffle(self.gt_labels)
+            self.cursor = 0
+        return g
+
+    def get(self):
+        images = np.zeros((self.batch_size, self.image_size, self.image_size, 3), np.float32)
+        labels = np.zeros((self.batch_size, self.cell_size, self.cell_size, 25), np.float32)
+        for count in range(self.batch_size):
+            g = self._next()
+            images[count] = self.image_read(g['imname'], g['flipped'])
+            labels[count] = g['label']
+        return images, labels
+
+    def get_u8(self, images_out=None, labels_out=None):
+        """the batch get() would return, images as uint8 BGR; writes into caller buffers (pinned memory) if given"""
+        images = np.empty((self.batch_size, self.image_size, self.image_size, 3), np.uint8) if images_out is None \
+            else images_out
+        labels = np.empty((self.batch_size, self.cell_size, self.cell_size, 25), np.float32) if labels_out is None \
+            else labels_out
+        for count in range(self.batch_size):
+            g = self._next()
+            images[count] = self.image_read_u8(g['imname'], g['flipped'])
+            labels[count] = g['label']
+        return images, labels

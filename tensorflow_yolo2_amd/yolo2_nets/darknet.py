@@ -153,10 +153,10 @@ class NetTensor:
     # --- graph plumbing ---------------------------------------------------
     def _network(self, training):
         x = self.inputs
-        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
-            raise TypeError("inputs must be a float32 NHWC torch tensor on the GPU")
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype in (torch.float32, torch.uint8) and x.dim() == 4):
+            raise TypeError("inputs must be a float32 (or uint8 BGR pixel) NHWC torch tensor on the GPU")
         chain = tuple(s for (s, _sp, _t) in self.segments)
-        key = (chain, tuple(x.shape), _DEFAULT_DTYPE, bool(training), self.tail)
+        key = (chain, tuple(x.shape), _DEFAULT_DTYPE, bool(training), self.tail)   # (float32 / uint8 inputs share a network)
         net = _NETWORKS.get(key)
         if net is None:
             spec = [l for (_s, sp, _t) in self.segments for l in sp]

@@ -87,6 +87,11 @@ class _Optimizer:
             store = getattr(net, "store", None)
             if store is not None:
                 store.version += 1
+                # the fused update re-packed THIS context's filter copies already: only the other graphs on the
+                # store need the re-pack the version bump asks for (it re-reads every parameter: 193 MB per step)
+                opt = self._slots(net)
+                if getattr(opt, "fused_pack", False) and net.training:
+                    net._seen_version = store.version
         return train_op
 
 
@@ -144,14 +149,44 @@ def show_yolo_detection(image_path, predict_output, imdb, object_thresh=0.5, sho
 # ---------------------------------------------------------------------------
 # snapshots keyed by the reference's TF variable names (the counterpart of
 # get_ordered_ckpts / restore_darknet19_variables, src/yolo2_nets/net_utils.py:14-110).
-# TF checkpoint FILES are out of scope (no TensorFlow here); the name map is what a converter needs,
-# and these .npz snapshots carry exactly the names tf.train.Saver would write.
+# Two file formats, same names and contents: `.npz` (numpy) and `.ckpt` = TensorFlow's V2 checkpoint
+# (`<prefix>.index` + `<prefix>.data-00000-of-00001`, utils/tf_bundle.py: read and written without TensorFlow), so
+# that the checkpoints the reference's tf.train.Saver writes -- and the author's published ones (README.md:22-24)
+# -- restore into these buffers, and snapshots written here load in the reference.
 # ---------------------------------------------------------------------------
 import glob
 import os
 import re
 
 from . import darknet as _darknet
+from ..utils import tf_bundle as _bundle
+
+
+class _BundleSnap:
+    """np.load-like view of a TF V2 checkpoint"""
+
+    def __init__(self, prefix):
+        self.r = _bundle.BundleReader(prefix)
+        self.files = self.r.names()
+
+    def __getitem__(self, name):
+        return self.r.get_tensor(name)
+
+
+def _ckpt_prefix(path):
+    """the checkpoint prefix if `path` names a TF V2 checkpoint (prefix, .index or .meta file), else None"""
+    for suffix in ("", ".index", ".meta"):
+        if suffix and not path.endswith(suffix):
+            continue
+        prefix = path[:len(path) - len(suffix)] if suffix else path
+        if _bundle.is_bundle(prefix):
+            return prefix
+    return None
+
+
+def _open_snapshot(path):
+    prefix = _ckpt_prefix(path)
+    return _BundleSnap(prefix) if prefix else np.load(path)
 
 
 def _kind_of(network):
@@ -199,24 +234,29 @@ def save_variables(network, path, kind=None, optimizer=None):
                 for k in engine.PARAM_KEYS:
                     blob[nm[k] + "/Adam"] = lm[k]
                     blob[nm[k] + "/Adam_1"] = lv[k]
-            blob["beta1_power"] = np.float64(optimizer.b1) ** st["t"]
-            blob["beta2_power"] = np.float64(optimizer.b2) ** st["t"]
-            blob["adam_step"] = np.int64(st["t"])
+            # TF1's Adam creates beta^1 and multiplies once per apply: after t steps the variables hold beta^(t+1)
+            blob["beta1_power"] = np.float32(np.float64(optimizer.b1) ** (st["t"] + 1))
+            blob["beta2_power"] = np.float32(np.float64(optimizer.b2) ** (st["t"] + 1))
+            blob["adam_step"] = np.int64(st["t"])       # authoritative here (not a TF variable)
         else:
             for la, nm in zip(_slot_views(network, torch.as_tensor(st["accum"])), names):
                 for k in engine.PARAM_KEYS:
                     blob[nm[k] + "/Momentum"] = la[k]
-    np.savez(path, **blob)
+    if path.endswith(".ckpt"):
+        _bundle.write_bundle(path, {k: np.asarray(v) for k, v in blob.items()})
+    else:
+        np.savez(path, **blob)
     return sorted(blob)
 
 
 def restore_variables(network, path, kind=None, optimizer=None):
-    """load the variables whose names are present in the snapshot, leave the others as they are
+    """`path`: an .npz snapshot or a TF V2 checkpoint (prefix `x.ckpt`, or its `.index` / `.meta` file name).
+    load the variables whose names are present in the snapshot, leave the others as they are
     (the reference restores the ImageNet-trained backbone into the detector this way, :83-103).
     A variable present with another shape raises (tf.train.Saver does too).  With `optimizer`, its slots
     are restored when the snapshot holds them.  Returns (restored names, names left untouched)."""
     names = _names(network, kind)
-    snap = np.load(path)
+    snap = _open_snapshot(path)
     layers = network.export_params()
     restored, kept = [], []
     for layer, nm in zip(layers, names):
@@ -242,8 +282,8 @@ def restore_variables(network, path, kind=None, optimizer=None):
                         flat[o[i]:o[i] + a.size] = a.reshape(-1)
             if "adam_step" in snap.files:
                 st["t"] = int(snap["adam_step"])
-            else:   # a converter from a TF checkpoint only has the beta powers
-                st["t"] = int(round(np.log(float(snap["beta1_power"])) / np.log(optimizer.b1)))
+            else:   # a checkpoint written by TF only has the beta powers: beta^(t+1) after t steps
+                st["t"] = max(0, int(round(np.log(float(snap["beta1_power"])) / np.log(optimizer.b1))) - 1)
             optimizer.load_state(st)
         elif "accum" in st and all((nm["W"] + "/Momentum") in snap.files for nm in names):
             flat = st["accum"]
@@ -262,11 +302,13 @@ def get_ordered_ckpts(ckpt_dir, net_name='darknet19', save_epoch=True):
     tag = "epoch" if save_epoch else "iter"
     # reference :27-28: cfg.TRAIN_SNAPSHOT_PREFIX + '_' + save_interval + '_*.ckpt.meta' inside
     # cfg.get_ckpts_dir(net_name, imdb.name); here the caller passes that directory
-    files = [f for f in glob.glob(os.path.join(ckpt_dir, "%s_%s_*.npz" % (cfg.TRAIN_SNAPSHOT_PREFIX, tag)))]
+    stem = os.path.join(ckpt_dir, "%s_%s_*" % (cfg.TRAIN_SNAPSHOT_PREFIX, tag))
+    files = glob.glob(stem + ".npz") + [f[:-len(".index")] for f in glob.glob(stem + ".ckpt.index")]
 
     def key(f):
-        m = re.search(r"_(\d+)\.npz$", f)
-        return (os.path.getmtime(f), int(m.group(1)) if m else 0)
+        m = re.search(r"_(\d+)\.(npz|ckpt)$", f)
+        stamp = os.path.getmtime(f if f.endswith(".npz") else f + ".index")
+        return (stamp, int(m.group(1)) if m else 0)
     return sorted(files, key=key)
 
 
@@ -282,5 +324,5 @@ def restore_darknet19_variables(network, ckpt_dir, net_name='darknet19', save_ep
                 restore_variables(network, prior[-1])
         return 0
     restore_variables(network, sfiles[-1], optimizer=optimizer)
-    m = re.search(r"_(\d+)\.npz$", sfiles[-1])
+    m = re.search(r"_(\d+)\.(npz|ckpt)$", sfiles[-1])
     return int(m.group(1)) if m else 0
