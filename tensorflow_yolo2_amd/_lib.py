@@ -12,6 +12,9 @@ LIB_PATH = os.path.join(_HERE, "libyolo2_hip.so")
 # development tools (scripts/bench_*.py) opt into the `make dev` library, which adds the kernel variant tables
 if os.environ.get("Y2_DEV_LIB") == "1":
     LIB_PATH = os.path.join(_HERE, "libyolo2_hip_dev.so")
+# same-box A/B of two builds (scripts/ab_layers.sh): an explicit library file; it must export the whole header too
+if os.environ.get("Y2_LIB_PATH"):
+    LIB_PATH = os.environ["Y2_LIB_PATH"]
 
 Y2_F32, Y2_F16, Y2_BF16 = 0, 1, 2
 Y2_TAIL_NONE, Y2_TAIL_AVGPOOL = 0, 1
@@ -116,6 +119,8 @@ def load():
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("Y2_LIB_PATH") and not hasattr(lib, name):
+            continue                     # an older build under A/B: its missing entry points simply cannot be called
         fn = getattr(lib, name)          # AttributeError if the symbol is absent
         fn.restype = res
         fn.argtypes = args

@@ -65,13 +65,18 @@ Y2_DEV void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TC][TP], char* smem, 
 
 // same, accumulators of 16x16 MFMA tiles: acc[i16][j16][r] = D[cout i16*16 + 4*(lane>>4) + r][pixel j16*16 + (lane&15)]
 // (TP, TC still count 32-wide units: the wave tile and the patch are the same as above)
-template <typename T, int WP, int WC, int TP, int TC>
+// 16x16 tiles over the compact halo image (conv_haloq.hip): MFMA column c of a 16-pixel fragment holds pixel offset
+// perm16(c) -- lanes {0-3, 12-15} the even pixels, lanes {4-11} the odd ones
+Y2_DEV int perm16(int c) { return c < 4 ? 2 * c : (c >= 12 ? 2 * (c - 8) : 2 * (c - 4) + 1); }
+
+// PERM: the accumulator columns are dealt by perm16 (the patch is written in pixel order either way)
+template <typename T, int WP, int WC, int TP, int TC, bool PERM = false>
 Y2_DEV void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[2 * TC][2 * TP], char* smem, int w, int lane, int m0,
                             int n0, int pt, int ct) {
     typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
     constexpr int SZ = Cfg::SZ, EROW = Cfg::EROW;
     const int wc = w % WC;
-    const int r16 = lane & 15, g4 = lane >> 4;
+    const int r16 = PERM ? perm16(lane & 15) : (lane & 15), g4 = lane >> 4;
     char* ew = smem + w * Cfg::EPW;
     const int cw0 = n0 + wc * TC * 32;
 #pragma unroll

@@ -11,6 +11,29 @@
 // resident: the WP waves that share a cout tile fetch the same lines), prefetched one step
 // ahead.  Only the halo image lives in LDS, so the workgroup barrier falls once per K-chunk
 // (nine tap steps), and the LDS serves a single fragment stream.
+//
+// COMPACT image (CPT; Y2_HALO_COMPACT=1 -- built, measured, NOT the default): the LDS rows follow the NHW pixel index,
+// not the bordered cell index, and every border tap reads one of 16 zero rows.  The bordered image skips a cell at
+// every image-row wrap, so the 16 LDS rows of a ds_read_b128 lane group ({0-3,12-15,20-27}, ...) stop being
+// distinct mod 16 whenever a 32-pixel fragment crosses an image row -- at W = 13 / 26 always: a 2-way bank conflict
+// on nearly every fragment read (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 measured, 0.50 in a bank
+// simulation of the address stream).  In pixel order a tap shift is uniform (kh W + kw) wherever the tap stays
+// inside the image, so a lane group's rows are lambda0 + {0-3,12-15,20-27}: all 16 residues, conflict-free under
+// the row-keyed XOR swizzle for every tap; a tap that leaves the image reads zero row (lambda & 15): the bank
+// position the in-image cell would have had.  The DMA source of an LDS row is a per-row cell index computed once
+// per workgroup (table in LDS); border cells are not staged.  16x16 MFMA tiles mix two k-chunks in a lane group:
+// there the pixel columns of a 16-pixel fragment are dealt so that the first chunk's lanes take the even pixels
+// and the other's the odd ones (perm16), conflict-free for odd and even lambda0 alike; the epilogue patch is
+// written through the same map.  MEASURED (13x13, 1024 -> 1024, batch 64, same box, round 3): conflict ratio
+// 0.50 -> 0.02, LDS-active cycles halved -- and the kernel 4 % SLOWER (181 vs 174 us): the per-(fragment, tap)
+// border select costs 36 more VALU instructions per tap step (87 vs 51 beside 48 MFMAs), and this loop is bound by
+// vector ISSUE, not by the LDS: SQ_WAIT_INST_LDS is 0.9 % of the wave cycles with the conflicts in place.  The
+// conflicts were never on the critical path; the bordered image (uniform shift, no select) stays the default.
+//
+// What did pay in round 3 (both images): the next tap's fragment addresses are computed one step ahead and pinned
+// between the MFMAs (mfma_interleave), k-group g of a fragment row is address ^ (g * 64) instead of a second swizzle,
+// and the filter fragments are loaded by inline asm with hand-counted vmcnt (frag_load) -- together -3 % on the
+// 13x13 / 26x26 layers against the round-2 kernel on the same box.
 #include "common.h"
 #include "conv_epilogue.h"
 #include "kernels.h"
@@ -19,7 +42,35 @@ namespace y2 {
 
 template <int V> struct IntC { static constexpr int value = V; };
 
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB>
+constexpr int kZeroRows = 16;   // compact image: zero rows in front of the image buffers (one per bank position)
+
+// Filter-fragment load the compiler does not see: 16 bytes per lane from a per-lane 64-bit address + immediate.  hipcc waits vmcnt(0) at the first use of ANY load it knows of while an LDS-DMA is in flight
+// (cdna_hip_programming.md, "Three .s-level traps" (b)): with plain loads every other tap step began by draining the
+// fragments it had just requested for the NEXT step -- one exposed L2 round trip per two steps.  These loads are counted
+// by hand instead (frag_wait: `s_waitcnt vmcnt(N)` leaves the N youngest operations in flight; they retire in order).
+template <int IMM>
+Y2_DEV void frag_load(u32x4& dst, const char* lane_ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(lane_ptr), "n"(IMM) : "memory");
+}
+// after the counted wait: the registers now hold the data (orders every consumer behind the wait)
+Y2_DEV void frag_ready(u32x4& v) { asm volatile("" : "+v"(v)); }
+// Order of one scheduling region that holds NM MFMAs, ND ds_reads and address VALU (the next tap's addresses): the
+// VALU and the LDS reads go BETWEEN the MFMAs (which leave vector-issue slots free) instead of in front of them --
+// left alone, hipcc puts all the VALU ahead of the first MFMA, on the critical path behind the LDS wait
+template <int NM, int ND>
+Y2_DEV void mfma_interleave() {
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+        if (k < ND) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read (next k-group's fragments)
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                 // up to three VALU
+    }
+}
+Y2_DEV u32x4 lds_read16(uint32_t lds_addr) {
+    return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)lds_addr;
+}
+
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT>
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int arows) {
     typedef typename Elem<T>::frag frag_t;
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
@@ -42,44 +93,109 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         return (long)bpix(n, h, ww, a.H, a.W);
     };
     const int p_last = (m0 + BP - 1 < a.M) ? m0 + BP - 1 : a.M - 1;
-    const long lo = bpos(m0) - pitch - 1;
-    const int nrows = (int)(bpos(p_last) + pitch + 1 - lo) + 1;
+    const long lo = CPT ? 0 : bpos(m0) - pitch - 1;
+    const int nrows = CPT ? arows : (int)(bpos(p_last) + pitch + 1 - lo) + 1;
     const int npieces = (nrows + RPI - 1) / RPI;
     const int abytes = arows * BKB;
-
-    const int lrow = lane / LPR, lslot = lane % LPR;
     const int rowbytes = a.C * SZ;
+    // compact image: [16 zero rows][image buffer(s): row lambda = pixel (m0 - W - 1 + lambda)][cell index per row]
+    char* const img0 = smem + (CPT ? kZeroRows * BKB : 0);
+    const uint32_t* const cell_tab = (const uint32_t*)(img0 + (ADB ? 2 : 1) * abytes);
+    if (CPT) {
+        uint32_t* tab = (uint32_t*)(img0 + (ADB ? 2 : 1) * abytes);
+        for (int r = tid; r < arows; r += NW * 64) {
+            int q = m0 - a.W - 1 + r;
+            q = q < 0 ? 0 : (q > a.M - 1 ? a.M - 1 : q);      // rows outside the tensor are never read as image cells
+            tab[r] = (uint32_t)bpos(q);
+        }
+        for (int o = tid * 16; o < kZeroRows * BKB; o += NW * 64 * 16) *(u32x4*)(smem + o) = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+
+    const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem
+    const int lrow = lane / LPR, lslot = lane % LPR;
     auto issueA = [&](int c, int ab) {
         const char* xs = xg + lo * (long)rowbytes + (long)c * BKB;
-        char* dst = smem + ab * abytes;
-        for (int i = w; i < npieces; i += NW) {
-            const int row = i * RPI + lrow;
-            const uint32_t off = (uint32_t)row * (uint32_t)rowbytes + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
-            glds16(xs + off, dst + i * 1024);
+        char* dst = img0 + ab * abytes;
+        if (CPT) {
+            // eight table entries first, then their DMAs: an LDS-DMA is an LDS write to the compiler, so a table read
+            // placed behind one waits for it -- piece by piece that was a chain of LDS latencies per chunk
+            for (int i0 = w; i0 < npieces; i0 += 8 * NW) {
+                uint32_t cell[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k * NW;
+                    cell[k] = cell_tab[(i < npieces ? i : i0) * RPI + lrow];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k * NW;
+                    if (i < npieces) {
+                        const int row = i * RPI + lrow;
+                        const uint32_t sw = (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+                        glds16(xs + (size_t)cell[k] * (size_t)rowbytes + sw, dst + i * 1024);
+                    }
+                }
+            }
+        } else {
+            for (int i = w; i < npieces; i += NW) {
+                const int row = i * RPI + lrow;
+                const uint32_t off = (uint32_t)row * (uint32_t)rowbytes + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+                glds16(xs + off, dst + i * 1024);
+            }
         }
     };
     // filter fragments: [cout tile of 32][tap][k-group of 32 bytes][lane][16 B]
     const int kgrow = rowbytes / 32;                     // k-groups per tap
-    const char* wbase[TC];
+    const char* wbase[TC];                               // this lane's 16 bytes of the wave's cout tiles
 #pragma unroll
     for (int i = 0; i < TC; ++i)
         wbase[i] = (const char*)a.w + ((size_t)(n0 / 32 + wc * TC + i) * 9 * kgrow * 64 + lane) * 16;
-    auto loadB = [&](int c, int t, frag_t (&fb)[TC][KG]) {
+    static_assert(KG <= 4, "immediate offsets of the fragment loads");
+    auto loadB = [&](int c, int t, u32x4 (&fb)[TC][KG]) {
         const size_t off = (size_t)(t * kgrow + c * KG) * 1024;
 #pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int g = 0; g < KG; ++g) fb[i][g] = *(const frag_t*)(wbase[i] + off + g * 1024);
+        for (int i = 0; i < TC; ++i) {
+            const char* b = wbase[i] + off;
+            frag_load<0>(fb[i][0], b);
+            if constexpr (KG > 1) frag_load<1024>(fb[i][1], b);
+            if constexpr (KG > 2) frag_load<2048>(fb[i][2], b);
+            if constexpr (KG > 3) frag_load<3072>(fb[i][3], b);
+        }
     };
+    constexpr int NBL = TC * KG;                         // loads per loadB
+    const int kA = w < npieces ? (npieces - 1 - w) / NW + 1 : 0;   // LDS-DMA pieces this wave issues per issueA
 
     const int r32 = lane & 31, hh = lane >> 5;
-    int arow_tl[TP];
+    int rowtlB[TP], fmk[TP];   // byte offset of the top-left tap's image row; CPT: which borders the pixel touches
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
         int p = m0 + (wp * TP + j) * 32 + r32;
         if (p > a.M - 1) p = a.M - 1;
-        arow_tl[j] = (int)(bpos(p) - pitch - 1 - lo);
+        if (CPT) {
+            const int rem = p % hw, h = rem / a.W, ww = rem - h * a.W;
+            fmk[j] = (ww == 0 ? 1 : 0) | (ww == a.W - 1 ? 2 : 0) | (h == 0 ? 4 : 0) | (h == a.H - 1 ? 8 : 0);
+            rowtlB[j] = (p - m0) * BKB;
+        } else {
+            fmk[j] = 0;
+            rowtlB[j] = (int)(bpos(p) - pitch - 1 - lo) * BKB;
+        }
     }
+    // LDS byte offset (from smem) and swizzle key of every pixel fragment row for tap (kh_, kw_) of chunk cc.  A tap that
+    // leaves the image reads zero row (lambda & 15): the bank position of the cell the uniform shift points at
+    auto tap_addr = [&](int kh_, int kw_, int cc, int (&ao)[TP]) {
+        const int shiftB = (kh_ * (CPT ? a.W : pitch) + kw_) * BKB;
+        const int tapm = (kw_ == 0 ? 1 : 0) | (kw_ == 2 ? 2 : 0) | (kh_ == 0 ? 4 : 0) | (kh_ == 2 ? 8 : 0);
+        const int bufB = smem_lds + (CPT ? kZeroRows * BKB : 0) + (ADB ? (cc & 1) : 0) * abytes;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int lamB = rowtlB[j] + shiftB;
+            const int sw = (lamB >> 8) & (LPR - 1);              // (row / RPB) % LPR: RPB rows = one 256-byte bank row
+            const int rowB = (CPT && (fmk[j] & tapm)) ? smem_lds + (lamB & (15 * BKB)) : lamB + bufB;
+            // address of k-group 0; group g sits at this address ^ (g * 32): (2g + hh) ^ sw = (hh ^ sw) ^ 2g
+            ao[j] = rowB + ((hh ^ sw) << 4);
+        }
+    };
 
     f32x16 acc[TC][TP];
 #pragma unroll
@@ -91,9 +207,11 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 
     const int nchunks = rowbytes / BKB;
     const int steps = nchunks * 9;
-    frag_t fbq[2][TC][KG];
+    u32x4 fbq[2][TC][KG];
+    int aoffq[2][TP];                          // fragment-row addresses of the current / the next tap step
     issueA(0, 0);
     loadB(0, 0, fbq[0]);
+    tap_addr(0, 0, 0, aoffq[0]);
     int c = 0, t = 0, kh = 0, kw = 0;
     auto step = [&](auto par, int s) {
         constexpr int P = decltype(par)::value;
@@ -108,44 +226,52 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
             asm volatile("" ::: "memory");
         }
         // next step's filter fragments first (so they never queue behind an image), then the next image
-        {
-            int tn = t + 1, cn = c;
-            if (tn == 9) { tn = 0; ++cn; }
-            if (s + 1 < steps) loadB(cn, tn, fbq[P ^ 1]);
-        }
-        if (ADB && t == 0 && c + 1 < nchunks) issueA(c + 1, (c + 1) & 1);
+        int tn = t + 1, cn = c, khn = kh, kwn = kw + 1;
+        if (kwn == 3) { kwn = 0; ++khn; }
+        if (tn == 9) { tn = 0; ++cn; khn = 0; }
+        const bool more = s + 1 < steps;
+        if (more) loadB(cn, tn, fbq[P ^ 1]);
+        const bool dma = ADB && t == 0 && c + 1 < nchunks;
+        if (dma) issueA(c + 1, (c + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 
-        const char* ab = smem + (ADB ? (c & 1) : 0) * abytes;
-        const int shift = kh * pitch + kw;
-        int aoff[TP], asw[TP];
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int row = arow_tl[j] + shift;
-            aoff[j] = row * BKB;
-            asw[j] = (row / RPB) % LPR;
-        }
         auto load_frags = [&](int g, frag_t (&fp)[TP]) {
 #pragma unroll
-            for (int j = 0; j < TP; ++j) fp[j] = *(const frag_t*)(ab + aoff[j] + (((2 * g + hh) ^ asw[j]) * 16));
+            for (int j = 0; j < TP; ++j)
+                fp[j] = __builtin_bit_cast(frag_t, lds_read16((uint32_t)(aoffq[P][j] ^ (g * 32))));
         };
         frag_t fp0[TP], fp1[TP];
         load_frags(0, fp0);
+        // this step's filter fragments were requested one step ago; younger than them are the image pieces of that
+        // step (t == 1 now) and the fragments just requested.  (t == 0: drained by the chunk wait above.)
+        if (t != 0) {
+            if (t == 1 && ADB && c + 1 < nchunks) wait_vmcnt_dyn((more ? NBL : 0) + kA);
+            else if (more) wait_vmcnt<NBL>();
+            else wait_vmcnt<0>();
+        }
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int g = 0; g < KG; ++g) frag_ready(fbq[P][i][g]);
         __builtin_amdgcn_sched_barrier(0);
+        // the next step's addresses: VALU work that issues beside this step's first MFMAs instead of in front of
+        // the next step's first LDS reads
+        tap_addr(khn, kwn, cn, aoffq[P ^ 1]);
 #pragma unroll
         for (int g = 0; g < KG; g += 2) {
             if (g + 1 < KG) load_frags(g + 1, fp1);
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int j = 0; j < TP; ++j) mma32(acc[i][j], fbq[P][i][g], fp0[j]);
+                for (int j = 0; j < TP; ++j) mma32(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][g]), fp0[j]);
+            if (g == 0) mfma_interleave<TC * TP, TP>();
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < KG) {
                 if (g + 2 < KG) load_frags(g + 2, fp0);
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int j = 0; j < TP; ++j) mma32(acc[i][j], fbq[P][i][g + 1], fp1[j]);
+                    for (int j = 0; j < TP; ++j) mma32(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][g + 1]), fp1[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -168,7 +294,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 //   [cout tile of 16][tap][k-group of 64 bytes][lane = (16-byte chunk)*16 + cout%16][16 B].
 // TP / TC still count 32-wide units, so tiles, LDS image and epilogue patch are those of the kernel above.
 // ---------------------------------------------------------------------------
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB>
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT>
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, int arows) {
     typedef typename Elem<T>::frag frag_t;
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
@@ -192,43 +318,109 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         return (long)bpix(n, h, ww, a.H, a.W);
     };
     const int p_last = (m0 + BP - 1 < a.M) ? m0 + BP - 1 : a.M - 1;
-    const long lo = bpos(m0) - pitch - 1;
-    const int nrows = (int)(bpos(p_last) + pitch + 1 - lo) + 1;
+    const long lo = CPT ? 0 : bpos(m0) - pitch - 1;
+    const int nrows = CPT ? arows : (int)(bpos(p_last) + pitch + 1 - lo) + 1;
     const int npieces = (nrows + RPI - 1) / RPI;
     const int abytes = arows * BKB;
-
-    const int lrow = lane / LPR, lslot = lane % LPR;
     const int rowbytes = a.C * SZ;
+    // compact image: [16 zero rows][image buffer(s): row lambda = pixel (m0 - W - 1 + lambda)][cell index per row]
+    char* const img0 = smem + (CPT ? kZeroRows * BKB : 0);
+    const uint32_t* const cell_tab = (const uint32_t*)(img0 + (ADB ? 2 : 1) * abytes);
+    if (CPT) {
+        uint32_t* tab = (uint32_t*)(img0 + (ADB ? 2 : 1) * abytes);
+        for (int r = tid; r < arows; r += NW * 64) {
+            int q = m0 - a.W - 1 + r;
+            q = q < 0 ? 0 : (q > a.M - 1 ? a.M - 1 : q);      // rows outside the tensor are never read as image cells
+            tab[r] = (uint32_t)bpos(q);
+        }
+        for (int o = tid * 16; o < kZeroRows * BKB; o += NW * 64 * 16) *(u32x4*)(smem + o) = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
+
+    const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem
+    const int lrow = lane / LPR, lslot = lane % LPR;
     auto issueA = [&](int c, int ab) {
         const char* xs = xg + lo * (long)rowbytes + (long)c * BKB;
-        char* dst = smem + ab * abytes;
-        for (int i = w; i < npieces; i += NW) {
-            const int row = i * RPI + lrow;
-            const uint32_t off = (uint32_t)row * (uint32_t)rowbytes + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
-            glds16(xs + off, dst + i * 1024);
+        char* dst = img0 + ab * abytes;
+        if (CPT) {
+            // eight table entries first, then their DMAs: an LDS-DMA is an LDS write to the compiler, so a table read
+            // placed behind one waits for it -- piece by piece that was a chain of LDS latencies per chunk
+            for (int i0 = w; i0 < npieces; i0 += 8 * NW) {
+                uint32_t cell[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k * NW;
+                    cell[k] = cell_tab[(i < npieces ? i : i0) * RPI + lrow];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + k * NW;
+                    if (i < npieces) {
+                        const int row = i * RPI + lrow;
+                        const uint32_t sw = (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+                        glds16(xs + (size_t)cell[k] * (size_t)rowbytes + sw, dst + i * 1024);
+                    }
+                }
+            }
+        } else {
+            for (int i = w; i < npieces; i += NW) {
+                const int row = i * RPI + lrow;
+                const uint32_t off = (uint32_t)row * (uint32_t)rowbytes + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+                glds16(xs + off, dst + i * 1024);
+            }
         }
     };
     const int kgrow = rowbytes / 64;                     // 64-byte k-groups per tap
-    const char* wbase[TC16];
+    const char* wbase[TC16];                             // this lane's 16 bytes of the wave's cout tiles
 #pragma unroll
     for (int i = 0; i < TC16; ++i)
         wbase[i] = (const char*)a.w + ((size_t)(n0 / 16 + wc * TC16 + i) * 9 * kgrow * 64 + lane) * 16;
-    auto loadB = [&](int c, int t, frag_t (&fb)[TC16][KG]) {
+    static_assert(KG <= 4, "immediate offsets of the fragment loads");
+    auto loadB = [&](int c, int t, u32x4 (&fb)[TC16][KG]) {
         const size_t off = (size_t)(t * kgrow + c * KG) * 1024;
 #pragma unroll
-        for (int i = 0; i < TC16; ++i)
-#pragma unroll
-            for (int g = 0; g < KG; ++g) fb[i][g] = *(const frag_t*)(wbase[i] + off + g * 1024);
+        for (int i = 0; i < TC16; ++i) {
+            const char* b = wbase[i] + off;
+            frag_load<0>(fb[i][0], b);
+            if constexpr (KG > 1) frag_load<1024>(fb[i][1], b);
+            if constexpr (KG > 2) frag_load<2048>(fb[i][2], b);
+            if constexpr (KG > 3) frag_load<3072>(fb[i][3], b);
+        }
     };
+    constexpr int NBL = TC16 * KG;                       // loads per loadB
+    const int kA = w < npieces ? (npieces - 1 - w) / NW + 1 : 0;   // LDS-DMA pieces this wave issues per issueA
 
     const int r16 = lane & 15, kc = lane >> 4;
-    int arow_tl[TP16];
+    const int c16 = CPT ? perm16(r16) : r16;      // pixel offset of this lane's MFMA column
+    int rowtlB[TP16], fmk[TP16];   // byte offset of the top-left tap's image row; CPT: which borders the pixel touches
 #pragma unroll
     for (int j = 0; j < TP16; ++j) {
-        int p = m0 + (wp * TP16 + j) * 16 + r16;
+        int p = m0 + (wp * TP16 + j) * 16 + c16;
         if (p > a.M - 1) p = a.M - 1;
-        arow_tl[j] = (int)(bpos(p) - pitch - 1 - lo);
+        if (CPT) {
+            const int rem = p % hw, h = rem / a.W, ww = rem - h * a.W;
+            fmk[j] = (ww == 0 ? 1 : 0) | (ww == a.W - 1 ? 2 : 0) | (h == 0 ? 4 : 0) | (h == a.H - 1 ? 8 : 0);
+            rowtlB[j] = (p - m0) * BKB;
+        } else {
+            fmk[j] = 0;
+            rowtlB[j] = (int)(bpos(p) - pitch - 1 - lo) * BKB;
+        }
     }
+    // LDS byte offset (from smem) and swizzle key of every pixel fragment row for tap (kh_, kw_) of chunk cc.  A tap that
+    // leaves the image reads zero row (lambda & 15): the bank position of the cell the uniform shift points at
+    auto tap_addr = [&](int kh_, int kw_, int cc, int (&ao)[TP16]) {
+        const int shiftB = (kh_ * (CPT ? a.W : pitch) + kw_) * BKB;
+        const int tapm = (kw_ == 0 ? 1 : 0) | (kw_ == 2 ? 2 : 0) | (kh_ == 0 ? 4 : 0) | (kh_ == 2 ? 8 : 0);
+        const int bufB = smem_lds + (CPT ? kZeroRows * BKB : 0) + (ADB ? (cc & 1) : 0) * abytes;
+#pragma unroll
+        for (int j = 0; j < TP16; ++j) {
+            const int lamB = rowtlB[j] + shiftB;
+            const int sw = (lamB >> 8) & (LPR - 1);              // (row / RPB) % LPR: RPB rows = one 256-byte bank row
+            const int rowB = (CPT && (fmk[j] & tapm)) ? smem_lds + (lamB & (15 * BKB)) : lamB + bufB;
+            // address of k-group 0; group g sits at this address ^ (g * 64): (4g + kc) ^ sw = (kc ^ sw) ^ 4g
+            ao[j] = rowB + ((kc ^ sw) << 4);
+        }
+    };
 
     f32x4 acc[TC16][TP16];
 #pragma unroll
@@ -238,9 +430,11 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
 
     const int nchunks = rowbytes / BKB;
     const int steps = nchunks * 9;
-    frag_t fbq[2][TC16][KG];
+    u32x4 fbq[2][TC16][KG];
+    int aoffq[2][TP16];                        // fragment-row addresses of the current / the next tap step
     issueA(0, 0);
     loadB(0, 0, fbq[0]);
+    tap_addr(0, 0, 0, aoffq[0]);
     int c = 0, t = 0, kh = 0, kw = 0;
     auto step = [&](auto par, int s) {
         constexpr int P = decltype(par)::value;
@@ -254,44 +448,50 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        {
-            int tn = t + 1, cn = c;
-            if (tn == 9) { tn = 0; ++cn; }
-            if (s + 1 < steps) loadB(cn, tn, fbq[P ^ 1]);
-        }
-        if (ADB && t == 0 && c + 1 < nchunks) issueA(c + 1, (c + 1) & 1);
+        int tn = t + 1, cn = c, khn = kh, kwn = kw + 1;
+        if (kwn == 3) { kwn = 0; ++khn; }
+        if (tn == 9) { tn = 0; ++cn; khn = 0; }
+        const bool more = s + 1 < steps;
+        if (more) loadB(cn, tn, fbq[P ^ 1]);
+        const bool dma = ADB && t == 0 && c + 1 < nchunks;
+        if (dma) issueA(c + 1, (c + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 
-        const char* ab = smem + (ADB ? (c & 1) : 0) * abytes;
-        const int shift = kh * pitch + kw;
-        int aoff[TP16], asw[TP16];
-#pragma unroll
-        for (int j = 0; j < TP16; ++j) {
-            const int row = arow_tl[j] + shift;
-            aoff[j] = row * BKB;
-            asw[j] = (row / RPB) % LPR;
-        }
         auto load_frags = [&](int g, frag_t (&fp)[TP16]) {
 #pragma unroll
-            for (int j = 0; j < TP16; ++j) fp[j] = *(const frag_t*)(ab + aoff[j] + (((4 * g + kc) ^ asw[j]) * 16));
+            for (int j = 0; j < TP16; ++j)
+                fp[j] = __builtin_bit_cast(frag_t, lds_read16((uint32_t)(aoffq[P][j] ^ (g * 64))));
         };
         frag_t fp0[TP16], fp1[TP16];
         load_frags(0, fp0);
+        // this step's filter fragments were requested one step ago; younger than them are the image pieces of that
+        // step (t == 1 now) and the fragments just requested.  (t == 0: drained by the chunk wait above.)
+        if (t != 0) {
+            if (t == 1 && ADB && c + 1 < nchunks) wait_vmcnt_dyn((more ? NBL : 0) + kA);
+            else if (more) wait_vmcnt<NBL>();
+            else wait_vmcnt<0>();
+        }
+#pragma unroll
+        for (int i = 0; i < TC16; ++i)
+#pragma unroll
+            for (int g = 0; g < KG; ++g) frag_ready(fbq[P][i][g]);
         __builtin_amdgcn_sched_barrier(0);
+        tap_addr(khn, kwn, cn, aoffq[P ^ 1]);   // next step's addresses beside this step's first MFMAs
 #pragma unroll
         for (int g = 0; g < KG; g += 2) {
             if (g + 1 < KG) load_frags(g + 1, fp1);
 #pragma unroll
             for (int i = 0; i < TC16; ++i)
 #pragma unroll
-                for (int j = 0; j < TP16; ++j) mma16(acc[i][j], fbq[P][i][g], fp0[j]);
+                for (int j = 0; j < TP16; ++j) mma16(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][g]), fp0[j]);
+            if (g == 0) mfma_interleave<TC16 * TP16, TP16>();
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < KG) {
                 if (g + 2 < KG) load_frags(g + 2, fp0);
 #pragma unroll
                 for (int i = 0; i < TC16; ++i)
 #pragma unroll
-                    for (int j = 0; j < TP16; ++j) mma16(acc[i][j], fbq[P][i][g + 1], fp1[j]);
+                    for (int j = 0; j < TP16; ++j) mma16(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][g + 1]), fp1[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -303,9 +503,15 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         if (s + 1 < steps) step(IntC<1>{}, s + 1);
     }
     __syncthreads();
-    conv_epilogue16<T, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    conv_epilogue16<T, WP, WC, TP, TC, CPT>(a, acc, smem, w, lane, m0, n0, pt, ct);
 }
 
+// compact image: pixels [m0 - W - 1, m0 + BP + W], rounded up to whole 16-row groups
+static int haloq_rows_compact(int W, int BP) { return (BP + 2 * W + 2 + 15) / 16 * 16; }
+static bool halo_compact() {
+    static const bool on = getenv("Y2_HALO_COMPACT") && atoi(getenv("Y2_HALO_COMPACT")) != 0;
+    return on;
+}
 static int haloq_rows(int H, int W, int BP, int RPI) {
     const int pitch = W + 1;
     const int rows_cross = (BP - 1) / W + 1;
@@ -315,16 +521,23 @@ static int haloq_rows(int H, int W, int BP, int RPI) {
     return (nrows + RPI - 1) / RPI * RPI;
 }
 
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool M16 = false>
+template <int BKB>
+static size_t haloq_lds(int arows, bool adb, bool cpt) {
+    return (size_t)(adb ? 2 : 1) * arows * BKB + (cpt ? (size_t)kZeroRows * BKB + (size_t)arows * 4 : 0);
+}
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool M16, bool CPT>
 static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
     typedef EpiCfg<T, WP, WC, TP, TC> Epi;
     constexpr int BP = WP * TP * 32, BC = WC * TC * 32, RPI = 64 / (BKB / 16);
     if ((a.C * (int)sizeof(T)) % BKB != 0) return hipErrorInvalidValue;
-    const int arows = haloq_rows(a.H, a.W, BP, RPI);
-    size_t lds = (size_t)(ADB ? 2 : 1) * arows * BKB;
+    const int arows = CPT ? haloq_rows_compact(a.W, BP) : haloq_rows(a.H, a.W, BP, RPI);
+    if (CPT && arows > 0xFFFF) return hipErrorOutOfMemory;
+    size_t lds = haloq_lds<BKB>(arows, ADB, CPT);
     if (lds < (size_t)Epi::LDS) lds = Epi::LDS;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    auto kern = M16 ? conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB> : conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB>;
+    void (*kern)(ConvArgs, int);
+    if constexpr (M16) kern = conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT>;
+    else kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT>;
     static size_t attr = 0;
     if (lds > attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -341,9 +554,15 @@ template <typename T, int WP, int WC, int TP, int TC, int BKB, bool M16 = false>
 static hipError_t haloq_pick(const ConvArgs& a, hipStream_t s) {
     constexpr int BP = WP * TP * 32, RPI = 64 / (BKB / 16);
     const int nchunks = a.C * (int)sizeof(T) / BKB;
+    if (halo_compact()) {
+        const int arows = haloq_rows_compact(a.W, BP);
+        if (nchunks > 1 && haloq_lds<BKB>(arows, true, true) <= 150 * 1024)
+            return haloq_launch<T, WP, WC, TP, TC, BKB, true, M16, true>(a, s);
+        return haloq_launch<T, WP, WC, TP, TC, BKB, false, M16, true>(a, s);
+    }
     const size_t arows = haloq_rows(a.H, a.W, BP, RPI);
-    if (nchunks > 1 && 2 * arows * BKB <= 150 * 1024) return haloq_launch<T, WP, WC, TP, TC, BKB, true, M16>(a, s);
-    return haloq_launch<T, WP, WC, TP, TC, BKB, false, M16>(a, s);
+    if (nchunks > 1 && 2 * arows * BKB <= 150 * 1024) return haloq_launch<T, WP, WC, TP, TC, BKB, true, M16, false>(a, s);
+    return haloq_launch<T, WP, WC, TP, TC, BKB, false, M16, false>(a, s);
 }
 
 template <typename T>
