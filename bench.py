@@ -118,24 +118,93 @@ def cpu_baseline(args, spec_core, spec_head):
                       "%dx%d, batch %d, median of %d steps, %d threads" % (size, size, bs, len(times), cores)}
 
 
-def f32_mode(args, images, labels, device, total_flops):
-    """the parity-grade arithmetic (exact-f32 MFMA, the mode the 1e-3 tests gate) timed on the same
-    workload: a short run, reported beside the headline number"""
+def f32_mode(args, images, labels, device, total_flops, igemm_flops):
+    """the parity-grade arithmetic (exact-f32 MFMA, the mode the 1e-3 tests gate) timed on the same workload:
+    2 warm-up + --f32-steps timed steps bracketed like the headline run, with its own roofline sub-record
+    (MFMA convolution launches, union of their HIP-event intervals on every 4th step, against the f32 MFMA peak)"""
     import torch
     from tensorflow_yolo2_amd.trainer import DetectorTrainer
     tr = DetectorTrainer(args.batch, args.image_size, dtype="f32", device=device, seed=0)
-    for _ in range(1):
+    for _ in range(2):
         tr.step(images, labels)
     torch.cuda.synchronize()
     n = max(1, args.f32_steps)
+    sampled = 0
     t0 = time.perf_counter()
-    for _ in range(n):
+    for i in range(n):
+        if i % 4 == 0:
+            tr.net.profile_enable(2 if sampled == 0 else 3)
+            sampled += 1
+        elif i % 4 == 1:
+            tr.net.profile_enable(0)
         tr.step(images, labels)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
+    busy_ms, launches = tr.net.profile_busy()
+    tr.net.profile_collect()
+    tr.net.profile_enable(0)
+    peak = MFMA_PEAK_TFLOPS["f32"]
     tf = total_flops / (ms * 1e-3) / 1e12
-    return {"dtype": "f32", "ms_per_step": ms, "images_per_s": args.batch / (ms * 1e-3), "steps": n,
-            "whole_step_tflops": tf, "peak": MFMA_PEAK_TFLOPS["f32"], "whole_step_frac": tf / MFMA_PEAK_TFLOPS["f32"]}
+    out = {"dtype": "f32", "ms_per_step": ms, "images_per_s": args.batch / (ms * 1e-3), "steps": n, "warmup": 2,
+           "whole_step_tflops": tf, "peak": peak, "whole_step_frac": tf / peak}
+    if busy_ms > 0 and sampled:
+        t = busy_ms / sampled * 1e-3
+        out["roofline"] = {"bound": "mfma", "achieved": igemm_flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                           "frac": igemm_flops / t / 1e12 / peak, "avg_launch_ms": busy_ms / max(launches, 1),
+                           "launches_per_step": launches / sampled, "bracketed_steps": sampled,
+                           "kernel": "MFMA implicit-GEMM convolution launches in exact-f32 MFMA (v_mfma_f32_32x32x2_f32)"}
+    return out
+
+
+def sustained(run, sync_all, steps, batch, world):
+    """a second, longer timed region (no events): the clock the chip holds once DVFS and temperature have settled"""
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    sync_all()
+    el = time.perf_counter() - t0
+    return {"steps": steps, "ms_per_step": el / steps * 1e3, "images_per_s": world * batch * steps / el}
+
+
+def fed_input(args, tr, device, resident_ms):
+    """the fed loop: uint8 batches assembled in pinned memory and uploaded on their own stream while the previous
+    step runs (utils/feeder.py), the float conversion inside the input pack kernel (y2_forward_u8).  The producer
+    copies pre-decoded uint8 images out of a host pool (what img_dataset.pascal_voc.get_u8 does with its cache)."""
+    import numpy as np
+    import torch
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.utils.feeder import DeviceFeeder
+    bs, size, S = args.batch, args.image_size, args.image_size // 32
+    rng = np.random.default_rng(7)
+    pool = rng.integers(0, 256, (4 * bs, size, size, 3), dtype=np.uint8)
+    labs = synthetic.det_labels(4 * bs, size, S, 99)
+    state = {"k": 0}
+
+    def produce(im, lab):
+        k = state["k"] % 4
+        im[...] = pool[k * bs:(k + 1) * bs]
+        lab[...] = labs[k * bs:(k + 1) * bs]
+        state["k"] += 1
+    feeder = DeviceFeeder(produce, bs, size, S, device=device)
+    n = max(1, args.fed_steps)
+
+    def one():
+        img, lab = feeder.get()
+        tr.step(img, lab)
+        feeder.release()
+        feeder.prefetch()
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return {"steps": n, "ms_per_step": ms, "images_per_s": bs / (ms * 1e-3), "vs_resident_input": ms / resident_ms,
+            "upload_bytes_per_step": bs * size * size * 3 + bs * S * S * 25 * 4,
+            "path": "pinned double buffer -> upload stream (uint8, 1 B per value) -> y2_forward_u8"}
 
 
 def bench_yolov2(args, images, labels, device, rank, world, dist):
@@ -152,11 +221,31 @@ def bench_yolov2(args, images, labels, device, rank, world, dist):
     for _ in range(args.warmup):
         tr.step(images, labels)
     sync_all()
+    nets = tr.networks()
+    stride, sampled = max(1, args.event_stride), 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if args.kernel_events == "timed":
+            if i % stride == 0:
+                for nt in nets:
+                    nt.profile_enable(2 if sampled == 0 else 3)
+                sampled += 1
+            elif i % stride == 1 or stride == 1:
+                for nt in nets:
+                    nt.profile_enable(0)
         tr.step(images, labels)
     sync_all()
     elapsed = time.perf_counter() - t0
+    # the three stacks run one after the other (each y2_backward joins its side stream before it returns), so the
+    # union of all MFMA launch intervals is the sum of the three stacks' unions
+    busy_ms, launches = 0.0, 0
+    if args.kernel_events == "timed":
+        for nt in nets:
+            b = nt.profile_busy()
+            busy_ms += b[0]
+            launches += b[1]
+            nt.profile_collect()
+            nt.profile_enable(0)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -166,6 +255,15 @@ def bench_yolov2(args, images, labels, device, rank, world, dist):
         ms = elapsed / args.steps * 1e3
         flops = tr.flops_per_step()
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        roof = {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "kernel": "MFMA implicit-GEMM convolution launches of the three stacks (forward, dgrad, wgrad); time = "
+                          "union of the launch intervals", "whole_step_frac": flops / (ms * 1e-3) / 1e12 / peak}
+        if busy_ms > 0 and sampled:
+            t_ig = busy_ms / sampled * 1e-3
+            ig = tr.flops_per_step(mfma_launches_only=True)
+            roof.update({"achieved": ig / t_ig / 1e12, "frac": ig / t_ig / 1e12 / peak,
+                         "avg_launch_ms": busy_ms / max(launches, 1), "launches_per_step": launches / sampled,
+                         "bracketed_steps": sampled, "flops_per_launch": ig / max(launches / sampled, 1)})
         out = {"metric": "images/sec fwd+bwd YOLOv2 (Darknet-19 + passthrough + anchor loss) 416x416",
                "value": world * args.batch * args.steps / elapsed, "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -176,9 +274,7 @@ def bench_yolov2(args, images, labels, device, rank, world, dist):
                           "image_size": args.image_size, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                           "S": args.image_size // 32, "B": tr.B, "parallelism": "dp%d" % world},
                "whole_step_tflops": flops / (ms * 1e-3) / 1e12,
-               "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                            "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None,
-                            "kernel": "whole step (algorithmic conv FLOPs / wall time)"}}
+               "roofline": roof}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
@@ -200,7 +296,9 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)     # bs 8
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
     ap.add_argument("--no-f32-mode", action="store_true")
-    ap.add_argument("--f32-steps", type=int, default=3)
+    ap.add_argument("--f32-steps", type=int, default=12)
+    ap.add_argument("--sustain-steps", type=int, default=300, help="extra timed region without events (0: skip)")
+    ap.add_argument("--fed-steps", type=int, default=30, help="fed-input leg: uint8 upload pipeline (0: skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: core forward only (inference BN)")
     ap.add_argument("--model", default="detector", choices=["detector", "yolov2"],
                     help="detector: the reference's Darknet-19 grid detector (the headline); yolov2: the north star's "
@@ -304,10 +402,14 @@ def main():
         if prof is None:
             prof = prof_all
 
+    sus = sustained(run, sync_all, args.sustain_steps, bs, world) if args.sustain_steps > 0 else None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed] + ([sus["ms_per_step"]] if sus else []), dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if sus:
+            sus["ms_per_step"] = float(t[1].item())
+            sus["images_per_s"] = world * bs / (sus["ms_per_step"] * 1e-3)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * bs * args.steps / elapsed
@@ -342,13 +444,15 @@ def main():
         # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (separate
         # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction), bytes per launch
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
+            tpath = [q for q in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+                     if os.path.exists(os.path.join(ROOT, "profiles", q))][0]
+            tj = json.load(open(os.path.join(ROOT, "profiles", tpath)))
             sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k or "conv_rf" in k or
                    "wgrad9" in k or "wgrad_kernel" in k]
             nl = sum(v["launches"] for v in sel)
             if nl and not args.forward_only and bs == 64 and size == 416 and args.dtype == "f16":
                 roof["traffic"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in sel) / nl
-                roof["traffic_source"] = "profiles/r02_pmc_hbm_traffic.json (same command, earlier run)"
+                roof["traffic_source"] = "profiles/%s (same command, earlier run)" % tpath
         except (OSError, ValueError, KeyError):
             pass
         if roof.get("avg_launch_ms"):
@@ -372,11 +476,18 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        if sus is not None:
+            out["sustained"] = sus
+        if world == 1 and not args.forward_only and args.fed_steps > 0:
+            try:
+                out["fed_input"] = fed_input(args, tr, device, ms_per_step)
+            except Exception as e:
+                out["fed_input"] = {"error": repr(e)}
         if world == 1 and not args.forward_only and not args.no_f32_mode and args.dtype != "f32":
             try:
                 del tr, net, run
                 torch.cuda.empty_cache()
-                out["f32_mode"] = f32_mode(args, images, labels, device, total_flops)
+                out["f32_mode"] = f32_mode(args, images, labels, device, total_flops, igemm_flops)
             except Exception as e:
                 out["f32_mode"] = {"dtype": "f32", "ms_per_step": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.forward_only:

@@ -157,6 +157,9 @@ int y2_passthrough_concat_backward(const float* dout, float* dfine, float* dcoar
 /* dst += src on fp32 buffers: the gradient of a tensor with two consumers (the 26x26x512 activation feeds the pool
  * and the passthrough) */
 int y2_accumulate(float* dst, const float* src, size_t n, void* stream);
+/* x *= s: the loss scale in front of a half-precision backward pass of a composed graph (no reference counterpart:
+ * the reference runs fp32) */
+int y2_scale(float* x, size_t n, float s, void* stream);
 /* anchor decode: net [N,S,S,B,5+C] (tx,ty,tw,th,to,classes), anchors [B][2] in cell units ->
  * boxes [N,S*S*B,4] (cx,cy,w,h relative to the image), scores [N,S*S*B,C] = sigmoid(to)*softmax(classes) */
 int y2_decode_anchors(const float* net, const float* anchors, float* boxes, float* scores, int N, int S, int B, int C,

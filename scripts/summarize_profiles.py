@@ -2,7 +2,8 @@
 
     python scripts/summarize_profiles.py stats <dir> <out.csv> [steps]
         <dir> holds *_kernel_stats.csv of `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`;
-        writes the per-kernel table (calls, total, average, percentage) and, with `steps`, ms per step.
+        writes the per-kernel table (calls, total, average, percentage) and, with `steps`, ms per step --
+        `steps` = EVERY step the traced command ran (warm-up + timed: round 2 divided by the timed steps only).
     python scripts/summarize_profiles.py pmc <fetch_dir> <write_dir> <out.json>
         the two directories hold *_counter_collection.csv of separate `--pmc FETCH_SIZE` and
         `--pmc WRITE_SIZE` passes of the same command.  Per kernel: launches, average counter values (KB)
@@ -13,6 +14,8 @@
         per-dispatch timeline (start, end relative to the step's first launch, in us) of the LAST step and, in
         the header comment, what bench.py's roofline uses: the length of the UNION of the MFMA convolution
         launches' intervals, their summed durations and the step's span.
+    python scripts/summarize_profiles.py gbps <stats.csv> <hbm.json> <out.csv>
+        HBM bytes per launch (pmc summary, FETCH doubled) / average launch duration (stats summary) per kernel.
     python scripts/summarize_profiles.py sq <dir> <out.csv>
         <dir> holds *_counter_collection.csv of one `--pmc SQ_...` pass; per kernel: launches and the average of
         every counter, plus MFMA busy / CU busy and LDS conflict ratios where the inputs are present.
@@ -161,11 +164,33 @@ def sq(d, out):
     print("wrote", out, len(acc), "kernels")
 
 
+def gbps(stats_csv, hbm_json, out):
+    st = {r["kernel"]: r for r in csv.DictReader(open(stats_csv))}
+    hb = json.load(open(hbm_json))
+    rows = []
+    for k, v in hb.items():
+        r = st.get(k)
+        if r is None:
+            continue
+        us = float(r["avg_us"])
+        b = v["hbm_bytes_per_launch_corrected"]
+        rows.append((float(r["total_us"]), k, r["calls"], us, b, b / (us * 1e-6) / 1e9 if us > 0 else 0.0))
+    rows.sort(reverse=True)
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "avg_us", "hbm_MB_per_launch(FETCHx2+WRITE)", "GB_per_s", "frac_of_8TBps"])
+        for _t, k, calls, us, b, g in rows:
+            w.writerow([k, calls, "%.2f" % us, "%.2f" % (b / 1e6), "%.0f" % g, "%.3f" % (g / 8000.0)])
+    print("wrote", out, len(rows), "kernels")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 1)
     elif sys.argv[1] == "sq":
         sq(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "gbps":
+        gbps(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else None)
     else:

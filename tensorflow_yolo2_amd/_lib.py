@@ -68,6 +68,7 @@ SIGNATURES = {
     "y2_passthrough_concat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_passthrough_concat_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_accumulate": (_i, [_vp, _vp, _sz, _vp]),
+    "y2_scale": (_i, [_vp, _sz, _f, _vp]),
     "y2_decode_anchors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp]),
     "y2_yolov2_loss_workspace_bytes": (_sz, [_i]),

@@ -482,6 +482,20 @@ int y2_accumulate(float* dst, const float* src, size_t n, void* stream) {
     return Y2_OK;
 }
 
+// x *= s (loss scaling of an output gradient in front of a half-precision backward pass)
+__global__ void scale_kernel(float* __restrict__ x, size_t n, float s) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+int y2_scale(float* x, size_t n, float s, void* stream) {
+    if (!x) return fail(Y2_ERR_ARG, "null tensor");
+    if (n == 0) return Y2_OK;
+    size_t nb = (n + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, n, s);
+    EXTCHK(hipGetLastError());
+    return Y2_OK;
+}
+
 size_t y2_yolov2_loss_workspace_bytes(int batch) { return (size_t)batch * 4 * sizeof(float) + 256; }
 
 int y2_yolov2_loss(const float* net, const float* labels, const float* anchors, int batch, int S, int B, int num_class,

@@ -733,6 +733,11 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         HIPCHK(launch_convert_grad(c->dtype, src, dA[0], y.M, y.cout, y.ldy, c->grad_scale, s));
         // every gradient element is written with a plain store each step (split-K partials go through the slab
         // and a fixed-order sum: wgrad.hip); the kernels that still add with atomics zero their own target
+        // A pass that starts at the top but stops above layer 0 leaves the gradients of [0, layer_lo) unwritten: zero
+        // them, so that an optimizer step over the whole flat buffer does not re-apply the previous step's values
+        // (the per-step zero-fill of the whole buffer went away with the split-K slab).  Sliced passes
+        // continue downwards with layer_hi < nl and overwrite their own ranges.
+        if (layer_lo > 0 && c->grads) HIPCHK(hipMemsetAsync(c->grads, 0, c->L[layer_lo].pW * sizeof(float), s));
     }
     float* psum = (float*)(c->ws + c->o_psum);
     bool forked = false;

@@ -51,8 +51,13 @@ def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, 
 class ResNet50Yolo:
     """resnet_v1_50 + the YOLO fully connected head, forward / backward / Adam(0.0005)"""
 
-    def __init__(self, batch, image_size=224, B=2, num_class=20, dtype="f16", blocks=None, root_depth=64,
-                 fc_hidden=4096, seed=0, device="cuda:0", learning_rate=0.0005, keep_prob=0.5):
+    def __init__(self, batch, image_size=224, B=2, num_class=20, dtype="f32", blocks=None, root_depth=64,
+                 fc_hidden=4096, seed=0, device="cuda:0", learning_rate=0.0005, keep_prob=0.5, loss_scale=None):
+        """dtype: arithmetic of the convolution / FC contractions.  "f32" (default: the reference's precision).  With
+        "f16" the gradient of the loss is multiplied by a dynamic loss scale before the backward pass (activation
+        gradients 50 layers deep at batch 4 fall below f16's normal range otherwise), the scale is divided out inside
+        the optimizer, and the update is the overflow-guarded Adam (an inf / NaN anywhere skips the step on the
+        device and halves the scale) -- the policy of the Darknet path (engine.LossScaler)."""
         assert image_size % 32 == 0
         self.batch, self.size, self.S, self.B, self.num_class = batch, image_size, image_size // 32, B, num_class
         self.dtype, self.device, self.keep_prob = dtype, torch.device(device), keep_prob
@@ -82,6 +87,10 @@ class ResNet50Yolo:
         self.drop_seed = seed * 7919 + 1
         self.init_params(seed)
         self.tape = None
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if dtype == "f16" else 1.0)
+        self.guard = dtype != "f32"
+        self.ctrl = torch.zeros(8, dtype=torch.int32, device=self.device)     # found_inf, step, skipped, -, lr_t
+        self.overflows, self._clean, self.growth_interval = 0, 0, 1000
 
     # ---- variables ---------------------------------------------------------
     def init_params(self, seed=0):
@@ -252,11 +261,32 @@ class ResNet50Yolo:
         """one iteration of pascal_train_resnet.py:49-62: get_loss + AdamOptimizer(0.0005).minimize"""
         grid = self.forward(images, True, update_moving=True)
         loss, ious, mask, dnet = E.yolo_loss(grid, labels, self.num_class, self.batch, self.size, self.S, self.B)
-        self.backward(dnet)
-        self.t += 1
         lib = E._lib.load()
-        E.check(lib.y2_adam_step(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads),
-                                 self.params.numel(), self.t, self.lr, 0.9, 0.999, 1e-8, 1.0, E._stream()))
+        if self.loss_scale != 1.0:
+            E.check(lib.y2_scale(E._ptr(dnet), dnet.numel(), self.loss_scale, E._stream()))
+        self.backward(dnet)
+        n = self.params.numel()
+        if not self.guard:
+            self.t += 1
+            E.check(lib.y2_adam_step(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n, self.t,
+                                     self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+            return loss, ious, mask
+        # half precision: full overflow scan, then the guarded update (skipped as a whole on the device when any
+        # gradient is inf / NaN; the step counter and TF's lr_t live in ctrl)
+        E.check(lib.y2_grad_check_full(E._ptr(self.grads), n, E._ptr(self.ctrl), E._stream()))
+        E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
+                                         E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+        c = self.ctrl.cpu()                      # this untuned batch-4 path can afford the host read every step
+        self.t = int(c[1])
+        if int(c[0]):
+            self.overflows += 1
+            self._clean = 0
+            self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+        else:
+            self._clean += 1
+            if self._clean >= self.growth_interval and self.loss_scale < 65536.0:
+                self._clean = 0
+                self.loss_scale *= 2.0
         return loss, ious, mask
 
 

@@ -150,14 +150,20 @@ class YOLOv2Trainer:
             opt.step(grad_mult=1.0 / world)
         return loss
 
-    def flops_per_step(self, size=None):
-        """algorithmic FLOPs of one train step (3 x forward conv FLOPs, SURVEY 8(d) convention)"""
+    def networks(self, size=None):
+        """the three stack contexts (stem, 13x13 stack, head) of an input size"""
+        return self._nets(size or self.default_size)
+
+    def flops_per_step(self, size=None, mfma_launches_only=False):
+        """algorithmic FLOPs of one train step (3 x forward conv FLOPs, SURVEY 8(d) convention);
+        mfma_launches_only: without the 3-channel first layer, which has its own (non-GEMM) kernels"""
         size = size or self.default_size
         tot = 0.0
         for spec, h0 in zip(self.specs, (size, size // 32, size // 32)):
             h = h0
             for (k, ci, co, pool) in spec:
-                tot += 2.0 * self.batch * h * h * k * k * ci * co
+                if not (mfma_launches_only and ci == 3):
+                    tot += 2.0 * self.batch * h * h * k * k * ci * co
                 if pool:
                     h = (h + 1) // 2
         return 3.0 * tot
