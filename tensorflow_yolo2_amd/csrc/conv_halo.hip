@@ -344,6 +344,16 @@ static int dev_rule(int W, int Cout) {
 // 2: 16-row fragments (conv_haloq on 16x16x32 tiles: the 384 x 128 tile class up to 26x26, +3-4 %).
 // row_bytes = input channels * element size of the launch (forward: cin_s, dgrad: ldy).
 int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad) {
+    if (taps == 1) {
+        // 1x1 on conv_haloq (one tap per K-chunk, compact image): 128-byte K chunks, more than 64 output channels, enough
+        // pixels for 384-pixel tiles; 384 x 64 tiles on 32x32 MFMAs (layout 1) where 384 x 128 tiles would leave CUs
+        // idle, else 384 x 128 on 16x16 MFMAs (layout 2).  Opt-in (Y2_HALOQ_1X1=1): measured no faster than conv_igemm
+        // (conv_haloq.hip, haloq_T1)
+        static const bool on = getenv("Y2_HALOQ_1X1") && atoi(getenv("Y2_HALOQ_1X1")) != 0;
+        if (!on || (row_bytes % 128) != 0 || Cout <= 64 || M < 384 * 8) return 0;
+        const bool narrow = ((M + 383) / 384) * ((Cout + 127) / 128) < 160;
+        return narrow ? 1 : 2;
+    }
     if (taps != 9) return 0;
     if (conv_rf_config(taps, W, row_bytes, Cout, M) || conv_rfn_config(taps, W, row_bytes, Cout, M, dgrad)) return 0;    // register-resident filters: fetched from K-contiguous rows
     if (!(W <= 26 || (W > 52 && W <= 104) || (W > 104 && Cout <= 32))) return 0;

@@ -70,8 +70,9 @@ Y2_DEV u32x4 lds_read16(uint32_t lds_addr) {
     return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)lds_addr;
 }
 
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT>
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT, int TAPS>
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int arows) {
+    static_assert(TAPS == 9 || (TAPS == 1 && CPT), "1x1 filters run on the compact image (no halo, no border taps)");
     typedef typename Elem<T>::frag frag_t;
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
     constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB, KG = BKB / 32;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     if (CPT) {
         uint32_t* tab = (uint32_t*)(img0 + (ADB ? 2 : 1) * abytes);
         for (int r = tid; r < arows; r += NW * 64) {
-            int q = m0 - a.W - 1 + r;
+            int q = m0 - (TAPS == 9 ? a.W + 1 : 0) + r;
             q = q < 0 ? 0 : (q > a.M - 1 ? a.M - 1 : q);      // rows outside the tensor are never read as image cells
             tab[r] = (uint32_t)bpos(q);
         }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     const char* wbase[TC];                               // this lane's 16 bytes of the wave's cout tiles
 #pragma unroll
     for (int i = 0; i < TC; ++i)
-        wbase[i] = (const char*)a.w + ((size_t)(n0 / 32 + wc * TC + i) * 9 * kgrow * 64 + lane) * 16;
+        wbase[i] = (const char*)a.w + ((size_t)(n0 / 32 + wc * TC + i) * TAPS * kgrow * 64 + lane) * 16;
     static_assert(KG <= 4, "immediate offsets of the fragment loads");
     auto loadB = [&](int c, int t, u32x4 (&fb)[TC][KG]) {
         const size_t off = (size_t)(t * kgrow + c * KG) * 1024;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     // leaves the image reads zero row (lambda & 15): the bank position of the cell the uniform shift points at
     auto tap_addr = [&](int kh_, int kw_, int cc, int (&ao)[TP]) {
         const int shiftB = (kh_ * (CPT ? a.W : pitch) + kw_) * BKB;
-        const int tapm = (kw_ == 0 ? 1 : 0) | (kw_ == 2 ? 2 : 0) | (kh_ == 0 ? 4 : 0) | (kh_ == 2 ? 8 : 0);
+        const int tapm = TAPS == 9 ? ((kw_ == 0 ? 1 : 0) | (kw_ == 2 ? 2 : 0) | (kh_ == 0 ? 4 : 0) | (kh_ == 2 ? 8 : 0)) : 0;
         const int bufB = smem_lds + (CPT ? kZeroRows * BKB : 0) + (ADB ? (cc & 1) : 0) * abytes;
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     const int nchunks = rowbytes / BKB;
-    const int steps = nchunks * 9;
+    const int steps = nchunks * TAPS;
     u32x4 fbq[2][TC][KG];
     int aoffq[2][TP];                          // fragment-row addresses of the current / the next tap step
     issueA(0, 0);
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         // next step's filter fragments first (so they never queue behind an image), then the next image
         int tn = t + 1, cn = c, khn = kh, kwn = kw + 1;
         if (kwn == 3) { kwn = 0; ++khn; }
-        if (tn == 9) { tn = 0; ++cn; khn = 0; }
+        if (tn == TAPS) { tn = 0; ++cn; khn = 0; kwn = 0; }
         const bool more = s + 1 < steps;
         if (more) loadB(cn, tn, fbq[P ^ 1]);
         const bool dma = ADB && t == 0 && c + 1 < nchunks;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
             }
         }
         if (++kw == 3) { kw = 0; ++kh; }
-        if (++t == 9) { t = 0; kh = 0; ++c; }
+        if (++t == TAPS) { t = 0; kh = 0; kw = 0; ++c; }
     };
     for (int s = 0; s < steps; s += 2) {
         step(IntC<0>{}, s);
@@ -294,8 +295,9 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 //   [cout tile of 16][tap][k-group of 64 bytes][lane = (16-byte chunk)*16 + cout%16][16 B].
 // TP / TC still count 32-wide units, so tiles, LDS image and epilogue patch are those of the kernel above.
 // ---------------------------------------------------------------------------
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT>
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT, int TAPS>
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, int arows) {
+    static_assert(TAPS == 9 || (TAPS == 1 && CPT), "1x1 filters run on the compact image (no halo, no border taps)");
     typedef typename Elem<T>::frag frag_t;
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
     constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB, KG = BKB / 64;   // k-groups of 64 bytes
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     if (CPT) {
         uint32_t* tab = (uint32_t*)(img0 + (ADB ? 2 : 1) * abytes);
         for (int r = tid; r < arows; r += NW * 64) {
-            int q = m0 - a.W - 1 + r;
+            int q = m0 - (TAPS == 9 ? a.W + 1 : 0) + r;
             q = q < 0 ? 0 : (q > a.M - 1 ? a.M - 1 : q);      // rows outside the tensor are never read as image cells
             tab[r] = (uint32_t)bpos(q);
         }
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     const char* wbase[TC16];                             // this lane's 16 bytes of the wave's cout tiles
 #pragma unroll
     for (int i = 0; i < TC16; ++i)
-        wbase[i] = (const char*)a.w + ((size_t)(n0 / 16 + wc * TC16 + i) * 9 * kgrow * 64 + lane) * 16;
+        wbase[i] = (const char*)a.w + ((size_t)(n0 / 16 + wc * TC16 + i) * TAPS * kgrow * 64 + lane) * 16;
     static_assert(KG <= 4, "immediate offsets of the fragment loads");
     auto loadB = [&](int c, int t, u32x4 (&fb)[TC16][KG]) {
         const size_t off = (size_t)(t * kgrow + c * KG) * 1024;
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     // leaves the image reads zero row (lambda & 15): the bank position of the cell the uniform shift points at
     auto tap_addr = [&](int kh_, int kw_, int cc, int (&ao)[TP16]) {
         const int shiftB = (kh_ * (CPT ? a.W : pitch) + kw_) * BKB;
-        const int tapm = (kw_ == 0 ? 1 : 0) | (kw_ == 2 ? 2 : 0) | (kh_ == 0 ? 4 : 0) | (kh_ == 2 ? 8 : 0);
+        const int tapm = TAPS == 9 ? ((kw_ == 0 ? 1 : 0) | (kw_ == 2 ? 2 : 0) | (kh_ == 0 ? 4 : 0) | (kh_ == 2 ? 8 : 0)) : 0;
         const int bufB = smem_lds + (CPT ? kZeroRows * BKB : 0) + (ADB ? (cc & 1) : 0) * abytes;
 #pragma unroll
         for (int j = 0; j < TP16; ++j) {
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         for (int j = 0; j < TP16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = rowbytes / BKB;
-    const int steps = nchunks * 9;
+    const int steps = nchunks * TAPS;
     u32x4 fbq[2][TC16][KG];
     int aoffq[2][TP16];                        // fragment-row addresses of the current / the next tap step
     issueA(0, 0);
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         }
         int tn = t + 1, cn = c, khn = kh, kwn = kw + 1;
         if (kwn == 3) { kwn = 0; ++khn; }
-        if (tn == 9) { tn = 0; ++cn; khn = 0; }
+        if (tn == TAPS) { tn = 0; ++cn; khn = 0; kwn = 0; }
         const bool more = s + 1 < steps;
         if (more) loadB(cn, tn, fbq[P ^ 1]);
         const bool dma = ADB && t == 0 && c + 1 < nchunks;
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
             }
         }
         if (++kw == 3) { kw = 0; ++kh; }
-        if (++t == 9) { t = 0; kh = 0; ++c; }
+        if (++t == TAPS) { t = 0; kh = 0; kw = 0; ++c; }
     };
     for (int s = 0; s < steps; s += 2) {
         step(IntC<0>{}, s);
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
 }
 
 // compact image: pixels [m0 - W - 1, m0 + BP + W], rounded up to whole 16-row groups
-static int haloq_rows_compact(int W, int BP) { return (BP + 2 * W + 2 + 15) / 16 * 16; }
+static int haloq_rows_compact(int W, int BP, int taps = 9) { return (BP + (taps == 9 ? 2 * W + 2 : 0) + 15) / 16 * 16; }
 static bool halo_compact() {
     static const bool on = getenv("Y2_HALO_COMPACT") && atoi(getenv("Y2_HALO_COMPACT")) != 0;
     return on;
@@ -525,19 +527,19 @@ template <int BKB>
 static size_t haloq_lds(int arows, bool adb, bool cpt) {
     return (size_t)(adb ? 2 : 1) * arows * BKB + (cpt ? (size_t)kZeroRows * BKB + (size_t)arows * 4 : 0);
 }
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool M16, bool CPT>
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool M16, bool CPT, int TAPS = 9>
 static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
     typedef EpiCfg<T, WP, WC, TP, TC> Epi;
     constexpr int BP = WP * TP * 32, BC = WC * TC * 32, RPI = 64 / (BKB / 16);
     if ((a.C * (int)sizeof(T)) % BKB != 0) return hipErrorInvalidValue;
-    const int arows = CPT ? haloq_rows_compact(a.W, BP) : haloq_rows(a.H, a.W, BP, RPI);
+    const int arows = CPT ? haloq_rows_compact(a.W, BP, TAPS) : haloq_rows(a.H, a.W, BP, RPI);
     if (CPT && arows > 0xFFFF) return hipErrorOutOfMemory;
     size_t lds = haloq_lds<BKB>(arows, ADB, CPT);
     if (lds < (size_t)Epi::LDS) lds = Epi::LDS;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
     void (*kern)(ConvArgs, int);
-    if constexpr (M16) kern = conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT>;
-    else kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT>;
+    if constexpr (M16) kern = conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
+    else kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
     static size_t attr = 0;
     if (lds > attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -563,6 +565,38 @@ static hipError_t haloq_pick(const ConvArgs& a, hipStream_t s) {
     const size_t arows = haloq_rows(a.H, a.W, BP, RPI);
     if (nchunks > 1 && 2 * arows * BKB <= 150 * 1024) return haloq_launch<T, WP, WC, TP, TC, BKB, true, M16, false>(a, s);
     return haloq_launch<T, WP, WC, TP, TC, BKB, false, M16, false>(a, s);
+}
+
+// 1x1 filters (round 3, Y2_HALOQ_1X1=1 -- built, measured, NOT the default): the same kernels with ONE tap per K-chunk on
+// the compact image (rows = the tile's pixels, no halo, no border taps, conflict-free); the pixel tile crosses LDS once
+// per cout tile, the filter fragments come straight from L2: 131 FLOP per staged byte (384 x 128 tile) against 65 of
+// conv_igemm's 128 x 128 tiles.  MEASURED against conv_igemm on the same box (C4 shapes, fwd / dgrad us): 52x52 256->128
+// 41.5 / 70.2 vs 42.3 / 63.9; 26x26 512->256 29.7 / 44.7 vs 31.5 / 42.2; 13x13 1024->512 30.8 / 31.6 vs 27.8 / 35.3 --
+// a wash: with one tap per chunk every 0.4-us step waits for its own 48-KB image piece (the nine-tap loop had nine steps
+// to hide it), and at 13x13 the 384 x 64 tiles that fill the chip halve the reuse again.  These layers are bound by
+// the per-CU global->LDS fill rate and by M (10,816 pixels): the fix is a K split across workgroups, not another tile.
+template <typename T, int WP, int WC, int TP, int TC, bool M16>
+static hipError_t haloq_pick1(const ConvArgs& a, hipStream_t s) {
+    constexpr int BP = WP * TP * 32, BKB = 128;
+    const int nchunks = a.C * (int)sizeof(T) / BKB;
+    const int arows = haloq_rows_compact(a.W, BP, 1);
+    if (nchunks > 1 && haloq_lds<BKB>(arows, true, true) <= 150 * 1024)
+        return haloq_launch<T, WP, WC, TP, TC, BKB, true, M16, true, 1>(a, s);
+    return haloq_launch<T, WP, WC, TP, TC, BKB, false, M16, true, 1>(a, s);
+}
+template <typename T>
+static hipError_t haloq_T1(const ConvArgs& a, hipStream_t s, int* bp) {
+    const int kb = a.C * (int)sizeof(T);
+    if ((kb % 128) != 0 || a.Cout <= 64) return hipErrorInvalidValue;
+    *bp = 384;
+    if (conv_filter_layout(1, a.W, kb, a.Cout, a.M, a.is_dgrad) == 2) {
+        if (sizeof(T) == 4) {     // the f32 epilogue patch of a 384 x 128 tile does not fit LDS
+            *bp = 256;
+            return haloq_pick1<T, 4, 2, 2, 2, true>(a, s);
+        }
+        return haloq_pick1<T, 4, 2, 3, 2, true>(a, s);
+    }
+    return haloq_pick1<T, 4, 2, 3, 1, false>(a, s);
 }
 
 template <typename T>
@@ -614,6 +648,14 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
 
 // filters must be packed in fragment order (pack.hip, PackLayer::wf_frag / wd_frag)
 hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* bp) {
+    if (a.taps == 1) {
+        switch (dtype) {
+            case 0: return haloq_T1<float>(a, s, bp);
+            case 1: return haloq_T1<half_t>(a, s, bp);
+            case 2: return haloq_T1<bf16_t>(a, s, bp);
+        }
+        return hipErrorInvalidValue;
+    }
     if (a.taps != 9) return hipErrorInvalidValue;
     switch (dtype) {
         case 0: return haloq_T<float>(a, s, bp);
