@@ -282,6 +282,44 @@ def bench_yolov2(args, images, labels, device, rank, world, dist):
     return out
 
 
+def bench_resnet(args, device, rank, world, dist):
+    """train step of the ResNet-50 backbone swap (yolo2_nets/tf_resnet.py; BASELINE.json configs[4]; the reference trains
+    it at batch 4, 224x224: src/pascal/pascal_train_resnet.py:26).  An operator-level composition, not a tuned path:
+    the roofline is the whole step's algorithmic FLOPs over wall time."""
+    import torch
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.yolo2_nets.tf_resnet import ResNet50Yolo
+    bs, size = args.batch, 224
+    dtype = args.dtype
+    m = ResNet50Yolo(bs, size, dtype=dtype, device=device, seed=0)
+    x = torch.as_tensor(synthetic.images(bs, size, 1234 + rank)).to(device)
+    lab = torch.as_tensor(synthetic.det_labels(bs, size, size // 32, 4321 + rank)).to(device)
+    for _ in range(args.warmup):
+        m.step(x, lab)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.step(x, lab)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    flops = m.flops_per_step()
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    out = {"metric": "images/sec fwd+bwd ResNet-50 (slim resnet_v1_50 + YOLO FC head) 224x224", "value": bs / (ms * 1e-3),
+           "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+           "config": {"workload": "ResNet-50 backbone swap train step: resnet_v1_50 (16 bottleneck units) + FC 4096 + dropout "
+                                  "+ FC 1470 + get_loss + backward + Adam(0.0005)", "image_size": size, "batch_per_gpu": bs,
+                      "global_batch": bs, "S": 7, "B": 2, "parallelism": "dp1",
+                      "note": "operator-level composition (fp32 tensors between operators, per-operator launches); "
+                              "replicas only for N > 1"},
+           "whole_step_tflops": flops / (ms * 1e-3) / 1e12,
+           "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                        "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None,
+                        "kernel": "whole step (convolution + FC FLOPs as defined / wall time): launch-bound at batch %d" % bs}}
+    print(json.dumps(out))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,7 +338,7 @@ def main():
     ap.add_argument("--sustain-steps", type=int, default=300, help="extra timed region without events (0: skip)")
     ap.add_argument("--fed-steps", type=int, default=30, help="fed-input leg: uint8 upload pipeline (0: skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: core forward only (inference BN)")
-    ap.add_argument("--model", default="detector", choices=["detector", "yolov2"],
+    ap.add_argument("--model", default="detector", choices=["detector", "yolov2", "resnet50"],
                     help="detector: the reference's Darknet-19 grid detector (the headline); yolov2: the north star's "
                          "anchor model (passthrough + anchor loss), not in the reference")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU functional test)")
@@ -346,6 +384,9 @@ def main():
 
     if args.model == "yolov2":
         return bench_yolov2(args, images, labels, device, rank, world, dist)
+    if args.model == "resnet50":
+        assert world == 1, "the ResNet swap is a single-GPU functional path (replicas only)"
+        return bench_resnet(args, device, rank, world, dist)
     if args.forward_only:
         net = E.Network(spec_core, bs, size, size, dtype=args.dtype, training=False, device=device)
         net.init_params(0)

@@ -193,90 +193,7 @@ hipError_t launch_bn_infer_prepare(const float* gamma, const float* beta, const 
 // ---------------------------------------------------------------------------
 // block = (256 / cpr) pixel rows x cpr 16-byte channel chunks over a contiguous pixel range: the
 // channel chunk of a thread is fixed (scale/shift live in registers) and (n, ho, wo) advance
-// incrementally -- no per-element div/mod (64-bit ones cost more than the pass's arithmetic).
-//
-// The sweep of one thread (shared by bn_act_kernel and bn_fin_act_kernel): output pixels po = first, first + rows, ...
-// < p_end.  U output pixels are in flight per thread -- every load of the U pixels (4 each when pooled) is issued
-// before the first value is used, from CLAMPED window coordinates so that no load hides behind a branch (round 2's
-// loop loaded, compared, loaded, ...: four dependent HBM round trips per pooled pixel, wait fraction 0.80).
-template <typename T, bool POOL, bool OUTF32, int U>
-Y2_DEV void bn_act_sweep(const BnActArgs& a, const float (&sc)[16 / sizeof(T)], const float (&sh)[16 / sizeof(T)], int c0,
-                         int rows, uint32_t first, uint32_t p_end, int Ho, int Wo) {
-    constexpr int EPC = 16 / sizeof(T);
-    constexpr int ND = POOL ? 4 : 1;
-    if (first >= p_end) return;
-    int wo = (int)(first % (uint32_t)Wo);
-    const uint32_t q0 = first / (uint32_t)Wo;
-    int ho = (int)(q0 % (uint32_t)Ho), n = (int)(q0 / (uint32_t)Ho);
-    const int drow = rows / Wo, dcol = rows % Wo;
-    const size_t ldyB = (size_t)a.ldy * sizeof(T);
-    for (uint32_t po = first; po < p_end; po += rows * U) {
-        Chunk<T> v[U][ND];
-        int nn[U], hh[U], ww[U];
-        bool live[U];
-        // ---- every load of the U pixels first
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            live[u] = po + (uint32_t)(u * rows) < p_end;
-            nn[u] = n; hh[u] = ho; ww[u] = wo;
-            if (POOL) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
-                    hi = hi < a.H ? hi : a.H - 1;                    // odd sizes: the clamped copy is masked out below
-                    wi = wi < a.W ? wi : a.W - 1;
-                    v[u][d] = ld_chunk<T>((const char*)a.y + ((size_t)(n * a.H + hi) * a.W + wi) * ldyB + (size_t)c0 * sizeof(T));
-                }
-            } else {
-                v[u][0] = ld_chunk<T>((const char*)a.y + (size_t)(po + (uint32_t)(u * rows)) * ldyB + (size_t)c0 * sizeof(T));
-            }
-            // advance to the next pixel of this thread; past the end the cursor parks on the last valid pixel
-            if (po + (uint32_t)((u + 1) * rows) < p_end) {
-                wo += dcol; ho += drow;
-                if (wo >= Wo) { wo -= Wo; ++ho; }
-                while (ho >= Ho) { ho -= Ho; ++n; }
-            }
-        }
-        // ---- then the arithmetic and the stores
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!live[u]) continue;
-            const uint32_t pu = po + (uint32_t)(u * rows);
-            float r[EPC];
-            if (POOL) {
-                Chunk<T> ys;   // conv output at the first arg-max of the window (backward: BnActArgs::ysel)
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const bool inside = (2 * hh[u] + (d >> 1) < a.H) && (2 * ww[u] + (d & 1) < a.W);
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const float act = leaky01(Elem<T>::to_f32(v[u][d].v[e]) * sc[e] + sh[e]);
-                        if (inside && act > r[e]) { r[e] = act; ys.v[e] = v[u][d].v[e]; }
-                    }
-                }
-                if (a.ysel) st_chunk<T>((char*)a.ysel + ((size_t)pu * a.ldy + c0) * sizeof(T), ys);
-            } else {
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) r[e] = leaky01(Elem<T>::to_f32(v[u][0].v[e]) * sc[e] + sh[e]);
-            }
-            if (OUTF32) {
-                float* o = (float*)a.out + (size_t)pu * a.C;
-#pragma unroll
-                for (int e = 0; e < EPC; ++e)
-                    if (c0 + e < a.C) o[c0 + e] = r[e];
-            } else {
-                Chunk<T> o;
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(r[e]);
-                const size_t off = (bpix(nn[u], hh[u], ww[u], Ho, Wo) * a.C + c0) * sizeof(T);
-                st_chunk<T>((char*)a.out + off, o);
-            }
-        }
-    }
-}
-
+// incrementally -- no per-element div/mod (64-bit ones cost more than the pass's arithmetic)
 template <typename T, bool POOL, bool OUTF32>
 __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
     constexpr int EPC = 16 / sizeof(T);
@@ -298,7 +215,55 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
         sc[e] = a.scale[c0 + e];
         sh[e] = a.shift[c0 + e];
     }
-    bn_act_sweep<T, POOL, OUTF32, POOL ? 2 : 4>(a, sc, sh, c0, rows, p_begin + row, p_end, Ho, Wo);
+    int wo, ho, n;
+    {
+        const uint32_t p0 = p_begin + row;
+        wo = (int)(p0 % (uint32_t)Wo);
+        const uint32_t q = p0 / (uint32_t)Wo;
+        ho = (int)(q % (uint32_t)Ho);
+        n = (int)(q / (uint32_t)Ho);
+    }
+    const int drow = rows / Wo, dcol = rows % Wo;
+    for (uint32_t po = p_begin + row; po < p_end; po += rows, wo += dcol, ho += drow) {
+        if (wo >= Wo) { wo -= Wo; ++ho; }
+        while (ho >= Ho) { ho -= Ho; ++n; }
+        float r[EPC];
+        if (POOL) {
+            Chunk<T> ys;   // conv output at the first arg-max of the window (backward: BnActArgs::ysel)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
+                if (hi < a.H && wi < a.W) {
+                    Chunk<T> v = ld_chunk<T>((const char*)a.y +
+                                             (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float act = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+                        if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
+                    }
+                }
+            }
+            if (a.ysel) st_chunk<T>((char*)a.ysel + ((size_t)po * a.ldy + c0) * sizeof(T), ys);
+        } else {
+            Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) r[e] = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+        }
+        if (OUTF32) {
+            float* o = (float*)a.out + (size_t)po * a.C;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+                if (c0 + e < a.C) o[c0 + e] = r[e];
+        } else {
+            Chunk<T> o;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(r[e]);
+            const size_t off = (bpix(n, ho, wo, Ho, Wo) * a.C + c0) * sizeof(T);
+            st_chunk<T>((char*)a.out + off, o);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -384,7 +349,47 @@ __global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalize
         sc[e] = s_sc[ch * EPC + e];
         sh[e] = s_sh[ch * EPC + e];
     }
-    bn_act_sweep<T, POOL, false, POOL ? 2 : 4>(a, sc, sh, c0, rows, p_begin + row, p_end, Ho, Wo);
+    int wo, ho, n;
+    {
+        const uint32_t p0 = p_begin + row;
+        wo = (int)(p0 % (uint32_t)Wo);
+        const uint32_t q = p0 / (uint32_t)Wo;
+        ho = (int)(q % (uint32_t)Ho);
+        n = (int)(q / (uint32_t)Ho);
+    }
+    const int drow = rows / Wo, dcol = rows % Wo;
+    for (uint32_t po = p_begin + row; po < p_end; po += rows, wo += dcol, ho += drow) {
+        if (wo >= Wo) { wo -= Wo; ++ho; }
+        while (ho >= Ho) { ho -= Ho; ++n; }
+        float r[EPC];
+        if (POOL) {
+            Chunk<T> ys;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
+                if (hi < a.H && wi < a.W) {
+                    Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float act = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+                        if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
+                    }
+                }
+            }
+            if (a.ysel) st_chunk<T>((char*)a.ysel + ((size_t)po * a.ldy + c0) * sizeof(T), ys);
+        } else {
+            Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) r[e] = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(r[e]);
+        const size_t off = (bpix(n, ho, wo, Ho, Wo) * a.C + c0) * sizeof(T);
+        st_chunk<T>((char*)a.out + off, o);
+    }
 }
 
 bool bn_fin_act_ok(const BnActArgs& a, const BnFinalizeArgs& f) {

@@ -665,14 +665,19 @@ def conv2d(x, w, bias=None, dtype="f32"):
     return y
 
 
-def conv2d_backward(x, w, dy, dtype="f32"):
+def conv2d_backward(x, w, dy, dtype="f32", dw_out=None):
+    """-> (dx, dw); dw_out: a contiguous fp32 tensor of w's size to receive dw (a view of a flat gradient buffer)"""
     lib = _lib.load()
     dt = _lib.DTYPES[dtype]
     n, h, wd, ci = x.shape
     k, _, _, co = w.shape
     x, w, dy = x.contiguous().float(), w.contiguous().float(), dy.contiguous().float()
     dx = torch.empty_like(x)
-    dw = torch.empty_like(w)
+    if dw_out is not None:
+        assert dw_out.is_cuda and dw_out.dtype == torch.float32 and dw_out.is_contiguous() and dw_out.numel() == w.numel()
+        dw = dw_out
+    else:
+        dw = torch.empty_like(w)
     ws = torch.empty(lib.y2_conv2d_workspace_bytes(n, h, wd, ci, co, k, dt), dtype=torch.uint8, device=x.device)
     check(lib.y2_conv2d_backward(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), n, h, wd, ci, co, k, dt,
                                  _ptr(ws), _stream()))

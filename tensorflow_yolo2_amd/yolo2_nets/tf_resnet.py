@@ -142,17 +142,17 @@ class ResNet50Yolo:
     def _conv_backward(self, rec, dy):
         kind, name = rec[0], rec[1]
         w = self.p[name]
+        gw = self.g[name]            # every variable has exactly one consumer: dW lands in the flat gradient buffer
         if kind == "conv":
-            dx, dw = E.conv2d_backward(rec[2], w, dy.contiguous(), self.dtype)
+            dx, _ = E.conv2d_backward(rec[2], w, dy.contiguous(), self.dtype, dw_out=gw)
         elif kind == "conv1s":
             x, xs, stride = rec[2], rec[3], rec[4]
-            dxs, dw = E.conv2d_backward(xs, w, dy.contiguous(), self.dtype)
+            dxs, _ = E.conv2d_backward(xs, w, dy.contiguous(), self.dtype, dw_out=gw)
             dx = E.subsample(dxs, stride, out_hw=tuple(x.shape[1:3]))
         else:
             x, hw, stride = rec[2], rec[3], rec[4]
             dfull = E.subsample(dy.contiguous(), stride, out_hw=hw)
-            dx, dw = E.conv2d_backward(x, w, dfull, self.dtype)
-        self.g[name].copy_(dw.view(self.g[name].shape))      # every variable has exactly one consumer
+            dx, _ = E.conv2d_backward(x, w, dfull, self.dtype, dw_out=gw)
         return dx
 
     def _bn(self, x, scope, relu, residual=None):
@@ -222,15 +222,15 @@ class ResNet50Yolo:
         dz2, db2 = E.bias_relu_backward(dgrid.reshape(n, -1).contiguous(), fc2, True)
         self.g["yolo_fc2/biases"].copy_(db2)
         w2 = self.p["yolo_fc2/weights"]
-        dh, dw2 = E.conv2d_backward(h.view(n, 1, 1, -1), w2.view(1, 1, *w2.shape), dz2.view(n, 1, 1, -1), self.dtype)
-        self.g["yolo_fc2/weights"].copy_(dw2.view(self.g["yolo_fc2/weights"].shape))
+        dh, _ = E.conv2d_backward(h.view(n, 1, 1, -1), w2.view(1, 1, *w2.shape), dz2.view(n, 1, 1, -1), self.dtype,
+                                  dw_out=self.g["yolo_fc2/weights"])
         dh = dh.view(n, -1)
         dfc1 = E.dropout(dh.contiguous(), self.keep_prob, seed) if use_drop else dh        # same mask, same 1/keep scale
         dz1, db1 = E.bias_relu_backward(dfc1.contiguous(), fc1, True)
         self.g["yolo_fc1/biases"].copy_(db1)
         w1 = self.p["yolo_fc1/weights"]
-        dflat, dw1 = E.conv2d_backward(flat, w1.view(1, 1, *w1.shape), dz1.view(n, 1, 1, -1), self.dtype)
-        self.g["yolo_fc1/weights"].copy_(dw1.view(self.g["yolo_fc1/weights"].shape))
+        dflat, _ = E.conv2d_backward(flat, w1.view(1, 1, *w1.shape), dz1.view(n, 1, 1, -1), self.dtype,
+                                     dw_out=self.g["yolo_fc1/weights"])
         dx = dflat.reshape(feat.shape).contiguous()
         for rec in reversed(self.tape[:-1]):
             if rec[0] == "unit":
@@ -256,6 +256,27 @@ class ResNet50Yolo:
             elif rec[0] == "conv7":
                 dw = E.conv7x7_s2_backward_filter(rec[1].contiguous(), dx.contiguous())
                 self.g["conv1/weights"].copy_(dw)
+
+    def flops_per_step(self):
+        """algorithmic FLOPs of one train step: 3 x the forward multiply-adds of every convolution / FC layer at the
+        size it is DEFINED at (a stride-2 3x3 counts its strided output; this composition computes it at stride 1 and
+        subsamples -- 4x the listed work for those three layers)"""
+        tot, h, cin = 0.0, self.size // 2, 3
+        n = self.batch
+        tot += 2.0 * n * h * h * 49 * 3 * self.vars[0][1][3]
+        cin = self.vars[0][1][3]
+        h //= 2
+        for _b, units in self.blocks:
+            for (depth, db, stride) in units:
+                ho = (h + stride - 1) // stride
+                if depth != cin:
+                    tot += 2.0 * n * ho * ho * cin * depth
+                tot += 2.0 * n * h * h * cin * db + 2.0 * n * ho * ho * 9 * db * db + 2.0 * n * ho * ho * db * depth
+                cin, h = depth, ho
+        flat = h * h * cin
+        fc_hidden = self.p["yolo_fc1/biases"].numel()
+        tot += 2.0 * n * flat * fc_hidden + 2.0 * n * fc_hidden * self.p["yolo_fc2/biases"].numel()
+        return 3.0 * tot
 
     def step(self, images, labels):
         """one iteration of pascal_train_resnet.py:49-62: get_loss + AdamOptimizer(0.0005).minimize"""
