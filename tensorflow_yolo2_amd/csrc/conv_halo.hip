@@ -338,8 +338,8 @@ static int dev_rule(int W, int Cout) {
 
 // filter fragments straight to registers (conv_haloq.hip) -- the filter pack must match (pack.hip,
 // PackLayer::wf_frag / wd_frag).
-// Measured (scripts/bench_conv.py, rotating buffers): wins up to 26x26 and again at 104x104 (big 512-pixel
-// tiles); at 52x52 the LDS filter ring is as fast, at 208x208 only the 32-channel dgrad gains.
+// Measured (scripts/bench_conv.py, rotating buffers; round 3: scripts/ab_layers.sh): wins up to 52x52 and again at
+// 104x104 (big 512-pixel tiles); at 208x208 only the 32-channel dgrad gains.
 // 0: K-contiguous rows (conv_halo / conv_igemm); 1: 32-row MFMA fragments (conv_haloq, 32x32x16 tiles);
 // 2: 16-row fragments (conv_haloq on 16x16x32 tiles: the 384 x 128 tile class up to 26x26, +3-4 %).
 // row_bytes = input channels * element size of the launch (forward: cin_s, dgrad: ldy).
@@ -356,15 +356,20 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgra
     }
     if (taps != 9) return 0;
     if (conv_rf_config(taps, W, row_bytes, Cout, M) || conv_rfn_config(taps, W, row_bytes, Cout, M, dgrad)) return 0;    // register-resident filters: fetched from K-contiguous rows
-    if (!(W <= 26 || (W > 52 && W <= 104) || (W > 104 && Cout <= 32))) return 0;
+    // Round 3: the 52-wide layers run on conv_haloq too (with the leaner tap step of this round it beats conv_halo's
+    // LDS filter ring there: 128 -> 256 @52x52 forward 130.6 -> 126.2 us, dgrad 130.4 -> 114.0, same box;
+    // Y2_NO_HALOQ_52=1 restores round 2's split for A/B)
+    static const bool no52 = getenv("Y2_NO_HALOQ_52") != nullptr;
+    const int wsmall = no52 ? 26 : 52;
+    if (!(W <= wsmall || (W > 52 && W <= 104) || (W > 104 && Cout <= 32))) return 0;
     const bool narrow = ((M + 383) / 384) * ((Cout + 127) / 128) < 160;
-    if (W <= 26 && Cout > 64 && M >= 384 * 8 && (row_bytes % 128) == 0 && !narrow) return 2;
+    if (W <= wsmall && Cout > 64 && M >= 384 * 8 && (row_bytes % 128) == 0 && !narrow) return 2;
     return 1;
 }
 
 // Kernel policy (measured on MI355X, scripts/bench_conv.py and profile_layers.py):
-//   3x3, rows <= 26 / 104 / the 208-wide 32-channel dgrad : conv_haloq (halo image + register filters)
-//   3x3, rows of 52                                        : conv_halo  (halo image + LDS filter ring)
+//   3x3, rows <= 52 / 104 / the 208-wide 32-channel dgrad : conv_haloq (halo image + register filters)
+//   3x3, what conv_haloq's K-chunk sizes do not divide     : conv_halo  (halo image + LDS filter ring)
 //   3x3 208-wide forward, and every 1x1                    : conv_igemm (per-tap staging)
 // *block_pixels receives the pixel-tile size used (= rows per BN partial record)
 hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_pixels, int* records) {

@@ -612,6 +612,8 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
             e = haloq_pick<T, 4, 2, 2, 2, 64>(a, s);
         } else if (a.Cout > 32) {
             *bp = 512;
+            // (64-byte K chunks here, so that the 512-pixel image at W = 104 can be double-buffered, measured 12 %
+            //  SLOWER than the single-buffered 128-byte ones: half the MFMAs per tap step for the same step overhead)
             e = k128 ? haloq_pick<T, 4, 2, 4, 1, 128>(a, s) : haloq_pick<T, 4, 2, 4, 1, 64>(a, s);
         } else {
             *bp = 512;
@@ -622,12 +624,22 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
     }
     if (a.Cout > 64) {
         hipError_t e = hipErrorOutOfMemory;
-        if (a.M >= 384 * 8) {   // every fragment-filter layer (W <= 26): 384-pixel tiles measured best
+        if (a.M >= 384 * 8) {   // every fragment-filter layer (W <= 52): 384-pixel tiles measured best
             *bp = 384;
             const bool narrow = ((a.M + 383) / 384) * ((a.Cout + 127) / 128) < 160 && k128;
             const bool m16 = conv_filter_layout(9, a.W, kb, a.Cout, a.M) == 2;   // filters packed for 16x16 tiles
             if (narrow) e = haloq_pick<T, 4, 2, 3, 1, 128>(a, s);
-            else if (m16) e = haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s);
+            else if (m16) {
+                // the filters are packed for 16-row fragments: ONLY a 16x16-tile kernel may run.  The f32 epilogue
+                // patch of a 384 x 128 tile does not fit LDS (209 KB): 256 x 128 there.  (Round 2 fell through to a
+                // 32x32-tile kernel on the 16-row pack in this case -- wrong outputs in the f32 mode whenever
+                // tiles x cout-tiles >= 160, i.e. from batch 24 up at 416x416; found by the f32 leg of the C5 test.)
+                if (sizeof(T) == 4) {
+                    *bp = 256;
+                    return haloq_pick<T, 4, 2, 2, 2, 128, true>(a, s);
+                }
+                return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s);
+            }
             else e = k128 ? haloq_pick<T, 4, 2, 3, 2, 128>(a, s) : haloq_pick<T, 4, 2, 3, 2, 64>(a, s);
         } else if (a.M >= 256 * 8) {
             *bp = 256;

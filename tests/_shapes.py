@@ -72,8 +72,9 @@ def wgrad_reference(x, dy, k, ci_s, co_s):
     return ref
 
 
-def check_layer_shape(N, name, k, cin, cout, hw, tag="C4"):
-    """y2_conv2d / y2_conv2d_backward (the network's own launch policy) in f16 at one layer shape against float64"""
+def check_layer_shape(N, name, k, cin, cout, hw, tag="C4", dtype="f16", tol=TOL):
+    """y2_conv2d / y2_conv2d_backward (the network's own launch policy) at one layer shape against float64; inputs are
+    f16-representable in every dtype (exact products in f16 and in f32)"""
     from tensorflow_yolo2_amd import engine as E
     rng = np.random.default_rng(k * 1000003 + cin * 1009 + cout * 31 + hw + 7 * abs(N - 64))
     x = f16_representable(rng.uniform(-1, 1, (N, hw, hw, cin)).astype(np.float32))
@@ -84,12 +85,12 @@ def check_layer_shape(N, name, k, cin, cout, hw, tag="C4"):
     pts = sample_pixels(N, hw, rng)
 
     # ---- forward: y = conv(x, W) + b at the sampled pixels, every cout, K = k*k*cin in float64
-    y = E.conv2d(xd, wd, torch.as_tensor(b).cuda(), dtype="f16").cpu().numpy().reshape(-1, cout)
+    y = E.conv2d(xd, wd, torch.as_tensor(b).cuda(), dtype=dtype).cpu().numpy().reshape(-1, cout)
     ref = gather_patches(x, pts, hw, k) @ w.reshape(k * k * cin, cout).astype(np.float64) + b.astype(np.float64)
     e_fwd = rel_to_max(y[pts], ref)
 
     # ---- dgrad: dx = conv(dy, flip(W)^T) at the sampled pixels, every cin
-    dx, dw = E.conv2d_backward(xd, wd, dyd, dtype="f16")
+    dx, dw = E.conv2d_backward(xd, wd, dyd, dtype=dtype)
     dx = dx.cpu().numpy().reshape(-1, cin)
     wflip = w[::-1, ::-1].transpose(0, 1, 3, 2).reshape(k * k * cout, cin).astype(np.float64)
     ref = gather_patches(dy, pts, hw, k) @ wflip
@@ -101,9 +102,9 @@ def check_layer_shape(N, name, k, cin, cout, hw, tag="C4"):
     dw = dw.cpu().numpy()
     ref = wgrad_reference(x, dy, k, ci_s, co_s)
     e_dw = rel_to_max(dw[:, :, ci_s][:, :, :, co_s], ref)
-    print("%s %-13s N=%d f16 vs float64 (rel. to max): forward %.2e  dgrad %.2e  wgrad %.2e" %
-          (tag, name, N, e_fwd, e_dx, e_dw))
-    assert e_fwd < TOL and e_dx < TOL and e_dw < TOL, (name, e_fwd, e_dx, e_dw)
+    print("%s %-13s N=%d %s vs float64 (rel. to max): forward %.2e  dgrad %.2e  wgrad %.2e" %
+          (tag, name, N, dtype, e_fwd, e_dx, e_dw))
+    assert e_fwd < tol and e_dx < tol and e_dw < tol, (name, dtype, e_fwd, e_dx, e_dw)
 
 
 def check_layer_in_network(N, name, k, cin, cout, hw, pool, tag="C4"):

@@ -44,6 +44,13 @@ def test_c4_layer_shape_f16_vs_float64(name, k, cin, cout, hw):
     check_layer_shape(N, name, k, cin, cout, hw, "C4")
 
 
+@pytest.mark.parametrize("name,k,cin,cout,hw", [s for s in C4_SHAPES if s[4] <= 52], ids=[s[0] for s in C4_SHAPES if s[4] <= 52])
+def test_c4_layer_shape_f32_mode_at_batch_64(name, k, cin, cout, hw):
+    """the parity-grade f32 mode (exact-f32 MFMA) at the BENCHMARKED batch: tile policies depend on N*H*W (round 2 ran a
+    32x32-tile kernel on 16-row filter packs from batch 24 up -- only small batches were under test); 1e-5 of the max"""
+    check_layer_shape(N, name, k, cin, cout, hw, "C4", dtype="f32", tol=1e-5)
+
+
 NET_SHAPES = [("conv2+pool", 3, 32, 64, 208, 1), ("conv3", 3, 64, 128, 104, 0), ("conv5+pool", 3, 64, 128, 104, 1),
               ("conv8+pool", 3, 128, 256, 52, 1), ("conv7", 1, 256, 128, 52, 0), ("conv13+pool", 3, 256, 512, 26, 1),
               ("conv14", 3, 512, 1024, 13, 0), ("head1", 3, 1024, 1024, 13, 0)]

@@ -88,9 +88,13 @@ def test_resnet_f16_loss_scale_gradients_and_overflow_guard():
     m.step(x, labels)
     assert m.overflows == 1 and m.loss_scale == 5e8 and m.t == 0
     assert torch.equal(m.params, p0) and torch.equal(m.m, m0)
+    # from the default scale the scaler backs off until the steps go through (this toy geometry overflows at 1024:
+    # gradients GROW through 49 batch-norms over 8 positions), then training proceeds
     m.loss_scale = 1024.0
-    losses = [float(m.step(x, labels)[0][4]) for _ in range(4)]
-    assert m.t == 4 and all(np.isfinite(losses)) and torch.isfinite(m.params).all()
+    losses = [float(m.step(x, labels)[0][4]) for _ in range(16)]
+    print("resnet f16 dynamic scale: %d steps applied of 16, %d overflows, scale %.0f" % (m.t, m.overflows, m.loss_scale))
+    assert m.t >= 4 and m.t + m.overflows - 1 == 16 and m.loss_scale < 1024.0
+    assert all(np.isfinite(losses)) and torch.isfinite(m.params).all() and torch.isfinite(m.m).all()
 
 
 def m_lib():
