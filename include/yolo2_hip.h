@@ -157,6 +157,9 @@ int y2_passthrough_concat_backward(const float* dout, float* dfine, float* dcoar
 /* dst += src on fp32 buffers: the gradient of a tensor with two consumers (the 26x26x512 activation feeds the pool
  * and the passthrough) */
 int y2_accumulate(float* dst, const float* src, size_t n, void* stream);
+/* scores [rows][classes] -> best score and class index per row (the class choice in front of the NMS of the YOLOv2
+ * detector; ties: smallest index, as np.argmax in net_utils.py:418) */
+int y2_class_argmax(const float* scores, float* best, int* cls, int rows, int classes, void* stream);
 /* x *= s: the loss scale in front of a half-precision backward pass of a composed graph (no reference counterpart:
  * the reference runs fp32) */
 int y2_scale(float* x, size_t n, float s, void* stream);
@@ -226,6 +229,9 @@ int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, 
  * counter untouched, ctrl.skipped += 1); otherwise ctrl.step advances and Adam's lr_t is computed on the
  * device for it.  No host synchronisation. */
 int y2_grad_check(y2_ctx* ctx, void* ctrl, void* stream);
+/* the same scan OR-ed into ctrl.found_inf WITHOUT clearing it first: further stacks of ONE composed graph scanned into
+ * the control block the first stack's y2_grad_check cleared -- the step is then all-or-nothing over the whole graph */
+int y2_grad_check_more(y2_ctx* ctx, void* ctrl, void* stream);
 int y2_grad_check_full(const float* grads, size_t n, void* ctrl, void* stream);
 int y2_adam_step_guarded(float* params, float* m, float* v, const float* grads, size_t n, void* ctrl, float lr,
                          float beta1, float beta2, float eps, float grad_mult, void* stream);
@@ -237,6 +243,8 @@ int y2_momentum_step_guarded(float* params, float* accum, const float* grads, si
  * current and skips its own re-pack pass).  Same arithmetic as y2_adam_step / y2_momentum_step.  ctrl: NULL for
  * the plain step number `step`, or the guard words of the *_guarded forms (run y2_grad_check first).  Other
  * contexts bound to the same parameter buffer must still call y2_params_changed. */
+/* (ctrl with step < 0: do not advance the control block -- a further stack of a composed graph whose first stack's call
+ * advanced it already: ONE step counter and lr_t for the whole graph) */
 int y2_adam_step_packed(y2_ctx* ctx, float* m, float* v, void* ctrl, int step, float lr, float beta1, float beta2,
                         float eps, float grad_mult, void* stream);
 int y2_momentum_step_packed(y2_ctx* ctx, float* accum, void* ctrl, float lr, float momentum, float grad_mult,

@@ -69,6 +69,7 @@ SIGNATURES = {
     "y2_passthrough_concat_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_accumulate": (_i, [_vp, _vp, _sz, _vp]),
     "y2_scale": (_i, [_vp, _sz, _f, _vp]),
+    "y2_class_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "y2_decode_anchors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_nms": (_i, [_vp, _vp, _vp, _i, _i, _f, _f, _i, _i, _vp, _vp, _vp]),
     "y2_yolov2_loss_workspace_bytes": (_sz, [_i]),
@@ -86,6 +87,7 @@ SIGNATURES = {
     "y2_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
     "y2_grad_check": (_i, [_vp, _vp, _vp]),
+    "y2_grad_check_more": (_i, [_vp, _vp, _vp]),
     "y2_grad_check_full": (_i, [_vp, _sz, _vp, _vp]),
     "y2_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step_guarded": (_i, [_vp, _vp, _vp, _sz, _vp, _f, _f, _f, _vp]),

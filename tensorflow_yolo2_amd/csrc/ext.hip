@@ -482,6 +482,30 @@ int y2_accumulate(float* dst, const float* src, size_t n, void* stream) {
     return Y2_OK;
 }
 
+// best class score and its index per box: scores [R][C] -> best [R], cls [R] (ties: the smallest index, as argmax)
+__global__ void class_argmax_kernel(const float* __restrict__ scores, float* __restrict__ best, int* __restrict__ cls,
+                                    int R, int C) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float* p = scores + (size_t)r * C;
+    float m = p[0];
+    int k = 0;
+    for (int c = 1; c < C; ++c) {
+        const float v = p[c];
+        if (v > m) { m = v; k = c; }
+    }
+    best[r] = m;
+    cls[r] = k;
+}
+int y2_class_argmax(const float* scores, float* best, int* cls, int rows, int classes, void* stream) {
+    if (!scores || !best || !cls || rows < 0 || classes < 1) return fail(Y2_ERR_ARG, "bad arguments");
+    if (rows == 0) return Y2_OK;
+    hipLaunchKernelGGL(class_argmax_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, scores, best, cls,
+                       rows, classes);
+    EXTCHK(hipGetLastError());
+    return Y2_OK;
+}
+
 // x *= s (loss scaling of an output gradient in front of a half-precision backward pass)
 __global__ void scale_kernel(float* __restrict__ x, size_t n, float s) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;

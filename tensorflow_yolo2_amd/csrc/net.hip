@@ -1040,6 +1040,12 @@ int y2_grad_check(y2_ctx* c, void* ctrl, void* stream) {
     HIPCHK(launch_grad_check_ranges(c->grads, c->ws + c->o_chkranges, c->n_chkranges, ctrl, (hipStream_t)stream));
     return Y2_OK;
 }
+int y2_grad_check_more(y2_ctx* c, void* ctrl, void* stream) {
+    if (!c->grads || !ctrl) return fail(Y2_ERR_ARG, "bind with a gradient buffer first");
+    HIPCHK(launch_grad_check_ranges(c->grads, c->ws + c->o_chkranges, c->n_chkranges, ctrl, (hipStream_t)stream, nullptr,
+                                    true));
+    return Y2_OK;
+}
 int y2_grad_check_full(const float* grads, size_t n, void* ctrl, void* stream) {
     if (!grads || !ctrl) return fail(Y2_ERR_ARG, "bad arguments");
     HIPCHK(launch_grad_check(grads, n, ctrl, (hipStream_t)stream));
@@ -1127,8 +1133,10 @@ int y2_adam_step_packed(y2_ctx* c, float* m, float* v, void* ctrl, int step, flo
                         float eps, float grad_mult, void* stream) {
     if (!m || !v || (!ctrl && step < 1)) return fail(Y2_ERR_ARG, "bad arguments");
     double lr_t = lr;
-    if (ctrl) HIPCHK(launch_opt_ctrl_advance(ctrl, lr, beta1, beta2, (hipStream_t)stream));
-    else lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
+    // ctrl with step < 0: the control block was advanced by another stack's call of this step (one composed graph,
+    // one step counter): use its lr_t / found_inf as they stand
+    if (ctrl && step >= 0) HIPCHK(launch_opt_ctrl_advance(ctrl, lr, beta1, beta2, (hipStream_t)stream));
+    else if (!ctrl) lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, step)) / (1.0 - pow((double)beta1, step));
     return opt_step_packed(c, 0, m, v, ctrl, (float)lr_t, beta1, beta2, eps, grad_mult, (hipStream_t)stream);
 }
 int y2_momentum_step_packed(y2_ctx* c, float* accum, void* ctrl, float lr, float momentum, float grad_mult,

@@ -119,9 +119,11 @@ __global__ __launch_bounds__(256) void grad_check_ranges_kernel(const float* g, 
     if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ctrl->found_inf, 1);
 }
 hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s,
-                                    unsigned* flag) {
-    hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int), s);
-    if (e != hipSuccess) return e;
+                                    unsigned* flag, bool keep) {
+    if (!keep) {
+        hipError_t e = hipMemsetAsync(ctrl, 0, sizeof(int), s);
+        if (e != hipSuccess) return e;
+    }
     const int nb = nranges < 1 ? 1 : (nranges < 64 ? nranges : 64);
     hipLaunchKernelGGL(grad_check_ranges_kernel, dim3(nb), dim3(256), 0, s, g, (const unsigned*)ranges_dev, nranges,
                        (OptCtrl*)ctrl, flag);

@@ -304,10 +304,13 @@ class LossScaler:
             self.nets.append(net)
             net.set_grad_scale(self.scale)
 
-    def scan(self, net, full=False):
-        """set ctrl.found_inf from net's gradient buffer: sentinel ranges (default) or every element"""
+    def scan(self, net, full=False, more=False):
+        """set ctrl.found_inf from net's gradient buffer: sentinel ranges (default) or every element;
+        more: OR into the flag another stack's scan of this step left (composed graphs: one all-or-nothing step)"""
         if full:
             check(net.lib.y2_grad_check_full(_ptr(net.grads), net.n_params, _ptr(self.ctrl), _stream()))
+        elif more:
+            check(net.lib.y2_grad_check_more(net.h, _ptr(self.ctrl), _stream()))
         else:
             check(net.lib.y2_grad_check(net.h, _ptr(self.ctrl), _stream()))
 
@@ -349,14 +352,24 @@ class AdamOptimizer:
         self.guard = (net.dtype == _lib.Y2_F16) if guard is None else bool(guard)
         self.scaler = LossScaler(net) if self.guard else None
 
-    def step(self, grad_mult=1.0, full_check=False):
+    def step(self, grad_mult=1.0, full_check=False, joint=None):
         """full_check: scan every gradient element instead of the sentinel ranges (a gradient buffer that was
-        not produced by this context's backward pass)"""
+        not produced by this context's backward pass).
+        joint: None, or this optimizer's place in a group that shares ONE LossScaler over a composed graph
+        ("first": the caller has scanned every stack into the shared flag -- advance the step counter once;
+        "next": use the counter / lr_t the first stack's call advanced)."""
         self.t += 1
         n = self.net
-        if self.guard:
+        if self.guard and joint is None:
             self.scaler.scan(n, full_check)
         ctrl = _ptr(self.scaler.ctrl) if self.guard else C.c_void_p(0)
+        if joint is not None:
+            assert self.guard and self.fused_pack and n.training
+            check(n.lib.y2_adam_step_packed(n.h, _ptr(self.m), _ptr(self.v), ctrl, self.t if joint == "first" else -1,
+                                            self.lr, self.b1, self.b2, self.eps, grad_mult, _stream()))
+            if joint == "first":
+                self.scaler.after_step()
+            return
         if self.fused_pack and n.training:
             # update + filter re-pack in one pass over the parameters (the context's packed copies stay current)
             check(n.lib.y2_adam_step_packed(n.h, _ptr(self.m), _ptr(self.v), ctrl, self.t, self.lr, self.b1, self.b2,
@@ -577,6 +590,18 @@ def accumulate(dst, src):
     assert dst.numel() == src.numel() and src.dtype == torch.float32
     check(lib.y2_accumulate(_ptr(dst), _ptr(src), dst.numel(), _stream()))
     return dst
+
+
+def class_argmax(scores):
+    """scores [..., C] -> (best [...], class index [...] int32); ties: the smallest index"""
+    lib = _lib.load()
+    assert scores.is_cuda and scores.dtype == torch.float32 and scores.is_contiguous()
+    c = scores.shape[-1]
+    rows = scores.numel() // c
+    best = torch.empty(scores.shape[:-1], dtype=torch.float32, device=scores.device)
+    cls = torch.empty(scores.shape[:-1], dtype=torch.int32, device=scores.device)
+    check(lib.y2_class_argmax(_ptr(scores), _ptr(best), _ptr(cls), rows, c, _stream()))
+    return best, cls
 
 
 def decode_anchors(net, anchors):

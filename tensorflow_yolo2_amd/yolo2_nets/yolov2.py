@@ -53,9 +53,8 @@ class YOLOv2Detector:
         """-> boxes [N,K,4] (cx,cy,w,h relative), best score [N,K], class id [N,K], keep [N,max_out], count [N]"""
         grid = self.forward(images)
         boxes, scores = E.decode_anchors(grid.contiguous(), self.anchors)
-        best, cls = scores.max(dim=2)
-        keep, count = E.nms(boxes, best.contiguous(), cls.to(torch.int32).contiguous(), iou_thresh, score_thresh, max_out,
-                            class_aware)
+        best, cls = E.class_argmax(scores)
+        keep, count = E.nms(boxes, best, cls, iou_thresh, score_thresh, max_out, class_aware)
         return boxes, best, cls, keep, count
 
 
@@ -100,6 +99,10 @@ class YOLOv2Trainer:
                 for i, net in enumerate(nets):
                     net.init_params(self.seed + i)
                 self.opts = [E.AdamOptimizer(net) for net in nets]
+                # ONE loss scale, overflow flag and step counter for the composed graph: an inf confined to
+                # one stack must skip the step of all three, and a skipped step must not advance any Adam bias correction
+                for opt in self.opts[1:]:
+                    opt.scaler = self.opts[0].scaler
             self.ctx[size] = nets
             self.reducers = getattr(self, "reducers", {})
             self.reducers[size] = [self._GradReducer(net) for net in nets]
@@ -143,11 +146,20 @@ class YOLOv2Trainer:
         world = red[0].backward_and_reduce(dfine)
         if dist is not None:
             red[1].join(); red[2].join()
+        scaler = self.opts[0].scaler
         for opt, net in zip(self.opts, (stem, deep, head)):
             opt.net = net
-            if opt.scaler is not None:
-                opt.scaler.attach(net)
-            opt.step(grad_mult=1.0 / world)
+            if scaler is not None:
+                scaler.attach(net)
+        if scaler is None:
+            for opt in self.opts:
+                opt.step(grad_mult=1.0 / world)
+            return loss
+        # every stack's sentinels into the one flag, then the three guarded updates: all of them or none
+        for i, net in enumerate((stem, deep, head)):
+            scaler.scan(net, more=(i > 0))
+        for i, opt in enumerate(self.opts):
+            opt.step(grad_mult=1.0 / world, joint="first" if i == 0 else "next")
         return loss
 
     def networks(self, size=None):

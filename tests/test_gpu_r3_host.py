@@ -100,3 +100,41 @@ def test_resnet_f16_loss_scale_gradients_and_overflow_guard():
 def m_lib():
     from tensorflow_yolo2_amd import _lib
     return _lib.load()
+
+
+def test_yolov2_trainer_one_scaler_for_the_three_stacks():
+    """the composed YOLOv2 graph has ONE loss scale, overflow flag and step counter: a train step advances the
+    device step counter by one (not by three), an overflow skips the update of ALL three stacks and halves the scale of
+    all three; class_argmax (the detector's class choice) equals argmax with first-index ties."""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from tensorflow_yolo2_amd.yolo2_nets.yolov2 import YOLOv2Trainer
+    n, size = 2, 64
+    tr = YOLOv2Trainer(n, size, dtype="f16", seed=1, width_div=8)
+    x = dev(synthetic.images(n, size, 3))
+    lab = dev(synthetic.det_labels(n, size, size // 32, 4))
+    sc = tr.opts[0].scaler
+    assert all(o.scaler is sc for o in tr.opts)
+    tr.step(x, lab)
+    assert sc.state() == (0, 1, 0)                       # one step counted for the whole graph
+    tr.step(x, lab)
+    assert sc.state() == (0, 2, 0)
+    before = [net.params.clone() for net in tr.nets]
+    slots = [o.m.clone() for o in tr.opts]
+    sc._apply(1e9)                                       # every f16 gradient overflows
+    assert all(net.grad_scale == 1e9 for net in tr.nets)
+    tr.step(x, lab)
+    assert sc.state() == (1, 2, 1)                       # found_inf, step NOT advanced, one skipped step
+    for net, p0 in zip(tr.nets, before):
+        assert torch.equal(net.params, p0)
+    for o, m0 in zip(tr.opts, slots):
+        assert torch.equal(o.m, m0)
+    sc._apply(1024.0)
+    tr.step(x, lab)                                      # the host sees the overflow one step late and halves the scale
+    assert sc.overflows == 1 and all(net.grad_scale == 512.0 for net in tr.nets)
+    assert sc.state()[1] == 3 and all(torch.isfinite(net.params).all() for net in tr.nets)
+    # class_argmax
+    rng = np.random.default_rng(0)
+    s = np.round(rng.uniform(0, 1, (3, 50, 20)), 1).astype(np.float32)      # rounded: ties on purpose
+    best, cls = E.class_argmax(dev(s))
+    np.testing.assert_array_equal(best.cpu().numpy(), s.max(-1))
+    np.testing.assert_array_equal(cls.cpu().numpy(), s.argmax(-1).astype(np.int32))
