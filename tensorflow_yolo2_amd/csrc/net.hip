@@ -1191,7 +1191,8 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
     const size_t sz = dtype_size(dtype);
     OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
     char* ws = (char*)workspace;
-    HIPCHK(hipMemsetAsync(ws, 0, p.total, s));
+    // only the bordered activations rely on zeros (borders, channel padding); the filter packs write their padding
+    HIPCHK(hipMemsetAsync(ws + p.xp, 0, p.wf - p.xp, s));
     PadGeom g{N, H, W, p.Cin_p};
     char* xp = ws + p.xp + g.base_off(sz);
     HIPCHK(launch_pack_act(dtype, x, xp, N, H, W, Cin, p.Cin_p, s));
@@ -1213,7 +1214,8 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
     const size_t sz = dtype_size(dtype);
     OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
     char* ws = (char*)workspace;
-    HIPCHK(hipMemsetAsync(ws, 0, p.total, s));
+    HIPCHK(hipMemsetAsync(ws + p.xp, 0, p.wf - p.xp, s));
+    HIPCHK(hipMemsetAsync(ws + p.dyp, 0, p.dx - p.dyp, s));
     PadGeom gx{N, H, W, p.Cin_p}, gy{N, H, W, p.Cdy};
     char* xp = ws + p.xp + gx.base_off(sz);
     char* dyp = ws + p.dyp + gy.base_off(sz);
@@ -1231,11 +1233,12 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
     }
     if (dw) {
         WgradArgs g{};
-        g.x = xp; g.dy = dyp; g.dW = (float*)(ws + p.dw);
+        const bool direct = p.Cin_p == Cin;      // no channel padding: the kernel writes the caller's tensor
+        g.x = xp; g.dy = dyp; g.dW = direct ? dw : (float*)(ws + p.dw);
         g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = p.Cin_p; g.Cdy = p.Cdy; g.Cout = Cout;
         g.taps = k * k; g.splitk = 0; g.scale = 1.f;
         HIPCHK(launch_wgrad_auto(dtype, g, s));
-        for (int t = 0; t < k * k; ++t)
+        for (int t = 0; t < k * k && !direct; ++t)
             HIPCHK(hipMemcpyAsync(dw + (size_t)t * Cin * Cout, (float*)(ws + p.dw) + (size_t)t * p.Cin_p * Cout,
                                   (size_t)Cin * Cout * sizeof(float), hipMemcpyDeviceToDevice, s));
     }

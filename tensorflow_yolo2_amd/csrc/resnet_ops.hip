@@ -10,11 +10,18 @@
 //   * max_pool2d([3,3], stride 2, 'SAME')          (resnet_v1.py:198)
 //   * conv2d_same(64, 7, stride 2) on the 3-channel image, forward + filter gradient (resnet_v1.py:197)
 //   * bias + ReLU of slim.fully_connected, dropout(0.5) (pascal_train_resnet.py:41-46)
-// The reference trains this model at batch 4: these operators are written for correctness and coalesced access,
-// not tuned -- the MFMA work is in the convolutions.
+// Per-channel reductions (BN statistics, BN backward sums, the root filter gradient) are two-level: the rows are cut
+// into slices so that ~2000 workgroups sweep the tensor at HBM rate, every workgroup leaves one double-precision
+// partial per channel in a per-stream scratch buffer, and a finalize kernel adds the partials in a fixed order
+// (deterministic run to run).  Round 2 had one workgroup per 32 channels sweep ALL rows: 2 workgroups on 256 CUs at
+// 64 channels, 4.5 ms per BN backward, 352 of 375 ms of the batch-32 step.
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "../../include/yolo2_hip.h"
 #include "common.h"
@@ -44,34 +51,181 @@ static inline unsigned grid_for(size_t total, unsigned cap = 16384) {
     return (unsigned)nb;
 }
 
-// ---------------------------------------------------------------------------
-// batch norm over [M][C] fp32.  Statistics: one block per 32 channels sweeps all rows (256 threads = 8 rows x 32
-// channels per pass: 128-byte row segments), shifted sums about the first row, double merge.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rn_bn_stats_kernel(const float* __restrict__ x, size_t M, int C, float* mean,
-                                                          float* var) {
-    __shared__ double r1[8][32], r2[8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), row0 = threadIdx.x >> 5;
-    const bool cv = c < C;
-    const float piv = cv ? x[c] : 0.f;
-    double s1 = 0.0, s2 = 0.0;
-    if (cv)
-        for (size_t m = row0; m < M; m += 8) {
-            const double d = (double)(x[m * C + c] - piv);
-            s1 += d;
-            s2 += d * d;
-        }
-    r1[row0][threadIdx.x & 31] = s1;
-    r2[row0][threadIdx.x & 31] = s2;
-    __syncthreads();
-    if (row0 == 0 && cv) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < 8; ++k) { a += r1[k][threadIdx.x]; b += r2[k][threadIdx.x]; }
-        const double md = a / (double)M;
-        mean[c] = (float)((double)piv + md);
-        double v = b / (double)M - md * md;
-        var[c] = (float)(v > 0 ? v : 0);
+// per-(device, stream) scratch for the partial sums; grows on demand (hipFree synchronises the device, so a buffer
+// is never released under a kernel that still uses it)
+static void* rn_scratch(hipStream_t s, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = pool[std::make_pair(dev, s)];
+    if (e.second < bytes) {
+        if (e.first) (void)hipFree(e.first);
+        e.first = nullptr;
+        e.second = 0;
+        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        if (hipMalloc(&e.first, want) != hipSuccess) { e.first = nullptr; return nullptr; }
+        e.second = want;
     }
+    return e.first;
+}
+
+// ---------------------------------------------------------------------------
+// batch norm over [M][C] fp32.  Partial sums: grid (channel groups of 32, row slices); 256 threads = RPP rows x 32
+// channels per pass (VEC = 4: eight lanes x float4 per 128-byte row segment, 32 rows per pass; VEC = 1 for channel
+// counts that are not multiples of 4).  Forward: shifted sums about the first row.  Backward: S1 = sum dz,
+// S2 = sum dz * xhat with dz = dy * [y > 0].  part[0][slice][c], part[1][slice][c] in double.
+// ---------------------------------------------------------------------------
+struct RnSlices {
+    int groups, slices;
+    size_t rows_per_slice;
+};
+static RnSlices rn_slices(size_t M, int C, int vec) {
+    const int rpp = 256 / (32 / vec);
+    RnSlices r;
+    r.groups = (C + 31) / 32;
+    size_t want = 2048 / (size_t)r.groups;
+    if (want < 1) want = 1;
+    const size_t maxs = (M + (size_t)rpp * 4 - 1) / ((size_t)rpp * 4);   // at least four passes per workgroup
+    if (want > maxs) want = maxs;
+    size_t rps = (M + want - 1) / want;
+    rps = (rps + rpp - 1) / rpp * rpp;
+    r.rows_per_slice = rps;
+    r.slices = (int)((M + rps - 1) / rps);
+    return r;
+}
+
+template <int VEC, bool BWD>
+__global__ __launch_bounds__(256) void rn_bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ y, size_t M, int C,
+                                                            const float* __restrict__ mean, const float* __restrict__ var,
+                                                            float eps, int relu, size_t rows_per_slice,
+                                                            double* __restrict__ part) {
+    constexpr int LPR = 32 / VEC, RPP = 256 / LPR;
+    __shared__ double r1[RPP][33], r2[RPP][33];
+    const int cl = (threadIdx.x % LPR) * VEC, row0 = threadIdx.x / LPR;
+    const int c = blockIdx.x * 32 + cl;
+    const bool cv = c < C;                       // VEC = 4 is only launched with C % 4 == 0
+    size_t m0 = (size_t)blockIdx.y * rows_per_slice, m1 = m0 + rows_per_slice;
+    if (m1 > M) m1 = M;
+    double s1[VEC], s2[VEC];
+    float a[VEC], b[VEC];                        // forward: pivot, -; backward: mean, invstd
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        s1[v] = 0.0;
+        s2[v] = 0.0;
+        a[v] = 0.f;
+        b[v] = 1.f;
+        if (cv) {
+            if (BWD) { a[v] = mean[c + v]; b[v] = 1.0f / sqrtf(var[c + v] + eps); }
+            else a[v] = x[c + v];
+        }
+    }
+    if (cv) {
+#pragma unroll 4
+        for (size_t m = m0 + row0; m < m1; m += RPP) {
+            const size_t i = m * C + c;
+            float xv[VEC], dv[VEC], yv[VEC];
+            if constexpr (VEC == 4) {
+                const float4 t = *(const float4*)(x + i);
+                xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+                if constexpr (BWD) {
+                    const float4 d = *(const float4*)(dy + i);
+                    dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+                    if (relu) {
+                        const float4 q = *(const float4*)(y + i);
+                        yv[0] = q.x; yv[1] = q.y; yv[2] = q.z; yv[3] = q.w;
+                    }
+                }
+            } else {
+                xv[0] = x[i];
+                if constexpr (BWD) {
+                    dv[0] = dy[i];
+                    if (relu) yv[0] = y[i];
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                if constexpr (BWD) {
+                    const float dz = (relu && !(yv[v] > 0.f)) ? 0.f : dv[v];
+                    s1[v] += (double)dz;
+                    s2[v] += (double)dz * (double)((xv[v] - a[v]) * b[v]);
+                } else {
+                    const double d = (double)(xv[v] - a[v]);
+                    s1[v] += d;
+                    s2[v] += d * d;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        r1[row0][cl + v] = s1[v];
+        r2[row0][cl + v] = s2[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int cc = blockIdx.x * 32 + threadIdx.x;
+        if (cc < C) {
+            double p = 0.0, q = 0.0;
+            for (int k = 0; k < RPP; ++k) { p += r1[k][threadIdx.x]; q += r2[k][threadIdx.x]; }
+            const size_t o = (size_t)blockIdx.y * C + cc;
+            part[o] = p;
+            part[(size_t)gridDim.y * C + o] = q;
+        }
+    }
+}
+// one workgroup per 32 channels: eight slice lanes per channel add every eighth slice, then one thread adds the
+// eight sums -- the same order every run (a single thread walking 1024 slices was latency-bound: 50 us)
+template <bool BWD>
+__global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const double* __restrict__ part, int slices, int C, size_t M,
+                                                             const float* __restrict__ x, float* o1, float* o2) {
+    __shared__ double r1[8][33], r2[8][33];
+    const int cl = threadIdx.x & 31, k0 = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double p = 0.0, q = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int k = k0; k < slices; k += 8) {
+            p += part[(size_t)k * C + c];
+            q += part[((size_t)slices + k) * C + c];
+        }
+    }
+    r1[k0][cl] = p;
+    r2[k0][cl] = q;
+    __syncthreads();
+    if (k0 != 0 || c >= C) return;
+    p = 0.0;
+    q = 0.0;
+    for (int k = 0; k < 8; ++k) { p += r1[k][cl]; q += r2[k][cl]; }
+    if (BWD) {
+        o2[c] = (float)p;     // dbeta
+        o1[c] = (float)q;     // dgamma
+    } else {
+        const double md = p / (double)M;
+        o1[c] = (float)((double)x[c] + md);
+        const double v = q / (double)M - md * md;
+        o2[c] = (float)(v > 0 ? v : 0);
+    }
+}
+template <bool BWD>
+static hipError_t rn_bn_reduce(const float* x, const float* dy, const float* y, size_t M, int C, const float* mean,
+                               const float* var, float eps, int relu, float* o1, float* o2, hipStream_t s) {
+    const uintptr_t al = (uintptr_t)x | (uintptr_t)dy | (uintptr_t)y;
+    const int vec = (C % 4 == 0 && al % 16 == 0) ? 4 : 1;
+    const RnSlices sl = rn_slices(M, C, vec);
+    double* part = (double*)rn_scratch(s, (size_t)2 * sl.slices * C * sizeof(double));
+    if (!part) return hipErrorOutOfMemory;
+    const dim3 grid(sl.groups, sl.slices);
+    if (vec == 4)
+        hipLaunchKernelGGL((rn_bn_partial_kernel<4, BWD>), grid, dim3(256), 0, s, x, dy, y, M, C, mean, var, eps, relu,
+                           sl.rows_per_slice, part);
+    else
+        hipLaunchKernelGGL((rn_bn_partial_kernel<1, BWD>), grid, dim3(256), 0, s, x, dy, y, M, C, mean, var, eps, relu,
+                           sl.rows_per_slice, part);
+    hipLaunchKernelGGL((rn_bn_finalize_kernel<BWD>), dim3(sl.groups), dim3(256), 0, s, part, sl.slices, C, M, x, o1, o2);
+    return hipGetLastError();
 }
 
 // y = act(gamma (x - mean) invstd + beta + res); moving <- decay moving + (1 - decay) batch when update
@@ -94,34 +248,6 @@ __global__ void rn_bn_moving_kernel(float* mm, float* mv, const float* mean, con
     mv[c] = decay * mv[c] + (1.0f - decay) * var[c] * unbias;
 }
 
-// backward: dz = dy * [y > 0] (ReLU on the stored output) ; S1 = sum dz, S2 = sum dz * xhat
-__global__ __launch_bounds__(256) void rn_bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                               const float* __restrict__ x, size_t M, int C,
-                                                               const float* mean, const float* var, float eps, int relu,
-                                                               float* dgamma, float* dbeta) {
-    __shared__ double r1[8][32], r2[8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), row0 = threadIdx.x >> 5;
-    const bool cv = c < C;
-    double s1 = 0.0, s2 = 0.0;
-    if (cv) {
-        const float mu = mean[c], inv = 1.0f / sqrtf(var[c] + eps);
-        for (size_t m = row0; m < M; m += 8) {
-            const size_t i = m * C + c;
-            const float dz = (relu && !(y[i] > 0.f)) ? 0.f : dy[i];
-            s1 += (double)dz;
-            s2 += (double)dz * (double)((x[i] - mu) * inv);
-        }
-    }
-    r1[row0][threadIdx.x & 31] = s1;
-    r2[row0][threadIdx.x & 31] = s2;
-    __syncthreads();
-    if (row0 == 0 && cv) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < 8; ++k) { a += r1[k][threadIdx.x]; b += r2[k][threadIdx.x]; }
-        dbeta[c] = (float)a;
-        dgamma[c] = (float)b;
-    }
-}
 // dx = gamma invstd (dz - dbeta/M - xhat dgamma/M)   (training)   |   gamma invstd dz   (moving statistics)
 // dres = dz (the residual branch enters before the activation)
 __global__ void rn_bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -185,51 +311,96 @@ __global__ void rn_maxpool3_kernel(const float* __restrict__ x, float* __restric
 
 // ---------------------------------------------------------------------------
 // root convolution: conv2d_same(64, 7, stride 2) on [N,H,W,3]: pad 3 before / 3 after, VALID stride 2
-// forward: one thread per (pixel, cout): 147 MACs;  filter gradient: one block per (kh, kw, c), thread = cout
+// (resnet_utils.py:77-122 -- explicit padding, not TF 'SAME').  One workgroup per output row (n, ho), persistent over
+// rows: the seven zero-padded input rows of that output row sit in LDS ([7][(W + 6) * 3] floats, 19 KB at 224), a
+// lane owns one filter (co), and the 21 (kw, c) taps of one filter row are CONTIGUOUS in the staged row -- the patch
+// reads are wave-uniform (LDS broadcast, no bank conflicts).
+//   forward: wave = slice of the output columns, all 147 taps of filter co in registers;
+//   filter gradient: wave = kh, 21 accumulators per lane, dy[p][co] read coalesced; every workgroup leaves its partial
+//   dW in the scratch buffer and a second kernel adds the partials in order (deterministic).
 // ---------------------------------------------------------------------------
-__global__ void rn_conv7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N,
-                                    int H, int W, int Co) {
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;     // (H + 6 - 7) / 2 + 1
-    const size_t total = (size_t)N * Ho * Wo * Co;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Co);
-        const size_t p = i / Co;
-        const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), n = (int)(p / ((size_t)Wo * Ho));
-        float acc = 0.f;
-        for (int kh = 0; kh < 7; ++kh) {
-            const int h = ho * 2 + kh - 3;
-            if (h < 0 || h >= H) continue;
-            for (int kw = 0; kw < 7; ++kw) {
-                const int ww = wo * 2 + kw - 3;
-                if (ww < 0 || ww >= W) continue;
-                const float* xp = x + (((size_t)n * H + h) * W + ww) * 3;
-                const float* wp = w + ((size_t)(kh * 7 + kw) * 3) * Co + co;
-                acc = fmaf(xp[0], wp[0], acc);
-                acc = fmaf(xp[1], wp[Co], acc);
-                acc = fmaf(xp[2], wp[2 * Co], acc);
-            }
+constexpr int kC7Threads = 448;   // seven waves
+
+Y2_DEV void rn_conv7_stage(const float* __restrict__ x, float* xs, int n, int ho, int H, int W) {
+    const int rowf = (W + 6) * 3;
+    for (int kh = 0; kh < 7; ++kh) {
+        const int h = ho * 2 + kh - 3;
+        const bool hv = h >= 0 && h < H;
+        const float* src = x + ((size_t)n * H + (hv ? h : 0)) * W * 3;
+        float* dst = xs + kh * rowf;
+        for (int i = threadIdx.x; i < rowf; i += kC7Threads) {
+            const int j = i - 9;
+            dst[i] = (hv && j >= 0 && j < W * 3) ? src[j] : 0.f;
         }
-        y[i] = acc;
     }
 }
-__global__ __launch_bounds__(256) void rn_conv7_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             float* __restrict__ dw, int N, int H, int W, int Co) {
-    // block = (kh, kw, c); 256 threads = 64 couts x 4 pixel slices
-    __shared__ float red[4][64];
-    const int t = blockIdx.x, c = t % 3, kw = (t / 3) % 7, kh = t / 21;
-    const int co = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    float acc = 0.f;
-    if (co < Co)
-        for (size_t p = sl; p < (size_t)N * Ho * Wo; p += 4) {
-            const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), n = (int)(p / ((size_t)Wo * Ho));
-            const int h = ho * 2 + kh - 3, ww = wo * 2 + kw - 3;
-            if (h < 0 || h >= H || ww < 0 || ww >= W) continue;
-            acc = fmaf(x[(((size_t)n * H + h) * W + ww) * 3 + c], dy[p * Co + co], acc);
+
+__global__ __launch_bounds__(kC7Threads) void rn_conv7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  float* __restrict__ y, int N, int H, int W, int Co) {
+    extern __shared__ float xs[];
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;     // (H + 6 - 7) / 2 + 1
+    const int rowf = (W + 6) * 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int co0 = 0; co0 < Co; co0 += 64) {
+        const int co = co0 + lane;
+        float wr[147];
+#pragma unroll
+        for (int t = 0; t < 147; ++t) wr[t] = co < Co ? w[(size_t)t * Co + co] : 0.f;
+        for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+            const int n = row / Ho, ho = row % Ho;
+            __syncthreads();
+            rn_conv7_stage(x, xs, n, ho, H, W);
+            __syncthreads();
+            for (int wo = wave; wo < Wo; wo += 7) {
+                float acc = 0.f;
+#pragma unroll
+                for (int kh = 0; kh < 7; ++kh) {
+                    const float* xp = xs + kh * rowf + wo * 6;
+#pragma unroll
+                    for (int j = 0; j < 21; ++j) acc = fmaf(xp[j], wr[kh * 21 + j], acc);
+                }
+                if (co < Co) y[((size_t)row * Wo + wo) * Co + co] = acc;
+            }
         }
-    red[sl][co] = acc;
-    __syncthreads();
-    if (sl == 0 && co < Co) dw[(size_t)t * Co + co] = red[0][co] + red[1][co] + red[2][co] + red[3][co];
+    }
+}
+
+__global__ __launch_bounds__(kC7Threads) void rn_conv7_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                    float* __restrict__ part, int N, int H, int W, int Co) {
+    extern __shared__ float xs[];
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int rowf = (W + 6) * 3;
+    const int co = threadIdx.x & 63, kh = threadIdx.x >> 6;
+    float acc[21];
+#pragma unroll
+    for (int j = 0; j < 21; ++j) acc[j] = 0.f;
+    for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+        const int n = row / Ho, ho = row % Ho;
+        __syncthreads();
+        rn_conv7_stage(x, xs, n, ho, H, W);
+        __syncthreads();
+        const float* dyr = dy + (size_t)row * Wo * Co + co;
+        const float* xr = xs + kh * rowf;
+#pragma unroll 4
+        for (int wo = 0; wo < Wo; ++wo) {
+            const float d = co < Co ? dyr[(size_t)wo * Co] : 0.f;
+            const float* xp = xr + wo * 6;
+#pragma unroll
+            for (int j = 0; j < 21; ++j) acc[j] = fmaf(xp[j], d, acc[j]);
+        }
+    }
+    if (co < Co) {
+        float* o = part + (size_t)blockIdx.x * 147 * Co;
+#pragma unroll
+        for (int j = 0; j < 21; ++j) o[(size_t)(kh * 21 + j) * Co + co] = acc[j];
+    }
+}
+__global__ void rn_sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * n + i];
+    out[i] = s;
 }
 
 // ---------------------------------------------------------------------------
@@ -282,8 +453,7 @@ int y2_batch_norm_forward(const float* x, const float* residual, float* y, size_
     hipStream_t s = (hipStream_t)stream;
     const size_t total = rows * channels;
     if (is_training) {
-        hipLaunchKernelGGL(rn_bn_stats_kernel, dim3((channels + 31) / 32), dim3(256), 0, s, x, rows, channels, save_mean,
-                           save_var);
+        RCHK((rn_bn_reduce<false>(x, nullptr, nullptr, rows, channels, nullptr, nullptr, eps, 0, save_mean, save_var, s)));
         if (update_moving) {
             // slim.batch_norm feeds the moving variance the UNBIASED batch variance (fused_batch_norm semantics are
             // version dependent; tf.nn.moments + assign_moving_average of the non-fused path use the biased one,
@@ -310,8 +480,7 @@ int y2_batch_norm_backward(const float* dy, const float* y, const float* x, floa
         return rfail(Y2_ERR_ARG, "bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const size_t total = rows * channels;
-    hipLaunchKernelGGL(rn_bn_bwd_reduce_kernel, dim3((channels + 31) / 32), dim3(256), 0, s, dy, y, x, rows, channels,
-                       save_mean, save_var, eps, relu, dgamma, dbeta);
+    RCHK((rn_bn_reduce<true>(x, dy, y, rows, channels, save_mean, save_var, eps, relu, dgamma, dbeta, s)));
     hipLaunchKernelGGL(rn_bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, y, x, dx, dresidual, total, rows,
                        channels, save_mean, save_var, gamma, eps, relu, is_training, dgamma, dbeta);
     RCHK(hipGetLastError());
@@ -347,17 +516,27 @@ int y2_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, 
 }
 
 int y2_conv7x7s2(const float* x, const float* w, float* y, int N, int H, int W, int Cout, void* stream) {
-    if (!x || !w || !y) return rfail(Y2_ERR_ARG, "null tensor");
-    const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * Cout;
-    hipLaunchKernelGGL(rn_conv7_fwd_kernel, dim3(grid_for(total, 65536)), dim3(256), 0, (hipStream_t)stream, x, w, y, N, H, W,
-                       Cout);
+    if (!x || !w || !y || N < 1 || H < 1 || W < 1 || Cout < 1) return rfail(Y2_ERR_ARG, "bad arguments");
+    const size_t lds = (size_t)7 * (W + 6) * 3 * sizeof(float);
+    if (lds > 64 * 1024) return rfail(Y2_ERR_ARG, "image rows of %d pixels do not fit the staged window", W);
+    const int rows = N * ((H + 1) / 2);
+    hipLaunchKernelGGL(rn_conv7_fwd_kernel, dim3(rows < 1024 ? rows : 1024), dim3(kC7Threads), lds, (hipStream_t)stream, x, w,
+                       y, N, H, W, Cout);
     RCHK(hipGetLastError());
     return Y2_OK;
 }
 int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* stream) {
-    if (!x || !dy || !dw) return rfail(Y2_ERR_ARG, "null tensor");
-    if (Cout > 64) return rfail(Y2_ERR_ARG, "the root convolution has 64 filters (resnet_v1.py:197)");
-    hipLaunchKernelGGL(rn_conv7_wgrad_kernel, dim3(147), dim3(256), 0, (hipStream_t)stream, x, dy, dw, N, H, W, Cout);
+    if (!x || !dy || !dw || N < 1 || H < 1 || W < 1) return rfail(Y2_ERR_ARG, "bad arguments");
+    if (Cout < 1 || Cout > 64) return rfail(Y2_ERR_ARG, "the root convolution has 64 filters (resnet_v1.py:197)");
+    const size_t lds = (size_t)7 * (W + 6) * 3 * sizeof(float);
+    if (lds > 64 * 1024) return rfail(Y2_ERR_ARG, "image rows of %d pixels do not fit the staged window", W);
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = N * ((H + 1) / 2);
+    const int blocks = rows < 512 ? rows : 512;
+    float* part = (float*)rn_scratch(s, (size_t)blocks * 147 * Cout * sizeof(float));
+    if (!part) return rfail(Y2_ERR_HIP, "no scratch memory for the filter-gradient partials");
+    hipLaunchKernelGGL(rn_conv7_wgrad_kernel, dim3(blocks), dim3(kC7Threads), lds, s, x, dy, part, N, H, W, Cout);
+    hipLaunchKernelGGL(rn_sum_partials_kernel, dim3((147 * Cout + 255) / 256), dim3(256), 0, s, part, dw, blocks, 147 * Cout);
     RCHK(hipGetLastError());
     return Y2_OK;
 }

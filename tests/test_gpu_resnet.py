@@ -104,6 +104,58 @@ def test_root_convolution_7x7_stride2():
         assert rel(dw.cpu().numpy(), wtt.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("shape,relu", [((8, 112, 112, 64), True), ((16, 7, 7, 2048), True), ((4, 56, 56, 256), False),
+                                        ((2, 9, 7, 6), True)])
+def test_batch_norm_at_the_network_shapes_vs_float64(shape, relu):
+    """The two-level reductions (row slices x channel groups, double partials added in a fixed order) at the shapes
+    the batch-32 ResNet-50 step runs them at -- statistics, dgamma / dbeta and dx against float64 -- and twice in a
+    row with the same bits (resnet_utils.py:230-257)."""
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(11)
+    C = shape[-1]
+    x = (rng.standard_normal(shape) * rng.uniform(0.5, 3.0, C) + rng.uniform(-2, 2, C)).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, C).astype(np.float32); beta = rng.uniform(-0.5, 0.5, C).astype(np.float32)
+    dy = rng.standard_normal(shape).astype(np.float32)
+    x64 = x.astype(np.float64).reshape(-1, C); M = x64.shape[0]
+    mean = x64.mean(0); var = x64.var(0); inv = 1.0 / np.sqrt(var + 1e-5)
+    xh = (x64 - mean) * inv
+    y64 = xh * gamma + beta
+    if relu:
+        y64 = np.maximum(y64, 0)
+    mm, mv = dev(np.zeros(C)), dev(np.ones(C))
+    y, sm, sv = E.batch_norm_forward(dev(x), dev(gamma), dev(beta), mm, mv, None, True, True, relu)
+    assert rel(sm.cpu().numpy(), mean) < 1e-6 and rel(sv.cpu().numpy(), var) < 2e-6
+    assert rel(y.cpu().numpy().reshape(-1, C), y64) < 1e-5
+    yk = y.cpu().numpy().astype(np.float64).reshape(-1, C)
+    dz = dy.astype(np.float64).reshape(-1, C) * ((yk > 0) if relu else 1.0)
+    dbeta = dz.sum(0); dgamma = (dz * xh).sum(0)
+    dx64 = gamma * inv * (dz - dbeta / M - xh * dgamma / M)
+    dx, _, dg, db = E.batch_norm_backward(dev(dy), y, dev(x), dev(gamma), sm, sv, True, relu, False)
+    assert rel(dg.cpu().numpy(), dgamma) < 2e-5 and rel(db.cpu().numpy(), dbeta) < 2e-5
+    assert rel(dx.cpu().numpy().reshape(-1, C), dx64) < 2e-5
+    dx2, _, dg2, db2 = E.batch_norm_backward(dev(dy), y, dev(x), dev(gamma), sm, sv, True, relu, False)
+    assert torch.equal(dg, dg2) and torch.equal(db, db2) and torch.equal(dx, dx2)
+
+
+def test_root_convolution_at_224_vs_float64():
+    """conv2d_same(64, 7, stride 2) and its filter gradient at the network's geometry (224 x 224, 64 filters, batch 8:
+    896 output rows over 512 persistent workgroups), plus an odd width with 24 filters (resnet_v1.py:197)."""
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(12)
+    for (n, h, w, co) in ((8, 224, 224, 64), (1, 37, 51, 24)):
+        x = rng.uniform(-1, 1, (n, h, w, 3)).astype(np.float32)
+        wt = (rng.standard_normal((7, 7, 3, co)) * 0.1).astype(np.float32)
+        wtt = torch.tensor(wt, dtype=torch.float64, requires_grad=True)
+        ref = RR.conv2d_same(torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2), wtt, 2).permute(0, 2, 3, 1)
+        y = E.conv7x7_s2(dev(x), dev(wt))
+        assert tuple(y.shape) == tuple(ref.shape) and rel(y.cpu().numpy(), ref.detach().numpy()) < 1e-5
+        dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        ref.backward(torch.tensor(dy, dtype=torch.float64))
+        dw = E.conv7x7_s2_backward_filter(dev(x), dev(dy))
+        assert rel(dw.cpu().numpy(), wtt.grad.numpy()) < 2e-5
+        assert torch.equal(dw, E.conv7x7_s2_backward_filter(dev(x), dev(dy)))
+
+
 def test_dropout_mask_is_a_function_of_the_seed():
     from tensorflow_yolo2_amd import engine as E
     x = torch.ones(1 << 16, device="cuda")
