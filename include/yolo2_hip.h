@@ -206,6 +206,15 @@ int y2_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, 
 /* root block: conv2d_same(net, 64, 7, stride=2) on the image [N,H,W,3], filter HWIO [7][7][3][Cout] (resnet_v1.py:197) */
 int y2_conv7x7s2(const float* x, const float* w, float* y, int N, int H, int W, int Cout, void* stream);
 int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* stream);
+/* slim.fully_connected (pascal_train_resnet.py:41-46; the flattened 7x7x2048 features -> 4096 -> S*S*(5B+C)) for a
+ * batch of 1..128 rows: y [rows][out] = act(x [rows][in] * w [in][out] + bias), bias may be NULL, in_features a multiple
+ * of 16.  One pass over the fp32 weights, converted in registers to `dtype` (0 fp32, 1 f16, 2 bf16) for the matrix
+ * cores, fp32 accumulation and fp32 results.  Backward: dx [rows][in] = dy * w^T (NULL: skipped),
+ * dw [in][out] = x^T * dy (NULL: skipped); dy is the gradient at the pre-activation (y2_bias_relu_backward). */
+int y2_fully_connected(const float* x, const float* w, const float* bias, float* y, int rows, int in_features,
+                       int out_features, int relu, int dtype, void* stream);
+int y2_fully_connected_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int rows,
+                                int in_features, int out_features, int dtype, void* stream);
 /* slim.fully_connected tail (pascal_train_resnet.py:41-46): y <- act(y + bias) in place; backward dz = dy [y > 0],
  * dbias = column sums; tf.nn.dropout(x, keep_prob) with a mask that is a function of (seed, index) */
 int y2_bias_relu(float* y, const float* bias, size_t rows, int channels, int relu, void* stream);

@@ -329,4 +329,7 @@ hipError_t launch_init_trunc_normal(float* p, size_t n, float stddev, uint64_t s
                                     hipStream_t s);
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 
+// per-(device, stream) scratch of the graph-level operators (split partial sums); grows on demand, never shrinks
+void* op_scratch(hipStream_t s, size_t bytes);
+
 }  // namespace y2

@@ -25,6 +25,7 @@
 
 #include "../../include/yolo2_hip.h"
 #include "common.h"
+#include "kernels.h"
 
 namespace y2 {
 int set_error(int code, const char* msg);
@@ -53,7 +54,8 @@ static inline unsigned grid_for(size_t total, unsigned cap = 16384) {
 
 // per-(device, stream) scratch for the partial sums; grows on demand (hipFree synchronises the device, so a buffer
 // is never released under a kernel that still uses it)
-static void* rn_scratch(hipStream_t s, size_t bytes) {
+namespace y2 {
+void* op_scratch(hipStream_t s, size_t bytes) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> pool;
     int dev = 0;
@@ -70,6 +72,7 @@ static void* rn_scratch(hipStream_t s, size_t bytes) {
     }
     return e.first;
 }
+}  // namespace y2
 
 // ---------------------------------------------------------------------------
 // batch norm over [M][C] fp32.  Partial sums: grid (channel groups of 32, row slices); 256 threads = RPP rows x 32
@@ -215,7 +218,7 @@ static hipError_t rn_bn_reduce(const float* x, const float* dy, const float* y, 
     const uintptr_t al = (uintptr_t)x | (uintptr_t)dy | (uintptr_t)y;
     const int vec = (C % 4 == 0 && al % 16 == 0) ? 4 : 1;
     const RnSlices sl = rn_slices(M, C, vec);
-    double* part = (double*)rn_scratch(s, (size_t)2 * sl.slices * C * sizeof(double));
+    double* part = (double*)op_scratch(s, (size_t)2 * sl.slices * C * sizeof(double));
     if (!part) return hipErrorOutOfMemory;
     const dim3 grid(sl.groups, sl.slices);
     if (vec == 4)
@@ -533,7 +536,7 @@ int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int
     hipStream_t s = (hipStream_t)stream;
     const int rows = N * ((H + 1) / 2);
     const int blocks = rows < 512 ? rows : 512;
-    float* part = (float*)rn_scratch(s, (size_t)blocks * 147 * Cout * sizeof(float));
+    float* part = (float*)op_scratch(s, (size_t)blocks * 147 * Cout * sizeof(float));
     if (!part) return rfail(Y2_ERR_HIP, "no scratch memory for the filter-gradient partials");
     hipLaunchKernelGGL(rn_conv7_wgrad_kernel, dim3(blocks), dim3(kC7Threads), lds, s, x, dy, part, N, H, W, Cout);
     hipLaunchKernelGGL(rn_sum_partials_kernel, dim3((147 * Cout + 255) / 256), dim3(256), 0, s, part, dw, blocks, 147 * Cout);

@@ -806,6 +806,37 @@ def conv7x7_s2_backward_filter(x, dy):
     return dw
 
 
+def fully_connected(x, w, bias=None, relu=True, dtype="f32"):
+    """slim.fully_connected on [rows, in] (rows = the batch, at most 128): act(x w + bias) -> [rows, out] fp32
+    (pascal_train_resnet.py:41-46); one pass over the fp32 weights (csrc/fc.hip)"""
+    lib = _lib.load()
+    _chk(x, w, bias)
+    m, k = x.shape
+    assert w.shape[0] == k
+    n = w.shape[1]
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    check(lib.y2_fully_connected(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), m, k, n, int(relu), _lib.DTYPES[dtype], _stream()))
+    return y
+
+
+def fully_connected_backward(x, w, dz, dtype="f32", want_dx=True, dw_out=None):
+    """dz = gradient at the pre-activation [rows, out] -> (dx [rows, in] or None, dw [in, out])"""
+    lib = _lib.load()
+    _chk(x, w, dz)
+    m, k = x.shape
+    n = w.shape[1]
+    assert tuple(dz.shape) == (m, n)
+    dx = torch.empty_like(x) if want_dx else None
+    if dw_out is not None:
+        assert dw_out.is_cuda and dw_out.dtype == torch.float32 and dw_out.is_contiguous() and dw_out.numel() == w.numel()
+        dw = dw_out
+    else:
+        dw = torch.empty_like(w)
+    check(lib.y2_fully_connected_backward(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), _ptr(dw), m, k, n, _lib.DTYPES[dtype],
+                                          _stream()))
+    return dx, dw
+
+
 def bias_relu_(y, bias, relu=True):
     lib = _lib.load()
     _chk(y, bias)

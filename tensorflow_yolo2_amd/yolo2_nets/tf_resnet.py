@@ -200,16 +200,12 @@ class ResNet50Yolo:
                 x = out
         feat = x                                                                              # [N,S,S,depth]
         n = self.batch
-        flat = feat.reshape(n, 1, 1, -1).contiguous()                                         # slim.flatten (NHWC order)
-        w1 = self.p["yolo_fc1/weights"]
-        fc1 = E.conv2d(flat, w1.view(1, 1, *w1.shape), None, self.dtype).view(n, -1)          # FC = 1x1 conv on a 1x1 map
-        E.bias_relu_(fc1, self.p["yolo_fc1/biases"], True)
+        flat = feat.reshape(n, -1).contiguous()                                               # slim.flatten (NHWC order)
+        fc1 = E.fully_connected(flat, self.p["yolo_fc1/weights"], self.p["yolo_fc1/biases"], True, self.dtype)
         use_drop = bool(dropout and is_training)
         self.drop_seed += 1
         h = E.dropout(fc1, self.keep_prob, self.drop_seed) if use_drop else fc1
-        w2 = self.p["yolo_fc2/weights"]
-        fc2 = E.conv2d(h.view(n, 1, 1, -1), w2.view(1, 1, *w2.shape), None, self.dtype).view(n, -1)
-        E.bias_relu_(fc2, self.p["yolo_fc2/biases"], True)
+        fc2 = E.fully_connected(h, self.p["yolo_fc2/weights"], self.p["yolo_fc2/biases"], True, self.dtype)
         tape.append(("head", feat, flat, fc1, h, fc2, use_drop, self.drop_seed))
         self.tape = tape
         return fc2.view(n, self.S, self.S, self.out_c)
@@ -221,16 +217,13 @@ class ResNet50Yolo:
         _k, feat, flat, fc1, h, fc2, use_drop, seed = self.tape[-1]
         dz2, db2 = E.bias_relu_backward(dgrid.reshape(n, -1).contiguous(), fc2, True)
         self.g["yolo_fc2/biases"].copy_(db2)
-        w2 = self.p["yolo_fc2/weights"]
-        dh, _ = E.conv2d_backward(h.view(n, 1, 1, -1), w2.view(1, 1, *w2.shape), dz2.view(n, 1, 1, -1), self.dtype,
-                                  dw_out=self.g["yolo_fc2/weights"])
-        dh = dh.view(n, -1)
-        dfc1 = E.dropout(dh.contiguous(), self.keep_prob, seed) if use_drop else dh        # same mask, same 1/keep scale
-        dz1, db1 = E.bias_relu_backward(dfc1.contiguous(), fc1, True)
+        dh, _ = E.fully_connected_backward(h, self.p["yolo_fc2/weights"], dz2, self.dtype,
+                                           dw_out=self.g["yolo_fc2/weights"])
+        dfc1 = E.dropout(dh, self.keep_prob, seed) if use_drop else dh                      # same mask, same 1/keep scale
+        dz1, db1 = E.bias_relu_backward(dfc1, fc1, True)
         self.g["yolo_fc1/biases"].copy_(db1)
-        w1 = self.p["yolo_fc1/weights"]
-        dflat, _ = E.conv2d_backward(flat, w1.view(1, 1, *w1.shape), dz1.view(n, 1, 1, -1), self.dtype,
-                                     dw_out=self.g["yolo_fc1/weights"])
+        dflat, _ = E.fully_connected_backward(flat, self.p["yolo_fc1/weights"], dz1, self.dtype,
+                                              dw_out=self.g["yolo_fc1/weights"])
         dx = dflat.reshape(feat.shape).contiguous()
         for rec in reversed(self.tape[:-1]):
             if rec[0] == "unit":

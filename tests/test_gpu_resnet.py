@@ -156,6 +156,43 @@ def test_root_convolution_at_224_vs_float64():
         assert torch.equal(dw, E.conv7x7_s2_backward_filter(dev(x), dev(dy)))
 
 
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("f16", 1e-3), ("bf16", 8e-3)])
+@pytest.mark.parametrize("M,K,N", [(32, 25088, 1024), (4, 1024, 98), (70, 512, 200), (128, 4096, 1470), (1, 16, 3)])
+def test_fully_connected_forward_backward_vs_float64(M, K, N, dtype, tol):
+    """slim.fully_connected (pascal_train_resnet.py:41-46) on the weight-streaming kernels of csrc/fc.hip: forward with
+    bias + ReLU, dx and dW against float64 (tolerances relative to each tensor's maximum: fp32 round-off, half-precision
+    operand rounding with fp32 accumulation), ragged row / column counts, and the same bits twice."""
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(M * 7 + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, N).astype(np.float32)
+    dz = rng.standard_normal((M, N)).astype(np.float32)
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    y64 = np.maximum(x64 @ w64 + b, 0)
+    dx, dw, dzd = dev(x), dev(w), dev(dz)
+    y = E.fully_connected(dx, dw, dev(b), True, dtype)
+    assert rel(y.cpu().numpy(), y64) < tol
+    lin = E.fully_connected(dx, dw, None, False, dtype)
+    assert rel(lin.cpu().numpy(), x64 @ w64) < tol
+    gx, gw = E.fully_connected_backward(dx, dw, dzd, dtype)
+    assert rel(gx.cpu().numpy(), dz.astype(np.float64) @ w64.T) < tol
+    assert rel(gw.cpu().numpy(), x64.T @ dz.astype(np.float64)) < tol
+    gx2, gw2 = E.fully_connected_backward(dx, dw, dzd, dtype)
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(y, E.fully_connected(dx, dw, dev(b), True, dtype))
+    none_dx, gw3 = E.fully_connected_backward(dx, dw, dzd, dtype, want_dx=False)
+    assert none_dx is None and torch.equal(gw3, gw)
+
+
+def test_fully_connected_rejects_what_it_does_not_cover():
+    from tensorflow_yolo2_amd import engine as E
+    x = torch.zeros(129, 32, device="cuda"); w = torch.zeros(32, 8, device="cuda")
+    with pytest.raises(RuntimeError):
+        E.fully_connected(x, w)
+    with pytest.raises(RuntimeError):
+        E.fully_connected(torch.zeros(4, 24, device="cuda"), torch.zeros(24, 8, device="cuda"))
+
+
 def test_dropout_mask_is_a_function_of_the_seed():
     from tensorflow_yolo2_amd import engine as E
     x = torch.ones(1 << 16, device="cuda")
