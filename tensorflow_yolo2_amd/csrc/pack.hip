@@ -123,9 +123,56 @@ __global__ void act_pack_kernel(const float* in, T* xp, float* out, int N, int H
         else out[i] = Elem<T>::to_f32(xp[po]);
     }
 }
+// the same with eight channels per thread (C, Cs multiples of 8, 16-byte aligned tensors): two 16-byte loads, one
+// 16-byte store of T (two for fp32); the scalar form spends its time on the per-element index arithmetic
+template <typename T, bool PACK>
+__global__ void act_pack8_kernel(const float* __restrict__ in, T* __restrict__ xp, float* __restrict__ out, int N, int H,
+                                 int W, int C, int Cs) {
+    const int G = (PACK ? Cs : C) / 8;
+    const size_t total = (size_t)N * H * W * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % G) * 8;
+        const size_t p = i / G;
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const int n = (int)(p / ((size_t)W * H));
+        T* q = xp + bpix(n, h, w, H, W) * Cs + c;
+        if (PACK) {
+            float v[8];
+            if (c < C) {
+                const float4 a = *(const float4*)(in + p * C + c), b = *(const float4*)(in + p * C + c + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            T t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = Elem<T>::from_f32(v[e]);
+#pragma unroll
+            for (int e = 0; e < 8 * (int)sizeof(T) / 16; ++e) ((u32x4*)q)[e] = ((const u32x4*)t)[e];
+        } else {
+            T t[8];
+#pragma unroll
+            for (int e = 0; e < 8 * (int)sizeof(T) / 16; ++e) ((u32x4*)t)[e] = ((const u32x4*)q)[e];
+            float* o = out + p * C + c;
+            *(float4*)o = make_float4(Elem<T>::to_f32(t[0]), Elem<T>::to_f32(t[1]), Elem<T>::to_f32(t[2]), Elem<T>::to_f32(t[3]));
+            *(float4*)(o + 4) = make_float4(Elem<T>::to_f32(t[4]), Elem<T>::to_f32(t[5]), Elem<T>::to_f32(t[6]), Elem<T>::to_f32(t[7]));
+        }
+    }
+}
 template <typename T, bool PACK>
 static hipError_t act_pack_T(const float* in, void* xp, float* out, int N, int H, int W, int C, int Cs,
                              hipStream_t s) {
+    if (C % 8 == 0 && Cs % 8 == 0 && (((uintptr_t)in | (uintptr_t)xp | (uintptr_t)out) & 15) == 0) {
+        size_t total8 = (size_t)N * H * W * ((PACK ? Cs : C) / 8);
+        size_t nb8 = (total8 + 255) / 256;
+        if (nb8 > 16384) nb8 = 16384;
+        if (nb8 < 1) nb8 = 1;
+        hipLaunchKernelGGL((act_pack8_kernel<T, PACK>), dim3((unsigned)nb8), dim3(256), 0, s, in, (T*)xp, out, N, H, W, C,
+                           Cs);
+        return hipGetLastError();
+    }
     size_t total = (size_t)N * H * W * (PACK ? Cs : C);
     size_t nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;
@@ -164,8 +211,43 @@ __global__ void cast_f32_kernel(const T* src, float* dst, size_t rows, int C, in
         dst[i] = scale == 1.0f ? v : v * scale;
     }
 }
+template <typename T>
+__global__ void cast_f32x8_kernel(const T* __restrict__ src, float* __restrict__ dst, size_t rows, int C, int lds,
+                                  float scale) {
+    const int G = C / 8;
+    const size_t total = rows * G;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / G;
+        const int c = (int)(i % G) * 8;
+        T t[8];
+#pragma unroll
+        for (int e = 0; e < 8 * (int)sizeof(T) / 16; ++e) ((u32x4*)t)[e] = ((const u32x4*)(src + r * lds + c))[e];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = Elem<T>::to_f32(t[e]);
+            if (scale != 1.0f) v[e] *= scale;
+        }
+        float* o = dst + r * C + c;
+        *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
 hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s,
                               float scale) {
+    if (C % 8 == 0 && lds % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+        size_t nb8 = (rows * (C / 8) + 255) / 256;
+        if (nb8 > 16384) nb8 = 16384;
+        if (nb8 < 1) nb8 = 1;
+        dim3 g8((unsigned)nb8), b8(256);
+        switch (dtype) {
+            case 0: hipLaunchKernelGGL(cast_f32x8_kernel<float>, g8, b8, 0, s, (const float*)src, dst, rows, C, lds, scale); break;
+            case 1: hipLaunchKernelGGL(cast_f32x8_kernel<half_t>, g8, b8, 0, s, (const half_t*)src, dst, rows, C, lds, scale); break;
+            case 2: hipLaunchKernelGGL(cast_f32x8_kernel<bf16_t>, g8, b8, 0, s, (const bf16_t*)src, dst, rows, C, lds, scale); break;
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     size_t total = rows * C;
     size_t nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;

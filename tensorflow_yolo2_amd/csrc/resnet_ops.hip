@@ -243,6 +243,28 @@ __global__ void rn_bn_apply_kernel(const float* __restrict__ x, const float* __r
         y[i] = relu ? fmaxf(v, 0.f) : v;
     }
 }
+// four channels per thread (C % 4 == 0, 16-byte aligned tensors)
+__global__ void rn_bn_apply4_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
+                                    size_t total4, int C, const float* mean, const float* var, const float* gamma,
+                                    const float* beta, float eps, int relu) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const float4 xv = ((const float4*)x)[i];
+        const float4 m = *(const float4*)(mean + c), v = *(const float4*)(var + c);
+        const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+        float4 o;
+        o.x = (xv.x - m.x) * (1.0f / sqrtf(v.x + eps)) * g.x + b.x;
+        o.y = (xv.y - m.y) * (1.0f / sqrtf(v.y + eps)) * g.y + b.y;
+        o.z = (xv.z - m.z) * (1.0f / sqrtf(v.z + eps)) * g.z + b.z;
+        o.w = (xv.w - m.w) * (1.0f / sqrtf(v.w + eps)) * g.w + b.w;
+        if (res) {
+            const float4 r = ((const float4*)res)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        ((float4*)y)[i] = o;
+    }
+}
 __global__ void rn_bn_moving_kernel(float* mm, float* mv, const float* mean, const float* var, int C, float decay,
                                     float unbias) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -266,6 +288,37 @@ __global__ void rn_bn_bwd_apply_kernel(const float* __restrict__ dy, const float
         if (dres) dres[i] = dz;
         const float xh = (x[i] - mean[c]) * inv;
         dx[i] = training ? gamma[c] * inv * (dz - dbeta[c] * invM - xh * dgamma[c] * invM) : gamma[c] * inv * dz;
+    }
+}
+
+__global__ void rn_bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                        const float* __restrict__ x, float* __restrict__ dx, float* __restrict__ dres,
+                                        size_t total4, size_t M, int C, const float* mean, const float* var,
+                                        const float* gamma, float eps, int relu, int training, const float* dgamma,
+                                        const float* dbeta) {
+    const float invM = 1.0f / (float)M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const float4 d4 = ((const float4*)dy)[i], x4 = ((const float4*)x)[i];
+        float dzv[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+        if (relu) {
+            const float4 y4 = ((const float4*)y)[i];
+            const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (!(yv[e] > 0.f)) dzv[e] = 0.f;
+        }
+        if (dres) ((float4*)dres)[i] = make_float4(dzv[0], dzv[1], dzv[2], dzv[3]);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float inv = 1.0f / sqrtf(var[c + e] + eps);
+            const float xh = (xv[e] - mean[c + e]) * inv;
+            o[e] = training ? gamma[c + e] * inv * (dzv[e] - dbeta[c + e] * invM - xh * dgamma[c + e] * invM)
+                            : gamma[c + e] * inv * dzv[e];
+        }
+        ((float4*)dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -446,6 +499,22 @@ __global__ void rn_dropout_kernel(const float* __restrict__ x, float* __restrict
     }
 }
 
+template <typename... P>
+static bool rn_vec4(int channels, P... ptrs) {
+    uintptr_t al = 0;
+    for (const void* q : {(const void*)ptrs...}) al |= (uintptr_t)q;
+    return channels % 4 == 0 && al % 16 == 0;
+}
+static void rn_bn_apply(const float* x, const float* res, float* y, size_t total, int channels, const float* mean,
+                        const float* var, const float* gamma, const float* beta, float eps, int relu, hipStream_t s) {
+    if (rn_vec4(channels, x, res, y, mean, var, gamma, beta))
+        hipLaunchKernelGGL(rn_bn_apply4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, s, x, res, y, total / 4, channels,
+                           mean, var, gamma, beta, eps, relu);
+    else
+        hipLaunchKernelGGL(rn_bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, res, y, total, channels, mean, var,
+                           gamma, beta, eps, relu);
+}
+
 extern "C" {
 
 int y2_batch_norm_forward(const float* x, const float* residual, float* y, size_t rows, int channels, const float* gamma,
@@ -464,13 +533,11 @@ int y2_batch_norm_forward(const float* x, const float* residual, float* y, size_
             hipLaunchKernelGGL(rn_bn_moving_kernel, dim3((channels + 255) / 256), dim3(256), 0, s, moving_mean, moving_var,
                                save_mean, save_var, channels, decay, 1.0f);
         }
-        hipLaunchKernelGGL(rn_bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, residual, y, total, channels,
-                           save_mean, save_var, gamma, beta, eps, relu);
+        rn_bn_apply(x, residual, y, total, channels, save_mean, save_var, gamma, beta, eps, relu, s);
     } else {
         RCHK(hipMemcpyAsync(save_mean, moving_mean, channels * sizeof(float), hipMemcpyDeviceToDevice, s));
         RCHK(hipMemcpyAsync(save_var, moving_var, channels * sizeof(float), hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(rn_bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, residual, y, total, channels,
-                           moving_mean, moving_var, gamma, beta, eps, relu);
+        rn_bn_apply(x, residual, y, total, channels, moving_mean, moving_var, gamma, beta, eps, relu, s);
     }
     RCHK(hipGetLastError());
     return Y2_OK;
@@ -484,8 +551,12 @@ int y2_batch_norm_backward(const float* dy, const float* y, const float* x, floa
     hipStream_t s = (hipStream_t)stream;
     const size_t total = rows * channels;
     RCHK((rn_bn_reduce<true>(x, dy, y, rows, channels, save_mean, save_var, eps, relu, dgamma, dbeta, s)));
-    hipLaunchKernelGGL(rn_bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, y, x, dx, dresidual, total, rows,
-                       channels, save_mean, save_var, gamma, eps, relu, is_training, dgamma, dbeta);
+    if (rn_vec4(channels, dy, y, x, dx, dresidual, save_mean, save_var, gamma, dgamma, dbeta))
+        hipLaunchKernelGGL(rn_bn_bwd_apply4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, s, dy, y, x, dx, dresidual,
+                           total / 4, rows, channels, save_mean, save_var, gamma, eps, relu, is_training, dgamma, dbeta);
+    else
+        hipLaunchKernelGGL(rn_bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, y, x, dx, dresidual, total,
+                           rows, channels, save_mean, save_var, gamma, eps, relu, is_training, dgamma, dbeta);
     RCHK(hipGetLastError());
     return Y2_OK;
 }
