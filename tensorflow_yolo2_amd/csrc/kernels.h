@@ -212,6 +212,10 @@ hipError_t launch_convert_grad(int dtype, const float* src, void* dst, int M, in
                                hipStream_t s);
 hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H, int W, int C, int Cs,
                              hipStream_t s);
+// whole allocation of a bordered tensor (guards, borders, body, padding channels) in one pass; hipErrorNotSupported
+// where the 16-byte form does not apply (the caller then zeroes the allocation and uses launch_pack_act)
+hipError_t launch_pack_act_region(int dtype, const float* in, void* region, size_t region_bytes, size_t front_px, int N,
+                                  int H, int W, int C, int Cs, hipStream_t s);
 hipError_t launch_pack_act(int dtype, const float* in, void* xp, int N, int H, int W, int C, int Cs,
                            hipStream_t s);
 hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s,

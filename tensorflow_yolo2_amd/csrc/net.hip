@@ -1179,6 +1179,18 @@ static OpPlan op_plan(int N, int H, int W, int Cin, int Cout, int k, int dtype) 
     p.total = off;
     return p;
 }
+// fp32 NHWC -> the bordered tensor of the op-level entries.  Only the bordered activations rely on zeros (guards, borders,
+// channel padding; the filter packs write their own padding): one pass writes the whole allocation where the 16-byte
+// form applies, else memset + the scalar pack.
+static hipError_t op_pack_bordered(int dtype, const float* x, char* region, size_t region_bytes, const PadGeom& g, int C,
+                                   hipStream_t s) {
+    hipError_t e = launch_pack_act_region(dtype, x, region, region_bytes, g.front_px(), g.N, g.H, g.W, C, g.C, s);
+    if (e != hipErrorNotSupported) return e;
+    (void)hipGetLastError();
+    e = hipMemsetAsync(region, 0, region_bytes, s);
+    if (e != hipSuccess) return e;
+    return launch_pack_act(dtype, x, region + g.base_off(dtype_size(dtype)), g.N, g.H, g.W, C, g.C, s);
+}
 size_t y2_conv2d_workspace_bytes(int N, int H, int W, int Cin, int Cout, int k, int dtype) {
     return op_plan(N, H, W, Cin, Cout, k, dtype).total;
 }
@@ -1191,11 +1203,9 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
     const size_t sz = dtype_size(dtype);
     OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
     char* ws = (char*)workspace;
-    // only the bordered activations rely on zeros (borders, channel padding); the filter packs write their padding
-    HIPCHK(hipMemsetAsync(ws + p.xp, 0, p.wf - p.xp, s));
     PadGeom g{N, H, W, p.Cin_p};
     char* xp = ws + p.xp + g.base_off(sz);
-    HIPCHK(launch_pack_act(dtype, x, xp, N, H, W, Cin, p.Cin_p, s));
+    HIPCHK(op_pack_bordered(dtype, x, ws + p.xp, p.wf - p.xp, g, Cin, s));
     HIPCHK(launch_pack_weights(dtype, w, ws + p.wf, nullptr, k * k, Cin, Cout, p.Cout_pad, p.Cin_p, 0, 0,
                                conv_filter_layout(k * k, W, p.Cin_p * (int)sz, Cout, N * H * W), s));
     ConvArgs a{};
@@ -1214,13 +1224,11 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
     const size_t sz = dtype_size(dtype);
     OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
     char* ws = (char*)workspace;
-    HIPCHK(hipMemsetAsync(ws + p.xp, 0, p.wf - p.xp, s));
-    HIPCHK(hipMemsetAsync(ws + p.dyp, 0, p.dx - p.dyp, s));
     PadGeom gx{N, H, W, p.Cin_p}, gy{N, H, W, p.Cdy};
     char* xp = ws + p.xp + gx.base_off(sz);
     char* dyp = ws + p.dyp + gy.base_off(sz);
-    HIPCHK(launch_pack_act(dtype, x, xp, N, H, W, Cin, p.Cin_p, s));
-    HIPCHK(launch_pack_act(dtype, dy, dyp, N, H, W, Cout, p.Cdy, s));
+    HIPCHK(op_pack_bordered(dtype, x, ws + p.xp, p.wf - p.xp, gx, Cin, s));
+    HIPCHK(op_pack_bordered(dtype, dy, ws + p.dyp, p.dx - p.dyp, gy, Cout, s));
     if (dx) {
         HIPCHK(launch_pack_weights(dtype, w, nullptr, ws + p.wd, k * k, Cin, Cout, 0, 0, p.Cin_pad, p.Cdy,
                                    conv_filter_layout(k * k, W, p.Cdy * (int)sz, p.Cin_p, N * H * W, 1), s));

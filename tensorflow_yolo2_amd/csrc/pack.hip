@@ -190,6 +190,57 @@ hipError_t launch_pack_act(int dtype, const float* in, void* xp, int N, int H, i
     }
     return hipErrorInvalidValue;
 }
+// The WHOLE bordered tensor of the op-level entries in one pass: front guard, zero borders, body, back guard and the
+// padding channels, one 16-byte chunk per thread -- no memset in front of it.  region = first byte of the allocation
+// (front_px cells before cell 0 of the bordered space), region_bytes a multiple of 16.
+template <typename T>
+__global__ void act_pack_region_kernel(const float* __restrict__ in, char* __restrict__ region, size_t chunks,
+                                       size_t front_px, int N, int H, int W, int C, int Cs) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int cpc = Cs / EPC;                       // chunks per cell
+    const size_t pitch = (size_t)W + 1, rows_img = (size_t)H + 1;
+    const size_t body = (size_t)N * rows_img * pitch;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t cell = i / cpc;
+        const int c = (int)(i % cpc) * EPC;
+        T t[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) t[e] = Elem<T>::from_f32(0.f);
+        if (cell >= front_px && cell - front_px < body && c < C) {
+            const size_t q = cell - front_px;
+            const size_t row = q / pitch;
+            const int wc = (int)(q - row * pitch);
+            const int hr = (int)(row % rows_img);
+            if (hr >= 1 && wc >= 1) {
+                const size_t n = row / rows_img;
+                const float* src = in + ((n * H + (hr - 1)) * W + (wc - 1)) * C + c;
+#pragma unroll
+                for (int e = 0; e < EPC; e += 4) {
+                    const float4 v = *(const float4*)(src + e);
+                    t[e] = Elem<T>::from_f32(v.x); t[e + 1] = Elem<T>::from_f32(v.y);
+                    t[e + 2] = Elem<T>::from_f32(v.z); t[e + 3] = Elem<T>::from_f32(v.w);
+                }
+            }
+        }
+        *(u32x4*)(region + i * 16) = *(const u32x4*)t;
+    }
+}
+hipError_t launch_pack_act_region(int dtype, const float* in, void* region, size_t region_bytes, size_t front_px, int N,
+                                  int H, int W, int C, int Cs, hipStream_t s) {
+    const int epc = dtype == 0 ? 4 : 8;
+    if (C % epc || Cs % epc || region_bytes % 16 || (((uintptr_t)in | (uintptr_t)region) & 15)) return hipErrorNotSupported;
+    const size_t chunks = region_bytes / 16;
+    size_t nb = (chunks + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    dim3 g((unsigned)nb), b(256);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(act_pack_region_kernel<float>, g, b, 0, s, in, (char*)region, chunks, front_px, N, H, W, C, Cs); break;
+        case 1: hipLaunchKernelGGL(act_pack_region_kernel<half_t>, g, b, 0, s, in, (char*)region, chunks, front_px, N, H, W, C, Cs); break;
+        case 2: hipLaunchKernelGGL(act_pack_region_kernel<bf16_t>, g, b, 0, s, in, (char*)region, chunks, front_px, N, H, W, C, Cs); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H, int W, int C, int Cs,
                              hipStream_t s) {
     switch (dtype) {

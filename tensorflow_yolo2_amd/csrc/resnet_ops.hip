@@ -243,26 +243,50 @@ __global__ void rn_bn_apply_kernel(const float* __restrict__ x, const float* __r
         y[i] = relu ? fmaxf(v, 0.f) : v;
     }
 }
-// four channels per thread (C % 4 == 0, 16-byte aligned tensors)
+// four channels per thread (C % 4 == 0, 16-byte aligned tensors).  The launcher makes the grid stride a multiple of
+// C / 4 where it can (FIXED): a thread then stays on its four channels and derives their coefficients once
+// (1 / sqrt and the products per element were as expensive as the memory traffic)
+template <bool FIXED>
 __global__ void rn_bn_apply4_kernel(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y,
                                     size_t total4, int C, const float* mean, const float* var, const float* gamma,
                                     const float* beta, float eps, int relu) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+    float m[4], a[4], b[4];
+    auto coef = [&](int c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m[e] = mean[c + e];
+            a[e] = 1.0f / sqrtf(var[c + e] + eps);
+            b[e] = beta[c + e];
+        }
+    };
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (FIXED && i0 < total4) coef((int)((i0 * 4) % C));
+    float g[4];
+    if (FIXED && i0 < total4) {
+        const int c = (int)((i0 * 4) % C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = gamma[c + e];
+    }
+    for (size_t i = i0; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        if (!FIXED) {
+            const int c = (int)((i * 4) % C);
+            coef(c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = gamma[c + e];
+        }
         const float4 xv = ((const float4*)x)[i];
-        const float4 m = *(const float4*)(mean + c), v = *(const float4*)(var + c);
-        const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
-        float4 o;
-        o.x = (xv.x - m.x) * (1.0f / sqrtf(v.x + eps)) * g.x + b.x;
-        o.y = (xv.y - m.y) * (1.0f / sqrtf(v.y + eps)) * g.y + b.y;
-        o.z = (xv.z - m.z) * (1.0f / sqrtf(v.z + eps)) * g.z + b.z;
-        o.w = (xv.w - m.w) * (1.0f / sqrtf(v.w + eps)) * g.w + b.w;
+        float o[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (o[e] - m[e]) * a[e] * g[e] + b[e];
         if (res) {
             const float4 r = ((const float4*)res)[i];
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+            o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
         }
-        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        ((float4*)y)[i] = o;
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        ((float4*)y)[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 __global__ void rn_bn_moving_kernel(float* mm, float* mv, const float* mean, const float* var, int C, float decay,
@@ -291,14 +315,28 @@ __global__ void rn_bn_bwd_apply_kernel(const float* __restrict__ dy, const float
     }
 }
 
+template <bool FIXED>
 __global__ void rn_bn_bwd_apply4_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                         const float* __restrict__ x, float* __restrict__ dx, float* __restrict__ dres,
                                         size_t total4, size_t M, int C, const float* mean, const float* var,
                                         const float* gamma, float eps, int relu, int training, const float* dgamma,
                                         const float* dbeta) {
     const float invM = 1.0f / (float)M;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+    float m[4], inv[4], gi[4], kb[4], kg[4];
+    auto coef = [&](int c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            m[e] = mean[c + e];
+            inv[e] = 1.0f / sqrtf(var[c + e] + eps);
+            gi[e] = gamma[c + e] * inv[e];
+            kb[e] = dbeta[c + e] * invM;
+            kg[e] = dgamma[c + e] * invM;
+        }
+    };
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (FIXED && i0 < total4) coef((int)((i0 * 4) % C));
+    for (size_t i = i0; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        if (!FIXED) coef((int)((i * 4) % C));
         const float4 d4 = ((const float4*)dy)[i], x4 = ((const float4*)x)[i];
         float dzv[4] = {d4.x, d4.y, d4.z, d4.w};
         const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
@@ -313,10 +351,8 @@ __global__ void rn_bn_bwd_apply4_kernel(const float* __restrict__ dy, const floa
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float inv = 1.0f / sqrtf(var[c + e] + eps);
-            const float xh = (xv[e] - mean[c + e]) * inv;
-            o[e] = training ? gamma[c + e] * inv * (dzv[e] - dbeta[c + e] * invM - xh * dgamma[c + e] * invM)
-                            : gamma[c + e] * inv * dzv[e];
+            const float xh = (xv[e] - m[e]) * inv[e];
+            o[e] = training ? gi[e] * (dzv[e] - kb[e] - xh * kg[e]) : gi[e] * dzv[e];
         }
         ((float4*)dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -505,12 +541,30 @@ static bool rn_vec4(int channels, P... ptrs) {
     for (const void* q : {(const void*)ptrs...}) al |= (uintptr_t)q;
     return channels % 4 == 0 && al % 16 == 0;
 }
+// grid of the four-channel kernels: at least four elements per thread where the tensor allows, and a stride
+// (grid * 256) that is a multiple of C / 4 so that a thread keeps its channels (*fixed)
+static unsigned rn_grid4(size_t total4, int channels, bool* fixed) {
+    size_t nb = (total4 + 1023) / 1024;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    const size_t q = (size_t)channels / 4;
+    *fixed = false;
+    for (size_t t = nb; t >= 1 && t + 8 > nb; --t)       // a nearby grid whose stride divides
+        if ((t * 256) % q == 0) { nb = t; *fixed = true; break; }
+    return (unsigned)nb;
+}
 static void rn_bn_apply(const float* x, const float* res, float* y, size_t total, int channels, const float* mean,
                         const float* var, const float* gamma, const float* beta, float eps, int relu, hipStream_t s) {
-    if (rn_vec4(channels, x, res, y, mean, var, gamma, beta))
-        hipLaunchKernelGGL(rn_bn_apply4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, s, x, res, y, total / 4, channels,
-                           mean, var, gamma, beta, eps, relu);
-    else
+    if (rn_vec4(channels, x, res, y)) {
+        bool fixed;
+        const unsigned nb = rn_grid4(total / 4, channels, &fixed);
+        if (fixed)
+            hipLaunchKernelGGL(rn_bn_apply4_kernel<true>, dim3(nb), dim3(256), 0, s, x, res, y, total / 4, channels, mean, var,
+                               gamma, beta, eps, relu);
+        else
+            hipLaunchKernelGGL(rn_bn_apply4_kernel<false>, dim3(nb), dim3(256), 0, s, x, res, y, total / 4, channels, mean, var,
+                               gamma, beta, eps, relu);
+    } else
         hipLaunchKernelGGL(rn_bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, res, y, total, channels, mean, var,
                            gamma, beta, eps, relu);
 }
@@ -551,10 +605,16 @@ int y2_batch_norm_backward(const float* dy, const float* y, const float* x, floa
     hipStream_t s = (hipStream_t)stream;
     const size_t total = rows * channels;
     RCHK((rn_bn_reduce<true>(x, dy, y, rows, channels, save_mean, save_var, eps, relu, dgamma, dbeta, s)));
-    if (rn_vec4(channels, dy, y, x, dx, dresidual, save_mean, save_var, gamma, dgamma, dbeta))
-        hipLaunchKernelGGL(rn_bn_bwd_apply4_kernel, dim3(grid_for(total / 4)), dim3(256), 0, s, dy, y, x, dx, dresidual,
-                           total / 4, rows, channels, save_mean, save_var, gamma, eps, relu, is_training, dgamma, dbeta);
-    else
+    if (rn_vec4(channels, dy, y, x, dx, dresidual)) {
+        bool fixed;
+        const unsigned nb = rn_grid4(total / 4, channels, &fixed);
+        if (fixed)
+            hipLaunchKernelGGL(rn_bn_bwd_apply4_kernel<true>, dim3(nb), dim3(256), 0, s, dy, y, x, dx, dresidual, total / 4,
+                               rows, channels, save_mean, save_var, gamma, eps, relu, is_training, dgamma, dbeta);
+        else
+            hipLaunchKernelGGL(rn_bn_bwd_apply4_kernel<false>, dim3(nb), dim3(256), 0, s, dy, y, x, dx, dresidual, total / 4,
+                               rows, channels, save_mean, save_var, gamma, eps, relu, is_training, dgamma, dbeta);
+    } else
         hipLaunchKernelGGL(rn_bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, y, x, dx, dresidual, total,
                            rows, channels, save_mean, save_var, gamma, eps, relu, is_training, dgamma, dbeta);
     RCHK(hipGetLastError());
