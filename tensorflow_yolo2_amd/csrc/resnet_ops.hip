@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void rn_bn_partial_kernel(const float* __restr
 // eight sums -- the same order every run (a single thread walking 1024 slices was latency-bound: 50 us)
 template <bool BWD>
 __global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const double* __restrict__ part, int slices, int C, size_t M,
-                                                             const float* __restrict__ x, float* o1, float* o2) {
+                                                             const float* __restrict__ x, float* o1, float* o2,
+                                                             float* mm, float* mv, float decay) {
     __shared__ double r1[8][33], r2[8][33];
     const int cl = threadIdx.x & 31, k0 = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -210,11 +211,16 @@ __global__ __launch_bounds__(256) void rn_bn_finalize_kernel(const double* __res
         o1[c] = (float)((double)x[c] + md);
         const double v = q / (double)M - md * md;
         o2[c] = (float)(v > 0 ? v : 0);
+        if (mm) {      // moving <- decay moving + (1 - decay) batch, with the values as stored (biased variance, see below)
+            mm[c] = decay * mm[c] + (1.0f - decay) * o1[c];
+            mv[c] = decay * mv[c] + (1.0f - decay) * o2[c];
+        }
     }
 }
 template <bool BWD>
 static hipError_t rn_bn_reduce(const float* x, const float* dy, const float* y, size_t M, int C, const float* mean,
-                               const float* var, float eps, int relu, float* o1, float* o2, hipStream_t s) {
+                               const float* var, float eps, int relu, float* o1, float* o2, hipStream_t s,
+                               float* mm = nullptr, float* mv = nullptr, float decay = 0.f) {
     const uintptr_t al = (uintptr_t)x | (uintptr_t)dy | (uintptr_t)y;
     const int vec = (C % 4 == 0 && al % 16 == 0) ? 4 : 1;
     const RnSlices sl = rn_slices(M, C, vec);
@@ -227,7 +233,8 @@ static hipError_t rn_bn_reduce(const float* x, const float* dy, const float* y, 
     else
         hipLaunchKernelGGL((rn_bn_partial_kernel<1, BWD>), grid, dim3(256), 0, s, x, dy, y, M, C, mean, var, eps, relu,
                            sl.rows_per_slice, part);
-    hipLaunchKernelGGL((rn_bn_finalize_kernel<BWD>), dim3(sl.groups), dim3(256), 0, s, part, sl.slices, C, M, x, o1, o2);
+    hipLaunchKernelGGL((rn_bn_finalize_kernel<BWD>), dim3(sl.groups), dim3(256), 0, s, part, sl.slices, C, M, x, o1, o2, mm,
+                       mv, decay);
     return hipGetLastError();
 }
 
@@ -288,13 +295,6 @@ __global__ void rn_bn_apply4_kernel(const float* __restrict__ x, const float* __
         }
         ((float4*)y)[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
-}
-__global__ void rn_bn_moving_kernel(float* mm, float* mv, const float* mean, const float* var, int C, float decay,
-                                    float unbias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    mm[c] = decay * mm[c] + (1.0f - decay) * mean[c];
-    mv[c] = decay * mv[c] + (1.0f - decay) * var[c] * unbias;
 }
 
 // dx = gamma invstd (dz - dbeta/M - xhat dgamma/M)   (training)   |   gamma invstd dz   (moving statistics)
@@ -579,14 +579,10 @@ int y2_batch_norm_forward(const float* x, const float* residual, float* y, size_
     hipStream_t s = (hipStream_t)stream;
     const size_t total = rows * channels;
     if (is_training) {
-        RCHK((rn_bn_reduce<false>(x, nullptr, nullptr, rows, channels, nullptr, nullptr, eps, 0, save_mean, save_var, s)));
-        if (update_moving) {
-            // slim.batch_norm feeds the moving variance the UNBIASED batch variance (fused_batch_norm semantics are
-            // version dependent; tf.nn.moments + assign_moving_average of the non-fused path use the biased one,
-            // which is what slim of the reference's era runs): biased
-            hipLaunchKernelGGL(rn_bn_moving_kernel, dim3((channels + 255) / 256), dim3(256), 0, s, moving_mean, moving_var,
-                               save_mean, save_var, channels, decay, 1.0f);
-        }
+        // slim.batch_norm feeds the moving variance the batch variance of the non-fused path (tf.nn.moments +
+        // assign_moving_average: biased), which is what slim of the reference's era runs; folded into the finalize
+        RCHK((rn_bn_reduce<false>(x, nullptr, nullptr, rows, channels, nullptr, nullptr, eps, 0, save_mean, save_var, s,
+                                  update_moving ? moving_mean : nullptr, update_moving ? moving_var : nullptr, decay)));
         rn_bn_apply(x, residual, y, total, channels, save_mean, save_var, gamma, beta, eps, relu, s);
     } else {
         RCHK(hipMemcpyAsync(save_mean, moving_mean, channels * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -732,16 +732,19 @@ def batch_norm_forward(x, gamma, beta, moving_mean, moving_var, residual=None, i
     return y, sm, sv
 
 
-def batch_norm_backward(dy, y, x, gamma, save_mean, save_var, is_training=True, relu=True, want_residual=False, eps=1e-5):
-    """-> (dx, dresidual or None, dgamma, dbeta)"""
+def batch_norm_backward(dy, y, x, gamma, save_mean, save_var, is_training=True, relu=True, want_residual=False, eps=1e-5,
+                        dgamma_out=None, dbeta_out=None):
+    """-> (dx, dresidual or None, dgamma, dbeta); dgamma_out / dbeta_out: write the parameter gradients there (views
+    of a flat gradient buffer)"""
     lib = _lib.load()
-    _chk(dy, y, x, gamma, save_mean, save_var)
+    _chk(dy, y, x, gamma, save_mean, save_var, dgamma_out, dbeta_out)
     c = x.shape[-1]
     rows = x.numel() // c
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_residual else None
-    dg = torch.empty(c, dtype=torch.float32, device=x.device)
-    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    dg = dgamma_out if dgamma_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
+    db = dbeta_out if dbeta_out is not None else torch.empty(c, dtype=torch.float32, device=x.device)
+    assert dg.numel() == c and db.numel() == c
     check(lib.y2_batch_norm_backward(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), _ptr(dres), rows, c, _ptr(gamma),
                                      _ptr(save_mean), _ptr(save_var), float(eps), int(is_training), int(relu), _ptr(dg),
                                      _ptr(db), _stream()))
@@ -845,12 +848,13 @@ def bias_relu_(y, bias, relu=True):
     return y
 
 
-def bias_relu_backward(dy, y, relu=True):
+def bias_relu_backward(dy, y, relu=True, dbias_out=None):
     lib = _lib.load()
-    _chk(dy, y)
+    _chk(dy, y, dbias_out)
     c = y.shape[-1]
     dz = torch.empty_like(dy)
-    db = torch.empty(c, dtype=torch.float32, device=dy.device)
+    db = dbias_out if dbias_out is not None else torch.empty(c, dtype=torch.float32, device=dy.device)
+    assert db.numel() == c
     check(lib.y2_bias_relu_backward(_ptr(dy), _ptr(y), _ptr(dz), _ptr(db), y.numel() // c, c, int(relu), _stream()))
     return dz, db
 

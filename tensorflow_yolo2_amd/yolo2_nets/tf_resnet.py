@@ -164,10 +164,9 @@ class ResNet50Yolo:
 
     def _bn_backward(self, rec, dy):
         _k, s, x, y, sm, sv, relu, has_res = rec
-        dx, dres, dg, db = E.batch_norm_backward(dy.contiguous(), y, x, self.p[s + "gamma"], sm, sv, self._training, relu,
-                                                 has_res, BN_EPS)
-        self.g[s + "gamma"].copy_(dg)
-        self.g[s + "beta"].copy_(db)
+        dx, dres, _dg, _db = E.batch_norm_backward(dy.contiguous(), y, x, self.p[s + "gamma"], sm, sv, self._training, relu,
+                                                   has_res, BN_EPS, dgamma_out=self.g[s + "gamma"],
+                                                   dbeta_out=self.g[s + "beta"])
         return dx, dres
 
     # ---- graph ---------------------------------------------------------------
@@ -215,13 +214,11 @@ class ResNet50Yolo:
         assert self.tape is not None
         n = self.batch
         _k, feat, flat, fc1, h, fc2, use_drop, seed = self.tape[-1]
-        dz2, db2 = E.bias_relu_backward(dgrid.reshape(n, -1).contiguous(), fc2, True)
-        self.g["yolo_fc2/biases"].copy_(db2)
+        dz2, _ = E.bias_relu_backward(dgrid.reshape(n, -1).contiguous(), fc2, True, dbias_out=self.g["yolo_fc2/biases"])
         dh, _ = E.fully_connected_backward(h, self.p["yolo_fc2/weights"], dz2, self.dtype,
                                            dw_out=self.g["yolo_fc2/weights"])
         dfc1 = E.dropout(dh, self.keep_prob, seed) if use_drop else dh                      # same mask, same 1/keep scale
-        dz1, db1 = E.bias_relu_backward(dfc1, fc1, True)
-        self.g["yolo_fc1/biases"].copy_(db1)
+        dz1, _ = E.bias_relu_backward(dfc1, fc1, True, dbias_out=self.g["yolo_fc1/biases"])
         dflat, _ = E.fully_connected_backward(flat, self.p["yolo_fc1/weights"], dz1, self.dtype,
                                               dw_out=self.g["yolo_fc1/weights"])
         dx = dflat.reshape(feat.shape).contiguous()
