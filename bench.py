@@ -291,10 +291,10 @@ def bench_resnet(args, device, rank, world, dist):
     from tensorflow_yolo2_amd.yolo2_nets.tf_resnet import ResNet50Yolo
     bs, size = args.batch, 224
     dtype = args.dtype
-    m = ResNet50Yolo(bs, size, dtype=dtype, device=device, seed=0)
+    m = ResNet50Yolo(bs, size, dtype=dtype, device=device, seed=0, graph=args.graph)
     x = torch.as_tensor(synthetic.images(bs, size, 1234 + rank)).to(device)
     lab = torch.as_tensor(synthetic.det_labels(bs, size, size // 32, 4321 + rank)).to(device)
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 4) if args.graph else args.warmup):     # graph: two eager steps, capture, one replay
         m.step(x, lab)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -310,6 +310,7 @@ def bench_resnet(args, device, rank, world, dist):
            "config": {"workload": "ResNet-50 backbone swap train step: resnet_v1_50 (16 bottleneck units) + FC 4096 + dropout "
                                   "+ FC 1470 + get_loss + backward + Adam(0.0005)", "image_size": size, "batch_per_gpu": bs,
                       "global_batch": bs, "S": 7, "B": 2, "parallelism": "dp1",
+                      "launch": "one HIP graph replay per step" if args.graph else "per-operator launches from Python",
                       "note": "operator-level composition (fp32 tensors between operators, per-operator launches); "
                               "replicas only for N > 1"},
            "whole_step_tflops": flops / (ms * 1e-3) / 1e12,
@@ -341,6 +342,7 @@ def main():
     ap.add_argument("--model", default="detector", choices=["detector", "yolov2", "resnet50"],
                     help="detector: the reference's Darknet-19 grid detector (the headline); yolov2: the north star's "
                          "anchor model (passthrough + anchor loss), not in the reference")
+    ap.add_argument("--graph", action="store_true", help="resnet50: replay the step from one HIP graph")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU functional test)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="functional test of the N>1 path on one GPU")
     args = ap.parse_args()

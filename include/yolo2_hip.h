@@ -221,6 +221,9 @@ int y2_bias_relu(float* y, const float* bias, size_t rows, int channels, int rel
 int y2_bias_relu_backward(const float* dy, const float* y, float* dz, float* dbias, size_t rows, int channels, int relu,
                           void* stream);
 int y2_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t seed, void* stream);
+/* the same with the seed read from device memory at run time: a train step captured in a HIP graph replays with a new
+ * mask every time (the host increments *seed between replays, or a captured kernel does) */
+int y2_dropout_dev(const float* x, float* y, size_t n, float keep_prob, const uint64_t* seed, void* stream);
 
 /* ---- optimizers on flat buffers (pascal_train_darknet.py:51, imagenet_train_darknet.py:58) */
 int y2_adam_step(float* params, float* m, float* v, const float* grads, size_t n, int step, float lr,

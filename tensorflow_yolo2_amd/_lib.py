@@ -86,6 +86,7 @@ SIGNATURES = {
     "y2_bias_relu": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
     "y2_bias_relu_backward": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "y2_dropout": (_i, [_vp, _vp, _sz, _f, _u64, _vp]),
+    "y2_dropout_dev": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
     "y2_adam_step": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _f, _f, _f, _f, _f, _vp]),
     "y2_momentum_step": (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
     "y2_grad_check": (_i, [_vp, _vp, _vp]),

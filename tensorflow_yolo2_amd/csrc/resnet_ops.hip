@@ -527,7 +527,8 @@ Y2_DEV uint64_t rn_mix64(uint64_t x) {
 // tf.nn.dropout(x, keep_prob): kept elements are scaled by 1 / keep_prob; the mask is a pure function of
 // (seed, element index), so the backward pass regenerates it
 __global__ void rn_dropout_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, float keep,
-                                  uint64_t seed) {
+                                  uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+    if (seed_dev) seed = *seed_dev;     // the seed lives in device memory when the step is replayed from a HIP graph
     const float inv = 1.0f / keep;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const float u = (float)(rn_mix64(seed * 0xD1B54A32D192ED03ull + i) >> 40) * (1.0f / 16777216.0f);
@@ -688,7 +689,15 @@ int y2_bias_relu_backward(const float* dy, const float* y, float* dz, float* dbi
 }
 int y2_dropout(const float* x, float* y, size_t n, float keep_prob, uint64_t seed, void* stream) {
     if (!x || !y || !(keep_prob > 0.f) || keep_prob > 1.f) return rfail(Y2_ERR_ARG, "bad arguments");
-    hipLaunchKernelGGL(rn_dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, keep_prob, seed);
+    hipLaunchKernelGGL(rn_dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, keep_prob, seed,
+                       (const uint64_t*)nullptr);
+    RCHK(hipGetLastError());
+    return Y2_OK;
+}
+int y2_dropout_dev(const float* x, float* y, size_t n, float keep_prob, const uint64_t* seed, void* stream) {
+    if (!x || !y || !seed || !(keep_prob > 0.f) || keep_prob > 1.f) return rfail(Y2_ERR_ARG, "bad arguments");
+    hipLaunchKernelGGL(rn_dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, keep_prob,
+                       (uint64_t)0, seed);
     RCHK(hipGetLastError());
     return Y2_OK;
 }

@@ -864,5 +864,9 @@ def dropout(x, keep_prob, seed):
     lib = _lib.load()
     _chk(x)
     y = torch.empty_like(x)
+    if isinstance(seed, torch.Tensor):          # int64 [1] on the device: read by the kernel (HIP-graph replay)
+        assert seed.is_cuda and seed.dtype == torch.int64 and seed.numel() == 1
+        check(lib.y2_dropout_dev(_ptr(x), _ptr(y), x.numel(), float(keep_prob), _ptr(seed), _stream()))
+        return y
     check(lib.y2_dropout(_ptr(x), _ptr(y), x.numel(), float(keep_prob), int(seed), _stream()))
     return y

@@ -52,7 +52,8 @@ class ResNet50Yolo:
     """resnet_v1_50 + the YOLO fully connected head, forward / backward / Adam(0.0005)"""
 
     def __init__(self, batch, image_size=224, B=2, num_class=20, dtype="f32", blocks=None, root_depth=64,
-                 fc_hidden=4096, seed=0, device="cuda:0", learning_rate=0.0005, keep_prob=0.5, loss_scale=None):
+                 fc_hidden=4096, seed=0, device="cuda:0", learning_rate=0.0005, keep_prob=0.5, loss_scale=None,
+                 graph=False, graph_check_every=16):
         """dtype: arithmetic of the convolution / FC contractions.  "f32" (default: the reference's precision).  With
         "f16" the gradient of the loss is multiplied by a dynamic loss scale before the backward pass (activation
         gradients 50 layers deep at batch 4 fall below f16's normal range otherwise), the scale is divided out inside
@@ -91,6 +92,15 @@ class ResNet50Yolo:
         self.guard = dtype != "f32"
         self.ctrl = torch.zeros(8, dtype=torch.int32, device=self.device)     # found_inf, step, skipped, -, lr_t
         self.overflows, self._clean, self.growth_interval = 0, 0, 1000
+        # graph=True: step() replays ONE HIP graph of forward + loss + backward + guarded Adam (the ~1500 launches of
+        # the operator-level step are issued from Python in ~17 ms at batch 4; the replay is bound by the GPU).  The
+        # step counter (ctrl), the dropout seed and the overflow flag live in device memory; the host reads ctrl every
+        # `graph_check_every` steps to follow the step count and adapt the loss scale (a changed scale re-captures).
+        self.graph = bool(graph)
+        self._graph, self._gstream, self._gin, self._gout = None, None, None, None
+        self._eager_on_gstream, self._since_check, self._skipped_seen = 0, 0, 0
+        self.graph_check_every = int(graph_check_every)
+        self._seed_dev = torch.tensor([self.drop_seed], dtype=torch.int64, device=self.device) if self.graph else None
 
     # ---- variables ---------------------------------------------------------
     def init_params(self, seed=0):
@@ -202,10 +212,15 @@ class ResNet50Yolo:
         flat = feat.reshape(n, -1).contiguous()                                               # slim.flatten (NHWC order)
         fc1 = E.fully_connected(flat, self.p["yolo_fc1/weights"], self.p["yolo_fc1/biases"], True, self.dtype)
         use_drop = bool(dropout and is_training)
-        self.drop_seed += 1
-        h = E.dropout(fc1, self.keep_prob, self.drop_seed) if use_drop else fc1
+        if self._seed_dev is not None:
+            self._seed_dev.add_(1)                  # captured with the step: every replay draws a new mask
+            seed_now = self._seed_dev
+        else:
+            self.drop_seed += 1
+            seed_now = self.drop_seed
+        h = E.dropout(fc1, self.keep_prob, seed_now) if use_drop else fc1
         fc2 = E.fully_connected(h, self.p["yolo_fc2/weights"], self.p["yolo_fc2/biases"], True, self.dtype)
-        tape.append(("head", feat, flat, fc1, h, fc2, use_drop, self.drop_seed))
+        tape.append(("head", feat, flat, fc1, h, fc2, use_drop, seed_now))
         self.tape = tape
         return fc2.view(n, self.S, self.S, self.out_c)
 
@@ -268,8 +283,78 @@ class ResNet50Yolo:
         tot += 2.0 * n * flat * fc_hidden + 2.0 * n * fc_hidden * self.p["yolo_fc2/biases"].numel()
         return 3.0 * tot
 
+    def _step_device(self, images, labels):
+        """the device work of one iteration with every piece of state in device memory (what the graph captures):
+        forward, loss, scaled backward, full overflow scan, guarded Adam"""
+        grid = self.forward(images, True, update_moving=True)
+        loss, ious, mask, dnet = E.yolo_loss(grid, labels, self.num_class, self.batch, self.size, self.S, self.B)
+        lib = E._lib.load()
+        if self.loss_scale != 1.0:
+            E.check(lib.y2_scale(E._ptr(dnet), dnet.numel(), self.loss_scale, E._stream()))
+        self.backward(dnet)
+        n = self.params.numel()
+        E.check(lib.y2_grad_check_full(E._ptr(self.grads), n, E._ptr(self.ctrl), E._stream()))
+        E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
+                                         E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+        self.tape = None
+        return loss, ious, mask
+
+    def _follow_ctrl(self):
+        """host read of the device control block: step count, skipped steps -> loss scale (graph mode)"""
+        c = self.ctrl.cpu()
+        self.t = int(c[1])
+        skipped = int(c[2])
+        changed = False
+        if skipped > self._skipped_seen:
+            self.overflows += skipped - self._skipped_seen
+            self._skipped_seen = skipped
+            self._clean = 0
+            if self.loss_scale > 1.0:
+                self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+                changed = True
+        else:
+            self._clean += self._since_check
+            if self.guard and self._clean >= self.growth_interval and self.loss_scale < 65536.0:
+                self._clean = 0
+                self.loss_scale *= 2.0
+                changed = True
+        self._since_check = 0
+        if changed:
+            self._graph = None          # the scale is an argument of two captured launches: capture again
+
+    def _step_graph(self, images, labels):
+        cur = torch.cuda.current_stream()
+        if self._gstream is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+            self._gin = (torch.empty_like(images), torch.empty_like(labels))
+        gs = self._gstream
+        gs.wait_stream(cur)
+        with torch.cuda.stream(gs):
+            self._gin[0].copy_(images)
+            self._gin[1].copy_(labels)
+            if self._eager_on_gstream < 2:
+                # two ordinary steps on the graph's stream first: they size the per-stream scratch buffers and set
+                # the kernels' attributes (neither is allowed inside a capture); they are real steps
+                self._eager_on_gstream += 1
+                out = self._step_device(*self._gin)
+            else:
+                if self._graph is None:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=gs):
+                        self._gout = self._step_device(*self._gin)
+                    self._graph = g
+                self._graph.replay()
+                out = self._gout
+        cur.wait_stream(gs)
+        self._since_check += 1
+        if self._since_check >= self.graph_check_every:
+            self._follow_ctrl()
+        return out
+
     def step(self, images, labels):
         """one iteration of pascal_train_resnet.py:49-62: get_loss + AdamOptimizer(0.0005).minimize"""
+        if self.graph:
+            return self._step_graph(images, labels)
         grid = self.forward(images, True, update_moving=True)
         loss, ious, mask, dnet = E.yolo_loss(grid, labels, self.num_class, self.batch, self.size, self.S, self.B)
         lib = E._lib.load()

@@ -301,3 +301,43 @@ def test_resnet50_full_width_224_runs():
     l0 = float(m.step(x, lab)[0][4])
     l1 = float(m.step(x, lab)[0][4])
     assert np.isfinite([l0, l1]).all() and tuple(m.forward(x, False).shape) == (n, 7, 7, 30)
+
+
+def test_graph_replay_follows_the_eager_steps():
+    """graph=True replays forward + loss + backward + guarded Adam from one HIP graph (step counter, dropout seed and
+    overflow flag in device memory).  Against the per-operator launches on the same changing batches: identical first
+    step, the same dropout seeds and step counts throughout, and the losses of the first replayed steps within 1e-3 --
+    this 1/8-width net normalises over 8 samples in its last block and amplifies the last-bit differences of the
+    atomically summed split-K weight gradients (two eager runs drift apart the same way, scripts/diag_graph.py), so
+    later steps are compared by their bookkeeping only."""
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.yolo2_nets import tf_resnet
+    blocks = RR.scaled_blocks(8)
+    kw = dict(dtype="f32", blocks=blocks, root_depth=8, fc_hidden=512, seed=3)
+    a = tf_resnet.ResNet50Yolo(2, 64, graph=False, **kw)
+    b = tf_resnet.ResNet50Yolo(2, 64, graph=True, graph_check_every=4, **kw)
+    a.guard = True                                             # the eager reference on the same guarded update
+    outs = []
+    for i in range(6):
+        x = torch.as_tensor(synthetic.images(2, 64, 100 + i)).cuda()
+        lab = torch.as_tensor(synthetic.det_labels(2, 64, 2, 200 + i)).cuda()
+        la = a.step(x, lab)[0].clone()
+        lb = b.step(x, lab)[0].clone()
+        outs.append((la, lb))
+        assert a.drop_seed == int(b._seed_dev)
+    torch.cuda.synchronize()
+    assert b._graph is not None and b._eager_on_gstream == 2
+    assert torch.equal(outs[0][0], outs[0][1])                 # same initial parameters, same mask
+    for la, lb in outs[:3]:                                    # two eager steps and the first replay
+        assert abs(float(la[4]) - float(lb[4])) < 1e-3 * float(la[4])
+    for la, lb in outs:
+        assert bool(torch.isfinite(lb).all())
+    b._follow_ctrl()
+    assert b.t == 6 and a.t == 6 and b.overflows == 0
+    # dropout really changes from replay to replay: two replays on the SAME batch and parameters give different losses
+    x = torch.as_tensor(synthetic.images(2, 64, 7)).cuda(); lab = torch.as_tensor(synthetic.det_labels(2, 64, 2, 8)).cuda()
+    p0 = b.params.clone(); m0, v0 = b.m.clone(), b.v.clone()
+    l1 = b.step(x, lab)[0].clone()
+    b.params.copy_(p0); b.m.copy_(m0); b.v.copy_(v0)
+    l2 = b.step(x, lab)[0].clone()
+    assert not torch.equal(l1, l2)
