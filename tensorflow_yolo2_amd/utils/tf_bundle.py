@@ -442,3 +442,192 @@ def write_bundle(prefix, tensors):
                                                              mask_crc(crc32c(raw)))))
     write_table(prefix + ".index", items)
     return sorted(tensors)
+
+
+# ---------------------------------------------------------------------------------------------- V1 checkpoints
+# The "V1" format (tensorflow/core/util/tensor_slice_writer.cc, saved_tensor_slice.proto; what tf.train.Saver wrote
+# before TF 0.12 and what the slim model zoo's resnet_v1_50.ckpt is -- the file restore_resnet_tf_variables loads,
+# src/yolo2_nets/net_utils.py:137-196): ONE file, the same SSTable container as the V2 index, whose values are
+# SavedTensorSlices messages:
+#   key ""                         -> { meta  { tensor { name, shape, type, slice* }*, versions } }
+#   key OrderedCode(0, name, slice) -> { data { name, slice { extent { start, length }* }, data = TensorProto } }
+# with the values of a slice in the TensorProto's typed repeated field (float_val = packed little-endian floats) or
+# its tensor_content bytes.  A Saver writes each variable as one full slice; partial slices are placed by their extents.
+_TP_FIELD = {DT_FLOAT: 5, DT_DOUBLE: 6, DT_INT32: 7, DT_INT64: 10}
+
+
+def _parse_shape(buf):
+    dims = []
+    for num, _wt, v in _pb_fields(buf):
+        if num == 2:
+            size = 0
+            for n2, _w2, v2 in _pb_fields(v):
+                if n2 == 1:
+                    size = _signed64(v2)
+            dims.append(size)
+    return tuple(dims)
+
+
+def _parse_slice(buf):
+    """TensorSliceProto -> [(start, length or None)]"""
+    ext = []
+    for num, _wt, v in _pb_fields(buf):
+        if num == 1:
+            start, length = 0, None
+            for n2, _w2, v2 in _pb_fields(v):
+                if n2 == 1:
+                    start = _signed64(v2)
+                elif n2 == 2:
+                    length = _signed64(v2)
+            ext.append((start, length))
+    return ext
+
+
+def _parse_tensor_proto(buf):
+    """TensorProto -> (dtype, flat numpy array)"""
+    dtype, content, chunks = 0, None, []
+    fields = _pb_fields(buf)
+    for num, _wt, v in fields:
+        if num == 1:
+            dtype = v
+    if dtype not in _DTYPES:
+        raise ValueError("unsupported tensor dtype %d in a V1 checkpoint" % dtype)
+    np_dt, want = _DTYPES[dtype], _TP_FIELD[dtype]
+    for num, wt, v in fields:
+        if num == 4:
+            content = np.frombuffer(v, dtype=np_dt)
+        elif num == want:
+            if wt == 2 and dtype in (DT_FLOAT, DT_DOUBLE):          # packed fixed-width values
+                chunks.append(np.frombuffer(v, dtype=np_dt))
+            elif wt == 2:                                            # packed varints
+                vals, pos = [], 0
+                while pos < len(v):
+                    x, pos = _get_varint(v, pos)
+                    vals.append(_signed64(x))
+                chunks.append(np.asarray(vals, dtype=np_dt))
+            elif wt == 5:
+                chunks.append(np.frombuffer(struct.pack("<I", v), dtype=np_dt))
+            elif wt == 1:
+                chunks.append(np.frombuffer(struct.pack("<Q", v), dtype=np_dt))
+            else:
+                chunks.append(np.asarray([_signed64(v)], dtype=np_dt))
+    if content is not None and content.size:
+        return dtype, content
+    return dtype, (np.concatenate(chunks) if chunks else np.zeros(0, np_dt))
+
+
+def is_v1_checkpoint(path):
+    """a single-file table whose first key is "" holding a SavedTensorSlices meta record"""
+    if not os.path.isfile(path) or os.path.isfile(path + ".index"):
+        return False
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, os.SEEK_END)
+            if f.tell() < 48:
+                return False
+            f.seek(-8, os.SEEK_END)
+            return struct.unpack("<Q", f.read(8))[0] == TABLE_MAGIC
+    except OSError:
+        return False
+
+
+def read_checkpoint_v1(path, verify=True):
+    """{tensor name: numpy array} of a V1 checkpoint file"""
+    entries = read_table(path, verify)
+    if not entries or entries[0][0] != b"":
+        raise ValueError("%s: no SavedTensorSlices header record" % path)
+    meta = {}
+    for num, _wt, v in _pb_fields(entries[0][1]):
+        if num != 1:
+            continue
+        for n2, _w2, v2 in _pb_fields(v):
+            if n2 != 1:
+                continue
+            name, shape, dtype = "", (), 0
+            for n3, _w3, v3 in _pb_fields(v2):
+                if n3 == 1:
+                    name = v3.decode()
+                elif n3 == 2:
+                    shape = _parse_shape(v3)
+                elif n3 == 3:
+                    dtype = v3
+            meta[name] = (shape, dtype)
+    out = {}
+    for key, value in entries[1:]:
+        for num, _wt, v in _pb_fields(value):
+            if num != 2:
+                continue
+            name, ext, tp = "", [], None
+            for n2, _w2, v2 in _pb_fields(v):
+                if n2 == 1:
+                    name = v2.decode()
+                elif n2 == 2:
+                    ext = _parse_slice(v2)
+                elif n2 == 3:
+                    tp = v2
+            if name not in meta or tp is None:
+                raise ValueError("%s: slice of %r without a header entry" % (path, name))
+            shape, dtype = meta[name]
+            dt, flat = _parse_tensor_proto(tp)
+            if dt != dtype:
+                raise ValueError("%s: %s is stored as dtype %d, the header says %d" % (path, name, dt, dtype))
+            full = all(length is None and start == 0 for start, length in ext) or not ext
+            if full:
+                if flat.size != int(np.prod(shape, dtype=np.int64)):
+                    raise ValueError("%s: %s holds %d values, shape %s" % (path, name, flat.size, shape))
+                out[name] = flat.reshape(shape).copy()
+            else:
+                arr = out.setdefault(name, np.zeros(shape, _DTYPES[dtype]))
+                idx = tuple(slice(s, None if ln is None else s + ln) for s, ln in ext)
+                arr[idx] = flat.reshape(arr[idx].shape)
+    missing = sorted(set(meta) - set(out))
+    if missing:
+        raise ValueError("%s: no data record for %s" % (path, ", ".join(missing[:5])))
+    return out
+
+
+def _ordered_num(v):
+    """OrderedCode::WriteNumIncreasing: length byte + big-endian bytes"""
+    body = b""
+    while v:
+        body = bytes([v & 0xFF]) + body
+        v >>= 8
+    return bytes([len(body)]) + body
+
+
+def _ordered_string(b):
+    """OrderedCode::WriteString: 0x00 -> 00 ff, 0xff -> ff 00, terminator 00 01"""
+    return b"".join(b"\x00\xff" if c == 0 else (b"\xff\x00" if c == 255 else bytes([c])) for c in b) + b"\x00\x01"
+
+
+def _v1_key(name, rank):
+    """EncodeTensorNameSlice of a full slice: 0, name, rank, then (start 0, length -1) per dimension -- small signed
+    numbers take one byte, 0x80 ^ value"""
+    return _ordered_num(0) + _ordered_string(name.encode()) + _ordered_num(rank) + bytes([0x80, 0x7f]) * rank
+
+
+def write_checkpoint_v1(path, tensors):
+    """the file tf.train.Saver(write_version=V1) writes for {name: array}: each tensor one full slice with its values
+    in the typed repeated field (used by the tests and to hand a backbone to the reference)"""
+    def shape_proto(shape):
+        return b"".join(_pb_bytes(2, _pb_varint(1, int(d))) for d in shape)
+
+    def slice_proto(rank):
+        return b"".join(_pb_bytes(1, b"") for _ in range(rank))
+    meta, items = b"", []
+    for name in sorted(tensors):
+        a = np.asarray(tensors[name])            # (ascontiguousarray would turn a scalar into shape (1,))
+        if a.dtype not in _DT_OF:
+            raise ValueError("%s: dtype %s cannot be written" % (name, a.dtype))
+        dt = _DT_OF[a.dtype]
+        meta += _pb_bytes(1, _pb_bytes(1, name.encode()) + _pb_bytes(2, shape_proto(a.shape)) + _pb_varint(3, dt) +
+                          _pb_bytes(4, slice_proto(a.ndim)))
+        if dt in (DT_FLOAT, DT_DOUBLE):
+            payload = a.astype(_DTYPES[dt]).tobytes()
+        else:
+            payload = b"".join(_put_varint(int(x)) for x in a.reshape(-1))
+        tp = _pb_varint(1, dt) + _pb_bytes(_TP_FIELD[dt], payload)
+        data = _pb_bytes(1, name.encode()) + _pb_bytes(2, slice_proto(a.ndim)) + _pb_bytes(3, tp)
+        items.append((_v1_key(name, a.ndim), _pb_bytes(2, data)))
+    header = _pb_bytes(1, meta + _pb_bytes(2, _pb_varint(1, 1)))          # versions { producer: 1 }
+    write_table(path, [(b"", header)] + sorted(items))

@@ -184,9 +184,24 @@ def _ckpt_prefix(path):
     return None
 
 
+class _DictSnap:
+    """np.load-like view of a dict of arrays (a V1 checkpoint read whole)"""
+
+    def __init__(self, d):
+        self.d = d
+        self.files = sorted(d)
+
+    def __getitem__(self, name):
+        return self.d[name]
+
+
 def _open_snapshot(path):
     prefix = _ckpt_prefix(path)
-    return _BundleSnap(prefix) if prefix else np.load(path)
+    if prefix:
+        return _BundleSnap(prefix)
+    if _bundle.is_v1_checkpoint(path):          # single-file tf.train.Saver V1 checkpoint (slim's resnet_v1_50.ckpt)
+        return _DictSnap(_bundle.read_checkpoint_v1(path))
+    return np.load(path)
 
 
 def _kind_of(network):
@@ -324,5 +339,110 @@ def restore_darknet19_variables(network, ckpt_dir, net_name='darknet19', save_ep
                 restore_variables(network, prior[-1])
         return 0
     restore_variables(network, sfiles[-1], optimizer=optimizer)
+    m = re.search(r"_(\d+)\.(npz|ckpt)$", sfiles[-1])
+    return int(m.group(1)) if m else 0
+
+
+# ---------------------------------------------------------------------------
+# ResNet-50 swap (yolo2_nets/tf_resnet.py: ResNet50Yolo): the counterpart of restore_resnet_tf_variables
+# (src/yolo2_nets/net_utils.py:137-219).  TF names: the backbone lives under the scope `resnet_v1_50/`, the head
+# (`yolo_fc1`, `yolo_fc2`) at the root; Adam slots `<var>/Adam`, `<var>/Adam_1`, `beta1_power`, `beta2_power`.
+# ---------------------------------------------------------------------------
+RESNET_SCOPE = "resnet_v1_50/"
+RESNET_HEAD_SCOPES = ("yolo_fc1", "yolo_fc2", "loss_layer")        # reference :177-186: excluded from the backbone restore
+
+
+def resnet_tf_name(name):
+    return name if name.split("/")[0] in RESNET_HEAD_SCOPES else RESNET_SCOPE + name
+
+
+def save_resnet_variables(model, path, with_optimizer=True):
+    """what tf.train.Saver() writes for the ResNet graph: every variable (moving statistics included) and the Adam
+    slots, `.npz` or a TF V2 checkpoint (`.ckpt`)"""
+    blob = {}
+    if getattr(model, "graph", False):
+        model._follow_ctrl()
+    t_off = 0
+    m_host = model.m.detach().cpu().numpy() if with_optimizer else None
+    v_host = model.v.detach().cpu().numpy() if with_optimizer else None
+    for (name, shape, trainable) in model.vars:
+        tfname = resnet_tf_name(name)
+        blob[tfname] = model.p[name].detach().cpu().numpy().copy()
+        if trainable:
+            n = int(np.prod(shape))
+            if with_optimizer:
+                blob[tfname + "/Adam"] = m_host[t_off:t_off + n].reshape(shape).copy()
+                blob[tfname + "/Adam_1"] = v_host[t_off:t_off + n].reshape(shape).copy()
+            t_off += n
+    if with_optimizer:
+        blob["beta1_power"] = np.float32(np.float64(0.9) ** (model.t + 1))       # TF1: beta^(t+1) after t applies
+        blob["beta2_power"] = np.float32(np.float64(0.999) ** (model.t + 1))
+        blob["adam_step"] = np.int64(model.t)
+    if path.endswith(".ckpt"):
+        _bundle.write_bundle(path, {k: np.asarray(v) for k, v in blob.items()})
+    else:
+        np.savez(path, **blob)
+    return sorted(blob)
+
+
+def restore_resnet_variables(model, path, exclude=(), with_optimizer=True):
+    """load the variables of `path` (.npz, TF V2 prefix, or a single-file V1 checkpoint such as slim's
+    resnet_v1_50.ckpt) that the graph has and whose scope is not in `exclude`; shapes must match.  Adam slots and the
+    step count are restored when the file holds all of them.  Returns (restored names, names left as they were)."""
+    snap = _open_snapshot(path)
+    have = set(snap.files)
+    restored, kept = [], []
+    for (name, shape, _t) in model.vars:
+        tfname = resnet_tf_name(name)
+        if name.split("/")[0] in exclude or tfname not in have:
+            kept.append(tfname)
+            continue
+        a = np.asarray(snap[tfname], np.float32)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError("snapshot %s: %s has shape %s, the graph expects %s" % (path, tfname, tuple(a.shape), tuple(shape)))
+        model.p[name].copy_(torch.as_tensor(a).to(model.p[name].device))
+        restored.append(tfname)
+    trainable = [(n, sh) for (n, sh, t) in model.vars if t]
+    if with_optimizer and all(resnet_tf_name(n) + "/Adam" in have and resnet_tf_name(n) + "/Adam_1" in have
+                              for n, _ in trainable):
+        m_host = np.empty(model.m.numel(), np.float32)
+        v_host = np.empty(model.v.numel(), np.float32)
+        off = 0
+        for n, sh in trainable:
+            k = int(np.prod(sh))
+            m_host[off:off + k] = np.asarray(snap[resnet_tf_name(n) + "/Adam"], np.float32).reshape(-1)
+            v_host[off:off + k] = np.asarray(snap[resnet_tf_name(n) + "/Adam_1"], np.float32).reshape(-1)
+            off += k
+        model.m.copy_(torch.as_tensor(m_host).to(model.m.device))
+        model.v.copy_(torch.as_tensor(v_host).to(model.v.device))
+        if "adam_step" in have:
+            t = int(snap["adam_step"])
+        elif "beta1_power" in have:
+            t = max(0, int(round(np.log(float(snap["beta1_power"])) / np.log(0.9))) - 1)
+        else:
+            t = 0
+        model.t = t
+        model.ctrl[1] = t                               # the guarded update keeps its step count on the device
+    return restored, kept
+
+
+def restore_resnet_tf_variables(model, ckpt_dir, net_name='resnet50', retrain=False, detection=True, save_epoch=True,
+                                new_optimizer=None, weights_path=None):
+    """Reference :137-219.  No snapshot in `ckpt_dir`: the head and the optimizer keep their initial values and the
+    convolutional layers are restored from the downloaded `resnet_v1_50.ckpt` under `weights_path` (cfg.WEIGHTS_PATH;
+    skipped when the file is absent) -> 0.  Otherwise the latest snapshot is restored (without its optimizer slots
+    when `new_optimizer` names a new optimizer) -> its iteration / epoch number."""
+    sfiles = get_ordered_ckpts(ckpt_dir, net_name, save_epoch) if ckpt_dir else []
+    if not sfiles or retrain:
+        if weights_path:
+            f = weights_path if os.path.isfile(weights_path) or _ckpt_prefix(weights_path) else \
+                os.path.join(weights_path, "resnet_v1_50.ckpt")
+            if os.path.isfile(f) or _ckpt_prefix(f):
+                print('Initializing new variables to train from downloaded resnet50 weights')
+                restore_resnet_variables(model, f, exclude=RESNET_HEAD_SCOPES if detection else (), with_optimizer=False)
+        return 0
+    print('Restorining model snapshots from {:s}'.format(sfiles[-1]))
+    restore_resnet_variables(model, sfiles[-1], with_optimizer=new_optimizer is None)
+    print('Restored.')
     m = re.search(r"_(\d+)\.(npz|ckpt)$", sfiles[-1])
     return int(m.group(1)) if m else 0

@@ -152,3 +152,58 @@ def test_bundle_round_trip_and_errors(tmp_path):
     open(str(tmp_path / "junk.index"), "wb").write(b"\0" * 100)
     with pytest.raises(ValueError):
         B.BundleReader(str(tmp_path / "junk"))
+
+
+def test_v1_checkpoint_round_trip_keys_and_partial_slices(tmp_path):
+    """The single-file "V1" checkpoint (tensor_slice_writer.cc / saved_tensor_slice.proto: slim's resnet_v1_50.ckpt,
+    which restore_resnet_tf_variables loads, net_utils.py:137-196): the writer's records byte for byte against the
+    published encodings (OrderedCode keys, SavedTensorSlices protos), the reader on them, on a slice stored by
+    extents, on tensor_content payloads, and its errors.  No TF-written file exists here: unpinned against TF itself."""
+    p = str(tmp_path / "model.ckpt")
+    t = {"resnet_v1_50/conv1/weights": np.arange(7 * 7 * 3 * 4, dtype=np.float32).reshape(7, 7, 3, 4) / 7,
+         "global_step": np.int64(1234), "a/b": np.arange(6, dtype=np.int32).reshape(2, 3) - 2,
+         "big": np.linspace(-1, 1, 300 * 50).astype(np.float32).reshape(300, 50), "empty": np.zeros((0,), np.float32)}
+    B.write_checkpoint_v1(p, t)
+    assert B.is_v1_checkpoint(p) and not B.is_bundle(p)
+    got = B.read_checkpoint_v1(p)
+    assert sorted(got) == sorted(t)
+    for k in t:
+        assert got[k].dtype == np.asarray(t[k]).dtype and got[k].shape == np.asarray(t[k]).shape
+        np.testing.assert_array_equal(got[k], t[k])
+    # keys: OrderedCode(0) | escaped name + 00 01 | OrderedCode(rank) | (start 0 -> 80, length -1 -> 7f) per dimension
+    assert B._v1_key("ab", 2) == bytes.fromhex("00" "6162" "0001" "0102" "807f807f")
+    assert B._v1_key("s", 0) == bytes.fromhex("00" "73" "0001" "00")
+    entries = B.read_table(p)
+    assert entries[0][0] == b"" and [k for k, _ in entries[1:]] == sorted(B._v1_key(n, np.asarray(a).ndim) for n, a in t.items())
+    # the record of "a/b": SavedTensorSlices{ data{ name, slice{extent{} extent{}}, data{dtype: DT_INT32, int_val: packed} } }
+    rec = dict(entries)[B._v1_key("a/b", 2)]
+    ints = b"".join(B._put_varint(v) for v in (-2, -1, 0, 1, 2, 3))
+    tp = bytes([0x08, 3]) + bytes([0x3a, len(ints)]) + ints
+    want = bytes([0x0a, 3]) + b"a/b" + bytes([0x12, 4, 0x0a, 0, 0x0a, 0]) + bytes([0x1a, len(tp)]) + tp
+    assert rec == bytes([0x12, len(want)]) + want
+    # a tensor saved in two row slices (extents with start / length) and one stored as tensor_content
+    def rec_slice(name, ext, arr, content=False):
+        sl = b"".join(B._pb_bytes(1, (B._pb_varint(1, s) if s else b"") + (B._pb_varint(2, ln) if ln is not None else b""))
+                      for s, ln in ext)
+        tpb = B._pb_varint(1, B.DT_FLOAT) + B._pb_bytes(4 if content else 5, arr.astype("<f4").tobytes())
+        return B._pb_bytes(2, B._pb_bytes(1, name.encode()) + B._pb_bytes(2, sl) + B._pb_bytes(3, tpb))
+    w = np.arange(12, dtype=np.float32).reshape(4, 3)
+    c = np.arange(5, dtype=np.float32)
+    shape = lambda s: b"".join(B._pb_bytes(2, B._pb_varint(1, d)) for d in s)
+    meta = b"".join(B._pb_bytes(1, B._pb_bytes(1, n.encode()) + B._pb_bytes(2, shape(s)) + B._pb_varint(3, B.DT_FLOAT))
+                    for n, s in (("w", (4, 3)), ("c", (5,))))
+    items = [(b"", B._pb_bytes(1, meta)), (b"\x00c1", rec_slice("c", [(0, None)], c, content=True)),
+             (b"\x00w1", rec_slice("w", [(0, 3), (0, None)], w[:3])), (b"\x00w2", rec_slice("w", [(3, 1), (0, None)], w[3:]))]
+    q = str(tmp_path / "sliced.ckpt")
+    B.write_table(q, items)
+    got = B.read_checkpoint_v1(q)
+    np.testing.assert_array_equal(got["w"], w)
+    np.testing.assert_array_equal(got["c"], c)
+    # errors: a header entry without data, a value count that does not match the shape
+    B.write_table(q, items[:2])
+    with pytest.raises(ValueError, match="no data record"):
+        B.read_checkpoint_v1(q)
+    B.write_table(q, [items[0], items[1], (b"\x00w1", rec_slice("w", [], w[:2]))])
+    with pytest.raises(ValueError, match="holds 6 values"):
+        B.read_checkpoint_v1(q)
+    assert not B.is_v1_checkpoint(str(tmp_path / "nothing.ckpt"))

@@ -202,3 +202,65 @@ def test_tf_checkpoint_round_trip_through_the_network(tmp_path):
         np.testing.assert_array_equal(after[l]["moving_var"], src[l]["moving_var"])
     for l in range(18, 22):
         np.testing.assert_array_equal(after[l]["W"], before[l]["W"])
+
+
+@pytest.mark.gpu
+def test_resnet_callers_train_resume_backbone_restore_and_detect(tmp_path, golden_dir):
+    """Counterparts of src/pascal/pascal_train_resnet.py / pascal_detect_resnet.py and restore_resnet_tf_variables
+    (net_utils.py:137-219) at 1/8 width: a fed training run from a V1 `resnet_v1_50.ckpt` (the convolutional layers
+    restored, the head and Adam left at their initial values), snapshots in both formats, a resumed run that continues
+    the step count with the Adam slots, and the detection script on a snapshot."""
+    import torch
+    from tensorflow_yolo2_amd.pascal import pascal_train_resnet, pascal_detect_resnet
+    from tensorflow_yolo2_amd.utils import tf_bundle as B
+    from tensorflow_yolo2_amd.yolo2_nets import net_utils, tf_resnet
+    kit = make_devkit(str(tmp_path / "VOCdevkit"), golden_dir, copies=3)
+    # a "downloaded" backbone: a V1 checkpoint with the backbone's variables under resnet_v1_50/ plus slim's logits
+    # layer, which the graph does not have
+    d = 8
+    kw = dict(blocks=[(n, [(dep // d, db // d, st) for (dep, db, st) in units]) for n, units in tf_resnet.BLOCKS_50],
+              root_depth=64 // d, fc_hidden=4096 // d)
+    donor = tf_resnet.ResNet50Yolo(2, 224, seed=11, **kw)
+    rng = np.random.default_rng(0)
+    pre = {}
+    for (name, shape, _t) in donor.vars:
+        if name.split("/")[0] not in net_utils.RESNET_HEAD_SCOPES:
+            pre["resnet_v1_50/" + name] = (rng.standard_normal(shape) * 0.05 + (1.0 if name.endswith(("gamma", "moving_variance")) else 0.0)).astype(np.float32)
+    pre["resnet_v1_50/logits/weights"] = np.zeros((1, 1, 256, 10), np.float32)
+    wdir = tmp_path / "weights"; wdir.mkdir()
+    B.write_checkpoint_v1(str(wdir / "resnet_v1_50.ckpt"), pre)
+    del donor
+    ck = str(tmp_path / "ckpts")
+    common = ["--batch", "2", "--width-div", "8", "--devkit", kit, "--ckpt-dir", ck, "--weights-path", str(wdir)]
+    r1 = pascal_train_resnet.main(common + ["--iters", "3", "--ckpt-format", "ckpt"])
+    m1 = r1["model"]
+    assert r1["first_iter"] == 1 and r1["last_iter"] == 3 and m1.t == 3 and np.isfinite(r1["losses"]).all()
+    assert os.path.isfile(os.path.join(ck, "train_iter_3.ckpt.index"))
+    snap = B.BundleReader(os.path.join(ck, "train_iter_3.ckpt"))
+    assert snap.has_tensor("resnet_v1_50/block4/unit_3/bottleneck_v1/conv3/BatchNorm/moving_variance")
+    assert snap.has_tensor("yolo_fc1/weights/Adam_1") and snap.has_tensor("beta2_power")
+    np.testing.assert_allclose(snap.get_tensor("beta1_power"), 0.9 ** 4, rtol=1e-6)
+    # the backbone came from the V1 file (three Adam steps of 5e-4 away), the head did not
+    fresh = tf_resnet.ResNet50Yolo(2, 224, **kw)
+    w = m1.p["block1/unit_1/bottleneck_v1/conv1/weights"].cpu().numpy()
+    assert np.abs(w - pre["resnet_v1_50/block1/unit_1/bottleneck_v1/conv1/weights"]).max() < 3 * 5e-4 * 1.01
+    assert np.abs(w - fresh.p["block1/unit_1/bottleneck_v1/conv1/weights"].cpu().numpy()).max() > 0.05
+    restored, kept = net_utils.restore_resnet_variables(fresh, str(wdir / "resnet_v1_50.ckpt"),
+                                                        exclude=net_utils.RESNET_HEAD_SCOPES, with_optimizer=False)
+    assert len(restored) == len(pre) - 1 and sorted(kept) == ["yolo_fc1/biases", "yolo_fc1/weights", "yolo_fc2/biases", "yolo_fc2/weights"]
+    # resume: the latest snapshot, Adam slots and step count included; the .npz format beside it
+    r2 = pascal_train_resnet.main(common + ["--iters", "2", "--ckpt-format", "npz", "--graph"])
+    m2 = r2["model"]
+    assert r2["first_iter"] == 4 and r2["last_iter"] == 5
+    m2._follow_ctrl()
+    assert m2.t == 5 and os.path.isfile(os.path.join(ck, "train_iter_5.npz"))
+    z = np.load(os.path.join(ck, "train_iter_5.npz"))
+    assert int(z["adam_step"]) == 5 and float(np.abs(z["yolo_fc2/weights/Adam"]).max()) > 0
+    again = tf_resnet.ResNet50Yolo(2, 224, **kw)
+    assert net_utils.restore_resnet_tf_variables(again, ck, 'resnet50', save_epoch=False) == 5
+    assert torch.equal(again.params, m2.params) and torch.equal(again.m, m2.m) and again.t == 5
+    # detection on the snapshot: moving statistics, no dropout, decode
+    out = pascal_detect_resnet.main([os.path.join(golden_dir, "testImg2.jpg"), "--ckpt-dir", ck, "--width-div", "8", "--no-show"])
+    assert out["restored"] == 5 and out["predicts"].shape == (1, 7, 7, 30) and np.isfinite(out["predicts"]).all()
+    ref = again.forward(torch.as_tensor(np.zeros((2, 224, 224, 3), np.float32)).cuda(), is_training=False, dropout=False)
+    assert ref.shape == (2, 7, 7, 30)
