@@ -413,8 +413,9 @@ __global__ void rn_maxpool3_kernel(const float* __restrict__ x, float* __restric
 // ---------------------------------------------------------------------------
 constexpr int kC7Threads = 448;   // seven waves
 
+constexpr int kC7Pad = 16;        // zero columns behind a staged row: a group of eight output pixels may overhang
 Y2_DEV void rn_conv7_stage(const float* __restrict__ x, float* xs, int n, int ho, int H, int W) {
-    const int rowf = (W + 6) * 3;
+    const int rowf = (W + 6 + kC7Pad) * 3;
     for (int kh = 0; kh < 7; ++kh) {
         const int h = ho * 2 + kh - 3;
         const bool hv = h >= 0 && h < H;
@@ -427,11 +428,14 @@ Y2_DEV void rn_conv7_stage(const float* __restrict__ x, float* xs, int n, int ho
     }
 }
 
+// forward: one output pixel per wave and iteration, the 147 taps of filter co in registers.  Bound by the LDS issue rate
+// (147 wave-uniform reads per 147 FMAs: 0.38 ms at batch 32); groups of 4 / 8 pixels that read each input column
+// once spill the filter registers (616 / 1292 bytes per lane) and are not faster.
 __global__ __launch_bounds__(kC7Threads) void rn_conv7_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   float* __restrict__ y, int N, int H, int W, int Co) {
     extern __shared__ float xs[];
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;     // (H + 6 - 7) / 2 + 1
-    const int rowf = (W + 6) * 3;
+    const int rowf = (W + 6 + kC7Pad) * 3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int co0 = 0; co0 < Co; co0 += 64) {
         const int co = co0 + lane;
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(kC7Threads) void rn_conv7_wgrad_kernel(const float*
                                                                     float* __restrict__ part, int N, int H, int W, int Co) {
     extern __shared__ float xs[];
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-    const int rowf = (W + 6) * 3;
+    const int rowf = (W + 6 + kC7Pad) * 3;
     const int co = threadIdx.x & 63, kh = threadIdx.x >> 6;
     float acc[21];
 #pragma unroll
@@ -487,12 +491,21 @@ __global__ __launch_bounds__(kC7Threads) void rn_conv7_wgrad_kernel(const float*
         for (int j = 0; j < 21; ++j) o[(size_t)(kh * 21 + j) * Co + co] = acc[j];
     }
 }
-__global__ void rn_sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// out[i] = sum over the partials in a fixed order: 64 outputs x 4 partial lanes per workgroup (one thread walking 512
+// partials was latency-bound: 120 us)
+__global__ __launch_bounds__(256) void rn_sum_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int nparts, int n) {
+    __shared__ float red[4][64];
+    const int il = threadIdx.x & 63, k0 = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
     float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += part[(size_t)k * n + i];
-    out[i] = s;
+    if (i < n) {
+#pragma unroll 4
+        for (int k = k0; k < nparts; k += 4) s += part[(size_t)k * n + i];
+    }
+    red[k0][il] = s;
+    __syncthreads();
+    if (k0 == 0 && i < n) out[i] = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
 }
 
 // ---------------------------------------------------------------------------
@@ -648,7 +661,7 @@ int y2_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, 
 
 int y2_conv7x7s2(const float* x, const float* w, float* y, int N, int H, int W, int Cout, void* stream) {
     if (!x || !w || !y || N < 1 || H < 1 || W < 1 || Cout < 1) return rfail(Y2_ERR_ARG, "bad arguments");
-    const size_t lds = (size_t)7 * (W + 6) * 3 * sizeof(float);
+    const size_t lds = (size_t)7 * (W + 6 + kC7Pad) * 3 * sizeof(float);
     if (lds > 64 * 1024) return rfail(Y2_ERR_ARG, "image rows of %d pixels do not fit the staged window", W);
     const int rows = N * ((H + 1) / 2);
     hipLaunchKernelGGL(rn_conv7_fwd_kernel, dim3(rows < 1024 ? rows : 1024), dim3(kC7Threads), lds, (hipStream_t)stream, x, w,
@@ -659,7 +672,7 @@ int y2_conv7x7s2(const float* x, const float* w, float* y, int N, int H, int W, 
 int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* stream) {
     if (!x || !dy || !dw || N < 1 || H < 1 || W < 1) return rfail(Y2_ERR_ARG, "bad arguments");
     if (Cout < 1 || Cout > 64) return rfail(Y2_ERR_ARG, "the root convolution has 64 filters (resnet_v1.py:197)");
-    const size_t lds = (size_t)7 * (W + 6) * 3 * sizeof(float);
+    const size_t lds = (size_t)7 * (W + 6 + kC7Pad) * 3 * sizeof(float);
     if (lds > 64 * 1024) return rfail(Y2_ERR_ARG, "image rows of %d pixels do not fit the staged window", W);
     hipStream_t s = (hipStream_t)stream;
     const int rows = N * ((H + 1) / 2);
@@ -667,7 +680,7 @@ int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int
     float* part = (float*)op_scratch(s, (size_t)blocks * 147 * Cout * sizeof(float));
     if (!part) return rfail(Y2_ERR_HIP, "no scratch memory for the filter-gradient partials");
     hipLaunchKernelGGL(rn_conv7_wgrad_kernel, dim3(blocks), dim3(kC7Threads), lds, s, x, dy, part, N, H, W, Cout);
-    hipLaunchKernelGGL(rn_sum_partials_kernel, dim3((147 * Cout + 255) / 256), dim3(256), 0, s, part, dw, blocks, 147 * Cout);
+    hipLaunchKernelGGL(rn_sum_partials_kernel, dim3((147 * Cout + 63) / 64), dim3(256), 0, s, part, dw, blocks, 147 * Cout);
     RCHK(hipGetLastError());
     return Y2_OK;
 }
