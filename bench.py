@@ -330,7 +330,7 @@ def main():
     ap.add_argument("--image-size", type=int, default=416)
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
     ap.add_argument("--kernel-events", default="timed", choices=["timed", "separate", "off"])
-    ap.add_argument("--event-stride", type=int, default=4, help="bracket the MFMA launches of every n-th timed step")
+    ap.add_argument("--event-stride", type=int, default=10, help="bracket the MFMA launches of every n-th timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)     # bs 8
     ap.add_argument("--cpu-seconds", type=float, default=25.0)
