@@ -242,9 +242,14 @@ struct BnFinalizeArgs {
     float* scratch = nullptr;   // >= 64 * (1 + 2 * ldp) floats: long partial lists are compressed to 64 records first
 };
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
-hipError_t launch_bn_infer_prepare(const float* gamma, const float* beta, const float* mm, const float* mv,
-                                   float* scale, float* shift, float* mean, float* invstd, int C, float eps,
-                                   hipStream_t s);
+// per layer: moving statistics + gamma / beta -> scale, shift, mean, invstd of the apply pass
+struct BnInferLayer {
+    const float *gamma, *beta, *mm, *mv;
+    float *scale, *shift, *mean, *invstd;
+    int C, is_core;
+};
+hipError_t launch_bn_infer_prepare_all(const BnInferLayer* tab, int nlayers, int max_c, int train_core, int train_head,
+                                       float eps, hipStream_t s);
 hipError_t launch_bn_update_moving(const float* mean, const float* var, float* mm, float* mv, int C, float momentum,
                                    hipStream_t s);
 struct BnActArgs {

@@ -108,6 +108,7 @@ struct y2_ctx {
     // pooled 3-channel first layer, training: the linear form of its backward pass (conv1_wgrad.hip) -- its conv
     // output is never stored
     bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
+    size_t o_infertab = 0;      // BnInferLayer per layer (one prepare launch for all inference-mode layers)
     size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0, o_slab = 0;
     size_t slab_floats = 0;     // split-K partial tiles of the weight gradients (WgradArgs::slab)
     int n_chkranges = 0, n_smallranges = 0, opt_tile_blocks = 0;
@@ -124,6 +125,7 @@ struct y2_ctx {
         int step = 0;
     } fopt;
     std::vector<PackLayer> packtab;
+    std::vector<BnInferLayer> infertab;
     int pack_blocks = 0;
     // optional per-launch HIP-event bracketing (bench.py roofline leg)
     int prof = 0;   // 0 off, 1 every launch, 2 only the dominant kernel (conv forward + dgrad)
@@ -212,6 +214,7 @@ static void plan(y2_ctx* c) {
     c->o_part_scratch = take((size_t)64 * (1 + 2 * max_ld) * sizeof(float));
     c->o_h32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
     c->o_packtab = take(c->L.size() * sizeof(PackLayer));
+    c->o_infertab = take(c->L.size() * sizeof(BnInferLayer));
     c->o_chkranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
     c->o_smallranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
     c->o_nfflag = take(256);
@@ -521,6 +524,21 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
     if (!c->packtab.empty())
         HIPCHK(hipMemcpyAsync(c->ws + c->o_packtab, c->packtab.data(), c->packtab.size() * sizeof(PackLayer),
                               hipMemcpyHostToDevice, (hipStream_t)stream));
+    {
+        std::vector<BnInferLayer>& tab = c->infertab;      // a member: the asynchronous copy reads it after this returns
+        tab.clear();
+        for (size_t l = 0; l < c->L.size(); ++l) {
+            const Layer& y = c->L[l];
+            float* stat = (float*)(c->ws + y.stat);
+            BnInferLayer t{};
+            t.gamma = params + y.pg; t.beta = params + y.pbeta; t.mm = state + y.smm; t.mv = state + y.smv;
+            t.scale = stat; t.shift = stat + y.ldy; t.mean = stat + 2 * y.ldy; t.invstd = stat + 3 * y.ldy;
+            t.C = y.cout; t.is_core = (int)l < c->core_layers ? 1 : 0;
+            tab.push_back(t);
+        }
+        HIPCHK(hipMemcpyAsync(c->ws + c->o_infertab, tab.data(), tab.size() * sizeof(BnInferLayer), hipMemcpyHostToDevice,
+                              (hipStream_t)stream));
+    }
     return Y2_OK;
 }
 
@@ -589,6 +607,12 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
     float* part_mean = (float*)(c->ws + c->o_part_mean);
     float* part_m2 = (float*)(c->ws + c->o_part_m2);
     const int nl = (int)c->L.size();
+    if (!train_core || (!train_head && c->core_layers < nl)) {     // some layer normalises with its moving statistics
+        int max_c = 0;
+        for (const Layer& y : c->L) max_c = y.cout > max_c ? y.cout : max_c;
+        HIPCHK(launch_bn_infer_prepare_all((const BnInferLayer*)(c->ws + c->o_infertab), nl, max_c, train_core, train_head,
+                                           kBnEps, s));
+    }
     for (int l = 0; l < nl; ++l) {
         c->prof_layer = l;
         const Layer& y = c->L[l];
@@ -646,12 +670,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             t.C = y.cout; t.ldy = y.ldy; t.out_f32 = 0;
             fin_fused = bn_fin_act_ok(t, f);
         }
-        if (training) {
-            if (!fin_fused) HIPCHK(launch_bn_finalize(f, s));
-        } else {
-            HIPCHK(launch_bn_infer_prepare(c->params + y.pg, c->params + y.pbeta, c->state + y.smm, c->state + y.smv,
-                                           scale, shift, mean, invstd, y.cout, kBnEps, s));
-        }
+        if (training && !fin_fused) HIPCHK(launch_bn_finalize(f, s));     // (inference: prepared for every layer above)
         if (pool1) {
             Conv1PoolArgs q{};
             q.x4 = xin; q.w = c->ws + y.wf; q.y = c->ws + y.y; q.bias = c->params + y.pb;
