@@ -487,7 +487,7 @@ def main():
         # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (separate
         # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction), bytes per launch
         try:
-            tpath = [q for q in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+            tpath = [q for q in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
                      if os.path.exists(os.path.join(ROOT, "profiles", q))][0]
             tj = json.load(open(os.path.join(ROOT, "profiles", tpath)))
             sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k or "conv_rf" in k or
@@ -496,7 +496,7 @@ def main():
             if nl and not args.forward_only and bs == 64 and size == 416 and args.dtype == "f16":
                 roof["traffic"] = sum(v["hbm_bytes_per_launch_corrected"] * v["launches"] for v in sel) / nl
                 roof["traffic_source"] = "profiles/%s (same command, earlier run)" % tpath
-        except (OSError, ValueError, KeyError):
+        except (OSError, ValueError, KeyError, IndexError):
             pass
         if roof.get("avg_launch_ms"):
             roof["flops_per_launch"] = igemm_flops / max(roof.get("launches_per_step", 1), 1)

@@ -52,8 +52,11 @@ static inline unsigned grid_for(size_t total, unsigned cap = 16384) {
     return (unsigned)nb;
 }
 
-// per-(device, stream) scratch for the partial sums; grows on demand (hipFree synchronises the device, so a buffer
-// is never released under a kernel that still uses it)
+// per-(device, stream) scratch for the partial sums.  Grows on demand and NEVER frees or moves a buffer it has handed
+// out: ResNet50Yolo(graph=True) bakes these pointers into a captured HIP graph, and stream handles come from a small
+// round-robin pool, so another user of the same hipStream_t may ask for more later.  A larger request gets
+// a NEW buffer; the old ones stay alive until the process ends (they are a few MB).  Growth during a stream capture
+// is refused (hipMalloc is not capturable and the graph would keep the too-small pointer): the caller fails loudly.
 namespace y2 {
 void* op_scratch(hipStream_t s, size_t bytes) {
     static std::mutex mu;
@@ -63,11 +66,17 @@ void* op_scratch(hipStream_t s, size_t bytes) {
     std::lock_guard<std::mutex> lock(mu);
     auto& e = pool[std::make_pair(dev, s)];
     if (e.second < bytes) {
-        if (e.first) (void)hipFree(e.first);
-        e.first = nullptr;
-        e.second = 0;
-        const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-        if (hipMalloc(&e.first, want) != hipSuccess) { e.first = nullptr; return nullptr; }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap != hipStreamCaptureStatusNone) {
+            set_error(Y2_ERR_STATE, "operator scratch would have to grow during a stream capture: run one eager step first");
+            return nullptr;
+        }
+        // generous first size: the largest request of the ResNet-50 swap at batch 32 is < 8 MB
+        const size_t want = bytes < (16u << 20) ? (16u << 20) : bytes + bytes / 2;
+        void* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e.first = p;          // the previous buffer (if any) is deliberately leaked: a graph may still replay into it
         e.second = want;
     }
     return e.first;

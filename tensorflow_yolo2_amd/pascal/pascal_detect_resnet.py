@@ -43,13 +43,20 @@ def main(argv=None):
                   root_depth=64 // d, fc_hidden=4096 // d)
     model = tf_resnet.ResNet50Yolo(1, size, B=B, num_class=imdb.num_class, dtype=args.dtype, **kw)
     restored = 0
-    if args.weights and (os.path.isfile(args.weights) or os.path.isfile(args.weights + ".index")):
+    if args.weights and not (os.path.isfile(args.weights) or os.path.isfile(args.weights + ".index")):
+        # the reference always restores before it runs (pascal_detect_resnet.py: saver.restore): a missing file is an error
+        raise FileNotFoundError("--weights %s: no such snapshot (.npz, V1 .ckpt file or V2 .ckpt prefix)" % args.weights)
+    if args.weights:
         print('Restorining model from weight file {:s}'.format(args.weights))
         names, _ = net_utils.restore_resnet_variables(model, args.weights, with_optimizer=False)
         restored = len(names)
         print('Restored.')
     elif args.ckpt_dir:
         restored = net_utils.restore_resnet_tf_variables(model, args.ckpt_dir, 'resnet50', save_epoch=False)
+    if not restored:
+        import warnings
+        warnings.warn("pascal_detect_resnet: no variables were restored (no --weights and no snapshot in --ckpt-dir): "
+                      "the boxes below come from randomly initialised variables", RuntimeWarning)
     input_data = torch.as_tensor(np.ascontiguousarray(image)).cuda()
     predicts = model.forward(input_data, is_training=False, update_moving=False, dropout=False).cpu().numpy()
     cfg.S = S

@@ -57,9 +57,12 @@ def reduce_flat(flat, ranges, dist, strategy="allreduce"):
     strategy "rs_ag": explicit reduce_scatter + all_gather of each range (the direct algorithm over the
     point-to-point xGMI links SURVEY section 5 prices at ~0.3 ms for 193 MB against ~2.2 ms for one ring);
     the < world trailing elements of a range that do not divide go through a small all_reduce."""
+    import os
     world = dist.get_world_size()
+    # world 1 only under Y2_FORCE_DIST=1 (tests/rccl_worker.py: the real backend's calls on one GPU)
+    multi = world > 1 or os.environ.get("Y2_FORCE_DIST") == "1"
     for (s, e) in ranges:
-        if strategy == "rs_ag" and world > 1 and (e - s) >= world * 1024:
+        if strategy == "rs_ag" and multi and (e - s) >= world * 1024:
             n = (e - s) // world * world
             body = flat[s:s + n]
             rank = dist.get_rank()

@@ -264,6 +264,26 @@ def save_variables(network, path, kind=None, optimizer=None):
     return sorted(blob)
 
 
+_F32_MIN_NORMAL = 1.1754943508222875e-38
+
+
+def adam_step_from_powers(beta1_power=None, beta2_power=None, b1=0.9, b2=0.999):
+    """Step count t of a TF-written Adam checkpoint, which only holds `beta1_power` = b1^(t+1) and `beta2_power` =
+    b2^(t+1) as float32 variables.  b1^(t+1) leaves the normal float32 range after ~830 steps and is 0.0 after ~1000
+    (the reference saves at 40000), so the slowly decaying b2 power is used while it is a normal float32 (t < ~87000);
+    beyond both, the bias corrections are 1 to float precision and any large t gives the same update."""
+    for power, b in ((beta2_power, b2), (beta1_power, b1)):
+        if power is None:
+            continue
+        v = float(np.asarray(power).reshape(-1)[0])
+        if np.isfinite(v) and _F32_MIN_NORMAL <= v < 1.0 and 0.0 < b < 1.0:
+            return max(0, int(round(np.log(v) / np.log(b))) - 1)
+        if np.isfinite(v) and v >= 1.0:
+            return 0
+    have = [p for p in (beta1_power, beta2_power) if p is not None]
+    return 10 ** 6 if have else 0
+
+
 def restore_variables(network, path, kind=None, optimizer=None):
     """`path`: an .npz snapshot or a TF V2 checkpoint (prefix `x.ckpt`, or its `.index` / `.meta` file name).
     load the variables whose names are present in the snapshot, leave the others as they are
@@ -298,7 +318,9 @@ def restore_variables(network, path, kind=None, optimizer=None):
             if "adam_step" in snap.files:
                 st["t"] = int(snap["adam_step"])
             else:   # a checkpoint written by TF only has the beta powers: beta^(t+1) after t steps
-                st["t"] = max(0, int(round(np.log(float(snap["beta1_power"])) / np.log(optimizer.b1))) - 1)
+                st["t"] = adam_step_from_powers(snap["beta1_power"] if "beta1_power" in snap.files else None,
+                                                snap["beta2_power"] if "beta2_power" in snap.files else None,
+                                                optimizer.b1, optimizer.b2)
             optimizer.load_state(st)
         elif "accum" in st and all((nm["W"] + "/Momentum") in snap.files for nm in names):
             flat = st["accum"]
@@ -417,10 +439,9 @@ def restore_resnet_variables(model, path, exclude=(), with_optimizer=True):
         model.v.copy_(torch.as_tensor(v_host).to(model.v.device))
         if "adam_step" in have:
             t = int(snap["adam_step"])
-        elif "beta1_power" in have:
-            t = max(0, int(round(np.log(float(snap["beta1_power"])) / np.log(0.9))) - 1)
         else:
-            t = 0
+            t = adam_step_from_powers(snap["beta1_power"] if "beta1_power" in have else None,
+                                      snap["beta2_power"] if "beta2_power" in have else None)
         model.t = t
         model.ctrl[1] = t                               # the guarded update keeps its step count on the device
     return restored, kept
@@ -431,7 +452,10 @@ def restore_resnet_tf_variables(model, ckpt_dir, net_name='resnet50', retrain=Fa
     """Reference :137-219.  No snapshot in `ckpt_dir`: the head and the optimizer keep their initial values and the
     convolutional layers are restored from the downloaded `resnet_v1_50.ckpt` under `weights_path` (cfg.WEIGHTS_PATH;
     skipped when the file is absent) -> 0.  Otherwise the latest snapshot is restored (without its optimizer slots
-    when `new_optimizer` names a new optimizer) -> its iteration / epoch number."""
+    when `new_optimizer` names a new optimizer) -> its iteration / epoch number.
+    Difference from the reference: its `retrain` argument is accepted and IGNORED there (:137-219 never reads it); here
+    `retrain=True` skips the snapshots and starts again from the downloaded backbone weights, as the name says.  The
+    default (False) is the reference's behaviour."""
     sfiles = get_ordered_ckpts(ckpt_dir, net_name, save_epoch) if ckpt_dir else []
     if not sfiles or retrain:
         if weights_path:

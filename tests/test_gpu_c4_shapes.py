@@ -69,14 +69,10 @@ def test_c4_first_layer_f16_vs_float64():
     check_first_layer(N, 416, backward=True, tag="C4")
 
 
-def test_full_detector_step_f32_416_bs8_vs_torch_oracle():
-    """One whole detector step in the parity-grade mode at BASELINE.json configs[3]'s geometry (416x416, S=13;
-    batch 8 to bound the host time of the oracle): grid_net, loss, ious, object_mask, and gradients against the
-    PyTorch-CPU restatement (oracle/torch_ref.py, fp32 autograd).  The batch-64 run of the benchmarked f16 mode is
-    covered by the per-shape tests above and the property test in test_gpu_net.py."""
+def _full_detector_step_f32_vs_torch_oracle(n):
     from oracle import torch_ref as T, loss_ref as L
     from tensorflow_yolo2_amd import engine as E, synthetic
-    n, size, S = 8, 416, 13
+    size, S = 416, 13
     spec = E.CORE_SPEC + E.det_head_spec(30)
     params = R.init_params(spec, seed=0)
     x = synthetic.images(n, size, 1234)
@@ -103,9 +99,27 @@ def test_full_detector_step_f32_416_bs8_vs_torch_oracle():
         a = g[l]["W"].ravel().astype(np.float64)
         b = tp[l]["W"].grad.numpy().ravel().astype(np.float64)
         cosines[l] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
-    print("C4 f32 step bs8: grid %.2e  loss %.2e  mask mismatches %d  last-layer grads %.2e  cos(dW) %s" %
-          (e_grid, e_loss, mism, e_last, cosines))
-    assert e_grid < TOL and e_loss < TOL and e_last < TOL
+    print("C4 f32 step bs%d: grid %.2e  loss %.2e  mask mismatches %d  last-layer grads %.2e  cos(dW) %s" %
+          (n, e_grid, e_loss, mism, e_last, cosines))
+    import _obs
+    _obs.gate("c4_f32_step_bs%d grid" % n, e_grid, TOL)
+    _obs.gate("c4_f32_step_bs%d loss" % n, e_loss, TOL)
+    _obs.gate("c4_f32_step_bs%d last-layer grads" % n, e_last, TOL)
+    _obs.gate("c4_f32_step_bs%d 1-min cos(dW)" % n, 1.0 - min(cosines.values()), 1e-3)
     # object_mask is index work: it may only differ where two IoUs tie to within fp32 round-off of the two sides
     assert mism == 0 or rel_to_max(ious.cpu().numpy(), rious.detach().numpy().astype(np.float64)) < 3e-3
     assert all(c > 0.999 for c in cosines.values()), cosines
+
+
+def test_full_detector_step_f32_416_bs8_vs_torch_oracle():
+    """One whole detector step in the parity-grade mode at BASELINE.json configs[3]'s geometry (416x416, S=13;
+    batch 8): grid_net, loss, ious, object_mask, and gradients against the PyTorch-CPU restatement
+    (oracle/torch_ref.py, fp32 autograd)."""
+    _full_detector_step_f32_vs_torch_oracle(8)
+
+
+def test_full_detector_step_f32_416_bs64_vs_torch_oracle():
+    """The same whole step at the BENCHMARKED batch (64 per GPU, configs[3]): tile policies, split-K depths and the
+    planner's filter layouts depend on N*H*W, and round 2's f32 mode produced wrong outputs from batch 24 up while
+    every end-to-end test ran at batch <= 16.  ~30-60 s of host time for the oracle."""
+    _full_detector_step_f32_vs_torch_oracle(64)

@@ -130,3 +130,22 @@ def test_c1_image_preprocessing_matches_golden(golden_dir):
     np.testing.assert_array_equal(img, g["image"])
     assert -1.0 <= img.min() and img.max() <= 1.0
     np.testing.assert_array_equal(D.normalise(D.resize_bilinear_u8(rgb[:, :, ::-1], 224, 224)), g["image"])
+
+
+def test_adam_step_recovered_from_tf_beta_powers_survives_underflow():
+    """A TF-written Adam checkpoint only holds float32 beta1_power = 0.9^(t+1) and beta2_power = 0.999^(t+1).  The first
+    is denormal after ~830 steps and 0.0 after ~1000 (the reference saves at 40000: pascal_train_darknet.py:104-109),
+    so the step must come from beta2_power; with neither usable any large t is equivalent."""
+    from tensorflow_yolo2_amd.yolo2_nets.net_utils import adam_step_from_powers as f
+    for t in (0, 1, 3, 50, 985, 1100, 40000, 80000):
+        b1p = np.float32(np.float64(0.9) ** (t + 1))
+        b2p = np.float32(np.float64(0.999) ** (t + 1))
+        assert f(b1p, b2p) == t, t
+    for t in (0, 3, 50, 400):                                  # beta1_power alone while it is a normal float32
+        assert f(np.float32(np.float64(0.9) ** (t + 1)), None) == t
+    assert f(np.float32(0.0), None) >= 10 ** 5                 # underflowed, no second power: bias corrections are 1
+    assert f(np.float32(0.0), np.float32(0.0)) >= 10 ** 5
+    assert f(np.float32(1e-42), None) >= 10 ** 5               # denormal: log of it is not a step count
+    assert f(np.float32(np.nan), np.float32(np.inf)) >= 10 ** 5
+    assert f(None, None) == 0
+    assert f(np.float32(1.0), np.float32(1.0)) == 0

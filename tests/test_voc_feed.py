@@ -188,6 +188,16 @@ def test_tf_checkpoint_round_trip_through_the_network(tmp_path):
     opt3 = E.AdamOptimizer(det2)
     NU.restore_variables(det2, str(tmp_path / "voc" / "train_iter_4.ckpt.index"), optimizer=opt3)
     assert opt3.t == 3
+    # after 40000 steps TF's float32 beta1_power has underflowed to 0.0 (log(0) used to raise here)
+    blob["beta1_power"] = np.float32(0.0)
+    blob["beta2_power"] = np.float32(np.float64(0.999) ** 40001)
+    tf_bundle.write_bundle(str(tmp_path / "voc" / "train_iter_40000.ckpt"), blob)
+    opt4 = E.AdamOptimizer(det2)
+    NU.restore_variables(det2, str(tmp_path / "voc" / "train_iter_40000.ckpt"), optimizer=opt4)
+    assert opt4.t == 40000
+    det2.grads.normal_()
+    opt4.step()
+    assert torch.isfinite(det2.params).all()
     # classifier checkpoint -> detector backbone
     cls = E.Network(list(E.CORE_SPEC) + list(E.CLS_HEAD_SPEC), 1, 64, 64, dtype="f32", core_layers=19, training=False)
     cls.init_params(7)
