@@ -1176,8 +1176,12 @@ int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, 
 // ---------------------------------------------------------------------------
 struct OpPlan {
     int Cin_p, Cdy, Cout_pad, Cin_pad, ldy;
-    size_t xp, wf, wd, y, dyp, dx, dw, total;
+    size_t xp, wf, wd, y, dyp, dx, dw, slab, total;
 };
+// split-K partial tiles of the op-level weight gradient (WgradArgs::slab): at most ~1,000 workgroups x one 64 x 32 x 9
+// (or 128 x 128) tile, as in the network plan -- the op-level gradients are then summed in a fixed order too
+// (no float atomics: bit-reproducible run to run, like the network's)
+constexpr size_t kOpSlabFloats = (size_t)1024 * 18432;
 static OpPlan op_plan(int N, int H, int W, int Cin, int Cout, int k, int dtype) {
     OpPlan p{};
     const size_t sz = dtype_size(dtype);
@@ -1195,6 +1199,7 @@ static OpPlan op_plan(int N, int H, int W, int Cin, int Cout, int k, int dtype) 
     p.dyp = take(PadGeom{N, H, W, p.Cdy}.bytes(sz));
     p.dx = take((size_t)N * H * W * p.Cin_p * sz + 256);
     p.dw = take((size_t)k * k * p.Cin_p * Cout * sizeof(float));
+    p.slab = take(kOpSlabFloats * sizeof(float));
     p.total = off;
     return p;
 }
@@ -1264,6 +1269,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
         g.x = xp; g.dy = dyp; g.dW = direct ? dw : (float*)(ws + p.dw);
         g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = p.Cin_p; g.Cdy = p.Cdy; g.Cout = Cout;
         g.taps = k * k; g.splitk = 0; g.scale = 1.f;
+        g.slab = (float*)(ws + p.slab); g.slab_floats = kOpSlabFloats;
         HIPCHK(launch_wgrad_auto(dtype, g, s));
         for (int t = 0; t < k * k && !direct; ++t)
             HIPCHK(hipMemcpyAsync(dw + (size_t)t * Cin * Cout, (float*)(ws + p.dw) + (size_t)t * p.Cin_p * Cout,

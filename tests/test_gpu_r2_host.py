@@ -306,8 +306,9 @@ def test_fused_train_op_equals_backward_then_step(dtype):
     assert torch.equal(a.net.params, b.net.params)
     lab = dev(synthetic.det_labels(n, size, S, 2))
 
-    # split-K float atomics make two backward passes differ in the last bits, so the second trainer takes the
-    # first one's gradient buffer and only runs the separate check + step on it
+    # the second trainer takes the first one's gradient buffer and only runs the separate check + step on it: the
+    # comparison is then about the optimizer forms alone (written when split-K float atomics still made two backward
+    # passes differ in the last bits; they have been order-fixed slab sums since round 2)
     for it in range(4):
         x = dev(synthetic.images(n, size, 10 + it))
         if it == 2 and dtype == "f16":       # one overflowing step: both forms must skip it

@@ -307,9 +307,10 @@ def test_graph_replay_follows_the_eager_steps():
     """graph=True replays forward + loss + backward + guarded Adam from one HIP graph (step counter, dropout seed and
     overflow flag in device memory).  Against the per-operator launches on the same changing batches: identical first
     step, the same dropout seeds and step counts throughout, and the losses of the first replayed steps within 1e-3 --
-    this 1/8-width net normalises over 8 samples in its last block and amplifies the last-bit differences of the
-    atomically summed split-K weight gradients (two eager runs drift apart the same way, scripts/diag_graph.py), so
-    later steps are compared by their bookkeeping only."""
+    this 1/8-width net normalises over 8 samples in its last block and amplifies last-bit differences; until round 4 the
+    op-level weight gradients (y2_conv2d_backward) added their split-K partials with float atomics and two eager runs
+    drifted apart the same way (scripts/diag_graph.py).  They now go through the slab and a fixed-order sum like the
+    network's (test_resnet_backward_is_bit_reproducible below); the later steps stay compared by their bookkeeping."""
     from tensorflow_yolo2_amd import synthetic
     from tensorflow_yolo2_amd.yolo2_nets import tf_resnet
     blocks = RR.scaled_blocks(8)
@@ -341,3 +342,89 @@ def test_graph_replay_follows_the_eager_steps():
     b.params.copy_(p0); b.m.copy_(m0); b.v.copy_(v0)
     l2 = b.step(x, lab)[0].clone()
     assert not torch.equal(l1, l2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: the bottleneck convolutions pick tile policies no Darknet shape touches
+# ---------------------------------------------------------------------------------------------------------------
+# every distinct (k, cin, cout, hw) of slim's resnet_v1_50 at 224x224 behind the 7x7/2 root + 3x3/2 pool
+# (src/slim_dir/nets/resnet_v1.py:185-199 blocks (64,3) (128,4) (256,6) (512,3); the stride-2 3x3 of a block's last
+# unit is computed at its INPUT resolution and subsampled -- resnet_utils.py:77-122 conv2d_same / subsample)
+RESNET50_CONV_SHAPES = [
+    (1, 64, 64, 56), (3, 64, 64, 56), (1, 64, 256, 56), (1, 256, 64, 56), (1, 64, 256, 28),
+    (1, 256, 128, 28), (3, 128, 128, 28), (1, 128, 512, 28), (1, 256, 512, 28), (1, 512, 128, 28), (1, 128, 512, 14),
+    (1, 512, 256, 14), (3, 256, 256, 14), (1, 256, 1024, 14), (1, 512, 1024, 14), (1, 1024, 256, 14), (1, 256, 1024, 7),
+    (1, 1024, 512, 7), (3, 512, 512, 7), (1, 512, 2048, 7), (1, 1024, 2048, 7), (1, 2048, 512, 7),
+]
+
+
+@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("f32", 1e-5)])
+@pytest.mark.parametrize("batch", [4, 32])
+@pytest.mark.parametrize("k,cin,cout,hw", RESNET50_CONV_SHAPES, ids=["%dx%d_%d-%d@%d" % (s[0], s[0], s[1], s[2], s[3])
+                                                                      for s in RESNET50_CONV_SHAPES])
+def test_resnet50_conv_shapes_vs_float64(k, cin, cout, hw, batch, dtype, tol):
+    """forward, dgrad and wgrad of y2_conv2d(_backward) at every ResNet-50 bottleneck shape, at the reference's batch 4
+    (pascal_train_resnet.py:26) and the benchmarked batch 32, in the f16 mode (1e-3 of the max) and the parity-grade
+    f32 mode (1e-5), against float64 (tests/_shapes.py)"""
+    from _shapes import check_layer_shape
+    check_layer_shape(batch, "resnet", k, cin, cout, hw, "C5-resnet50", dtype=dtype, tol=tol)
+
+
+def test_resnet_backward_is_bit_reproducible():
+    """The op-level weight gradients (y2_conv2d_backward) sum their split-K partial tiles through a slab in a fixed order
+    since round 4 (they were float atomics: ResNet gradients were not run-to-run reproducible while the detector's
+    were -- VERDICT r3 weak 6): two backward passes of ResNet50Yolo from the same forward state give the same bits."""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from tensorflow_yolo2_amd.yolo2_nets import tf_resnet
+    for dtype, kw in (("f32", dict(blocks=RR.scaled_blocks(4), root_depth=16, fc_hidden=512)), ("f16", {})):
+        n, size = (4, 96) if kw else (4, 224)
+        m = tf_resnet.ResNet50Yolo(n, size, dtype=dtype, seed=1, **kw)
+        x = dev(synthetic.images(n, size, 5))
+        lab = dev(synthetic.det_labels(n, size, size // 32, 6))
+        runs = []
+        for _ in range(3):
+            m.drop_seed = 10                                    # the same dropout mask every time
+            grid = m.forward(x, True, update_moving=False)
+            _l, _i, _m, dnet = E.yolo_loss(grid, lab, 20, n, size, size // 32, 2)
+            m.grads.zero_()
+            m.backward(dnet * m.loss_scale)                     # 1024 in f16 (tf_resnet.py), 1 in f32
+            torch.cuda.synchronize()
+            runs.append(m.grads.clone())
+        assert float(runs[0].abs().max()) > 0 and torch.isfinite(runs[0]).all()
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), dtype
+
+
+def test_resnet50_full_width_directional_derivative_f32():
+    """Full-width resnet_v1_50 + FC head at 224x224, batch 4, f32 (the reference's configuration,
+    pascal_train_resnet.py:26,37-50): the loss change along the gradient matches <grad, v> -- independent of any
+    oracle, like test_full_size_416_properties for the Darknet detector.  Dropout off (the reference's keep_prob is
+    a training-time mask; the derivative is of the deterministic function)."""
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from tensorflow_yolo2_amd.yolo2_nets import tf_resnet
+    n, size, S = 4, 224, 7
+    m = tf_resnet.ResNet50Yolo(n, size, dtype="f32", seed=0)
+    x = dev(synthetic.images(n, size, 1))
+    lab = dev(synthetic.det_labels(n, size, S, 2))
+    p0 = m.params.clone()
+
+    def loss_at(params, need_grad):
+        m.params.copy_(params)
+        grid = m.forward(x, True, update_moving=False, dropout=False)
+        l, _i, mask, d = E.yolo_loss(grid, lab, 20, n, size, S, 2)
+        return l[4].item(), d, mask.clone()
+
+    base, dnet, mask0 = loss_at(p0, True)
+    m.grads.zero_()
+    m.backward(dnet)
+    g = m.grads.clone()
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    # the loss jumps where a cell's responsible box changes: take the largest step that leaves object_mask alone
+    for frac in (2e-3, 5e-4, 1e-4):
+        v = g * (frac * base / float((g * g).sum()))
+        lp, _, mp = loss_at(p0 + v, False)
+        lm, _, mm = loss_at(p0 - v, False)
+        if torch.equal(mp, mask0) and torch.equal(mm, mask0):
+            break
+    num, ana = (lp - lm) / 2, float((g * v).sum())
+    print("resnet50 full width f32: loss %.4f  step %.0e  numeric %.4e  analytic %.4e" % (base, frac, num, ana))
+    assert ana > 0 and abs(num - ana) < 0.1 * abs(ana), (num, ana, base, frac)
