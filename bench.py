@@ -167,6 +167,73 @@ def sustained(run, sync_all, steps, batch, world):
     return {"steps": steps, "ms_per_step": el / steps * 1e3, "images_per_s": world * batch * steps / el}
 
 
+def extra_leg(name, net, run, spec, flop_mult, bs, size, dtype, steps=20, warmup=3):
+    """another BASELINE.json configuration timed in the same process (driver-visible: the driver only runs
+    `bench.py --gpus 1`): `warmup` untimed + `steps` timed steps between synchronisations; the MFMA convolution
+    launches of two of them are bracketed with HIP events (union of the intervals, as the headline's `roofline.frac`)"""
+    import torch
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    sampled = 0
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i % 10 == 0:
+            net.profile_enable(2 if sampled == 0 else 3)
+            sampled += 1
+        elif i % 10 == 1:
+            net.profile_enable(0)
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    busy_ms, launches = net.profile_busy()
+    net.profile_collect()
+    net.profile_enable(0)
+    per = conv_flops(spec, bs, size)
+    total, igemm = sum(per) * flop_mult, sum(per[1:]) * flop_mult
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    out = {"workload": name, "dtype": dtype, "batch": bs, "image_size": size, "steps": steps, "warmup": warmup,
+           "ms_per_step": ms, "images_per_s": bs / (ms * 1e-3), "whole_step_tflops": total / (ms * 1e-3) / 1e12,
+           "whole_step_frac": total / (ms * 1e-3) / 1e12 / peak, "frac": None}
+    if busy_ms > 0 and sampled:
+        t = busy_ms / sampled * 1e-3
+        out.update({"frac": igemm / t / 1e12 / peak, "mfma_launch_union_ms": busy_ms / sampled,
+                    "launches_per_step": launches / sampled, "bracketed_steps": sampled})
+    return out
+
+
+def c2_forward_leg(args, device):
+    """BASELINE.json configs[1]: darknet19_core forward, 416x416, batch 32, batch norm with the moving statistics
+    (pascal_detect_darknet.py:41-43)"""
+    import torch
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    bs, size = 32, 416
+    net = E.Network(list(E.CORE_SPEC), bs, size, size, dtype=args.dtype, training=False, device=device)
+    net.init_params(0)
+    x = torch.as_tensor(synthetic.images(bs, size, 1234)).to(device)
+    out = extra_leg("configs[1]: darknet19_core forward 416x416 batch 32, inference batch norm", net,
+                    lambda: net.forward(x, False, False), list(E.CORE_SPEC), 1.0, bs, size, args.dtype)
+    out["target_ms"] = 0.65                      # 40 % of the dense peak (SURVEY 8d)
+    return out
+
+
+def c3_classifier_leg(args, device):
+    """BASELINE.json configs[2]: darknet19() + softmax cross-entropy fwd+bwd + Momentum(0.001, 0.9), 224x224, batch 128
+    (src/imagenet/imagenet_train_darknet.py:46-58)"""
+    import numpy as np
+    import torch
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    from tensorflow_yolo2_amd.trainer import ClassifierTrainer
+    bs, size = 128, 224
+    tr = ClassifierTrainer(bs, size, dtype=args.dtype, device=device, seed=0)
+    x = torch.as_tensor(synthetic.images(bs, size, 1234)).to(device)
+    lab = torch.as_tensor(np.random.default_rng(5).integers(0, 1000, bs).astype(np.int32)).to(device)
+    out = extra_leg("configs[2]: darknet19 classifier fwd+bwd + Momentum 224x224 batch 128", tr.net,
+                    lambda: tr.step(x, lab), list(E.CORE_SPEC) + list(E.CLS_HEAD_SPEC), 3.0, bs, size, args.dtype)
+    out["target_ms"] = 2.30
+    return out
+
+
 def fed_input(args, tr, device, resident_ms):
     """the fed loop: uint8 batches assembled in pinned memory and uploaded on their own stream while the previous
     step runs (utils/feeder.py), the float conversion inside the input pack kernel (y2_forward_u8).  The producer
@@ -339,7 +406,9 @@ def main():
     ap.add_argument("--sustain-steps", type=int, default=300, help="extra timed region without events (0: skip)")
     ap.add_argument("--fed-steps", type=int, default=30, help="fed-input leg: uint8 upload pipeline (0: skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: core forward only (inference BN)")
-    ap.add_argument("--model", default="detector", choices=["detector", "yolov2", "resnet50"],
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the c2_forward (configs[1]) and c3_classifier (configs[2]) legs of the default line")
+    ap.add_argument("--model", default="detector", choices=["detector", "yolov2", "resnet50", "classifier"],
                     help="detector: the reference's Darknet-19 grid detector (the headline); yolov2: the north star's "
                          "anchor model (passthrough + anchor loss), not in the reference")
     ap.add_argument("--graph", action="store_true", help="resnet50: replay the step from one HIP graph")
@@ -389,6 +458,17 @@ def main():
     if args.model == "resnet50":
         assert world == 1, "the ResNet swap is a single-GPU functional path (replicas only)"
         return bench_resnet(args, device, rank, world, dist)
+    if args.model == "classifier":      # configs[2] on its own (what profiles/r04_*_c3* trace)
+        assert world == 1
+        out = c3_classifier_leg(args, device)
+        line = {"metric": "images/sec fwd+bwd Darknet-19 classifier 224x224", "value": out["images_per_s"],
+                "unit": "images/s", "n_gpus": 1, "steps": out["steps"], "warmup": out["warmup"],
+                "ms_per_step": out["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic", "config": {"workload": out["workload"]},
+                "roofline": {"bound": "mfma", "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                             "frac": out["frac"], "whole_step_frac": out["whole_step_frac"], "traffic": None}}
+        print(json.dumps(line))
+        return line
     if args.forward_only:
         net = E.Network(spec_core, bs, size, size, dtype=args.dtype, training=False, device=device)
         net.init_params(0)
@@ -526,9 +606,19 @@ def main():
                 out["fed_input"] = fed_input(args, tr, device, ms_per_step)
             except Exception as e:
                 out["fed_input"] = {"error": repr(e)}
+        if world == 1 and not args.forward_only and not args.no_extra_legs:
+            del tr, net, run
+            torch.cuda.empty_cache()
+            tr = net = run = None
+            for key, leg in (("c2_forward", c2_forward_leg), ("c3_classifier", c3_classifier_leg)):
+                try:
+                    out[key] = leg(args, device)
+                except Exception as e:
+                    out[key] = {"error": repr(e)}
+                torch.cuda.empty_cache()
         if world == 1 and not args.forward_only and not args.no_f32_mode and args.dtype != "f32":
             try:
-                del tr, net, run
+                tr = net = run = None
                 torch.cuda.empty_cache()
                 out["f32_mode"] = f32_mode(args, images, labels, device, total_flops, igemm_flops)
             except Exception as e:

@@ -135,6 +135,34 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
     // exact products of the stored values, fp32 accumulation; the block's (mean, M2) record is formed in double.
     bool mfma_stats = false;
     if constexpr (SZ == 2) mfma_stats = stats && !bw && (m0 + BP <= a.M);   // block-uniform
+    if (!bw && a.aff_out) {
+        // ---- inference batch norm folded in (kernels.h ConvArgs::aff_*): out = leaky(T(conv + b) * scale + shift)
+        // into the consumer's bordered tensor.  Bordered position of pixel m = r*W + w, r = n*H + h:
+        //   bpix = (r + n + 1) * (W + 1) + w + 1 = m + r + (n + 1) * (W + 1) + 1
+        const bool cv = cch < a.ldy;
+        float sc[EPC], sh[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            sc[e] = cv ? a.aff_scale[cch + e] : 0.f;
+            sh[e] = cv ? a.aff_shift[cch + e] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int prow = it * RPIe + prow0;
+            Chunk<T> c = ld_chunk<T>(ew + prow * EROW + ch * 16);
+            const uint32_t m = (uint32_t)(mw0 + prow);
+            if ((int)m < a.M && cv) {
+                const uint32_t r = (uint32_t)(((uint64_t)m * a.aff_magW) >> a.aff_shW);
+                const uint32_t n = (uint32_t)(((uint64_t)r * a.aff_magH) >> a.aff_shH);
+                const size_t bp = (size_t)m + r + (size_t)(n + 1) * (uint32_t)(a.W + 1) + 1;
+                Chunk<T> o;
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(leaky01(Elem<T>::to_f32(c.v[e]) * sc[e] + sh[e]));
+                st_chunk<T>((char*)a.aff_out + (bp * a.ldy + cch) * SZ, o);
+            }
+        }
+        return;
+    }
     if (!bw) {
         const bool chk = a.nonfinite != nullptr;
         bool bad = false;

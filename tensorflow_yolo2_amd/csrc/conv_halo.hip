@@ -343,7 +343,48 @@ static int dev_rule(int W, int Cout) {
 // 0: K-contiguous rows (conv_halo / conv_igemm); 1: 32-row MFMA fragments (conv_haloq, 32x32x16 tiles);
 // 2: 16-row fragments (conv_haloq on 16x16x32 tiles: the 384 x 128 tile class up to 26x26, +3-4 %).
 // row_bytes = input channels * element size of the launch (forward: cin_s, dgrad: ldy).
-int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad) {
+// Tile choice of conv_haloq on the short-row layers.  Rounds 1-3 tuned the launch policy on the 416x416 batch-64 shapes
+// only: 384 x 128 tiles (384 x 64 where fewer than 160 of them exist).  At 224x224 batch 128 (configs[2]) that puts 264
+// workgroups of the 14x14 layers on 256 CUs -- two rounds, the second with eight workgroups -- and 136 / 272 on the
+// 7x7 ones: those layers ran at 0.5-0.6 PFLOP/s against 1.0-1.1 for their 26x26 / 13x13 siblings
+// (profiles/r04_layers_c3_round_start.txt).  Cost model fitted to a sweep of six tile shapes over the six 3x3 shapes
+// of configs[2] (scripts/sweep_c3.sh, profiles/r04_sweep_c3_tiles.txt; rms error 7 %):
+//     time ~ rounds * BP * BC / (eff(tile) * (1 + (1 - fill)))     rounds = ceil(workgroups / 256), fill = wgs / (rounds * 256)
+// (one 8-wave workgroup per CU; a partly filled chip runs each workgroup faster: clocks and L2 share).  The legacy
+// choice stays unless the model sees more than 8 % in another tile, so every configs[3] layer keeps its kernel.
+static double hq_cost(int M, int Cout, int bp, int bc, double eff) {
+    const long n = (long)((M + bp - 1) / bp) * ((Cout + bc - 1) / bc);
+    const long r = (n + 255) / 256;
+    const double fill = (double)n / (double)(r * 256);
+    return (double)r * bp * bc / (eff * (2.0 - fill));
+}
+int haloq_tile_choice(int W, int row_bytes, int Cout, int M, int elem_size) {
+    static const bool no52 = getenv("Y2_NO_HALOQ_52") != nullptr;
+    static const bool legacy_only = getenv("Y2_LEGACY_TILES") != nullptr;     // A/B switch: rounds 1-3 policy
+    const int wsmall = no52 ? 26 : 52;
+    if (!(W <= wsmall && Cout > 64 && M >= 384 * 8 && (row_bytes % 128) == 0)) return HQ_NONE;
+    const bool narrow = ((M + 383) / 384) * ((Cout + 127) / 128) < 160;
+    // the f32 epilogue patch of a 384 x 128 (and 512 x 128) tile does not fit LDS: 256 x 128 on 16x16 tiles there
+    const int legacy = narrow ? HQ_384x64 : (elem_size == 4 ? HQ_256x128_M16 : HQ_384x128_M16);
+    if (legacy_only) return legacy;
+    struct Cand { int id, bp, bc; double eff; bool f32_ok; };
+    static const Cand cand[] = {{HQ_384x128_M16, 384, 128, 1.00, false}, {HQ_256x128_M16, 256, 128, 0.95, true},
+                                {HQ_384x64, 384, 64, 0.80, true},        {HQ_512x128, 512, 128, 1.02, false},
+                                {HQ_256x128, 256, 128, 0.92, true},      {HQ_512x64, 512, 64, 0.90, true},
+                                {HQ_256x64, 256, 64, 0.74, true}};
+    double lc = 0.0, bc = 0.0;
+    int best = legacy;
+    for (const Cand& c : cand)
+        if (c.id == legacy) lc = bc = hq_cost(M, Cout, c.bp, c.bc, c.eff);
+    for (const Cand& c : cand) {
+        if (elem_size == 4 ? !c.f32_ok : c.id == HQ_256x128_M16) continue;
+        const double v = hq_cost(M, Cout, c.bp, c.bc, c.eff);
+        if (v < bc) { bc = v; best = c.id; }
+    }
+    return bc < 0.92 * lc ? best : legacy;
+}
+
+int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad, int elem_size) {
     if (taps == 1) {
         // 1x1 on conv_haloq (one tap per K-chunk, compact image): 128-byte K chunks, more than 64 output channels, enough
         // pixels for 384-pixel tiles; 384 x 64 tiles on 32x32 MFMAs (layout 1) where 384 x 128 tiles would leave CUs
@@ -362,9 +403,19 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgra
     static const bool no52 = getenv("Y2_NO_HALOQ_52") != nullptr;
     const int wsmall = no52 ? 26 : 52;
     if (!(W <= wsmall || (W > 52 && W <= 104) || (W > 104 && Cout <= 32))) return 0;
-    const bool narrow = ((M + 383) / 384) * ((Cout + 127) / 128) < 160;
-    if (W <= wsmall && Cout > 64 && M >= 384 * 8 && (row_bytes % 128) == 0 && !narrow) return 2;
-    return 1;
+    const int tile = haloq_tile_choice(W, row_bytes, Cout, M, elem_size);
+    return (tile == HQ_384x128_M16 || tile == HQ_256x128_M16) ? 2 : 1;
+}
+
+// Inference batch norm folded into the epilogue (ConvArgs::aff_*): every kernel on the shared epilogue
+// (conv_epilogue.h); the register-filter kernels (conv_rf.hip) keep the two-pass form.  Y2_NO_INFER_FOLD=1: A/B switch.
+bool conv_affine_ok(int dtype, const ConvArgs& a) {
+    static const bool off = getenv("Y2_NO_INFER_FOLD") != nullptr;
+    if (off || a.bw_psum || a.part_mean || a.is_dgrad) return false;
+    const int rowb = a.C * (int)dtype_size(dtype);
+    if (dtype != 0 && (conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M) ||
+                       conv_rfn_config(a.taps, a.W, rowb, a.Cout, a.M, 0))) return false;
+    return a.M > 0 && (unsigned)a.M < 0x7FFFFFFFu;
 }
 
 // Kernel policy (measured on MI355X, scripts/bench_conv.py and profile_layers.py):
@@ -380,6 +431,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
     const int rowb = a.C * (int)dtype_size(dtype);
+    const int esz = (int)dtype_size(dtype);
     if (dtype != 0 && ((!a.bw_psum && conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M)) ||
                        conv_rfn_config(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad))) {
         int rec = 0;
@@ -388,7 +440,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_
         if (records) *records = rec;
         return e;
     }
-    if (conv_filter_layout(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad)) e = launch_conv_haloq(dtype, a, s, &bp);
+    if (conv_filter_layout(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad, esz)) e = launch_conv_haloq(dtype, a, s, &bp);
 #ifdef Y2_DEV
     else if (a.taps == 9 && dtype == 1 && dev_rule(a.W, a.Cout) >= 0)
         e = launch_conv_halo_variant(dev_rule(a.W, a.Cout), a, s, &bp);

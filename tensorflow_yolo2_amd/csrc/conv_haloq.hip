@@ -589,7 +589,7 @@ static hipError_t haloq_T1(const ConvArgs& a, hipStream_t s, int* bp) {
     const int kb = a.C * (int)sizeof(T);
     if ((kb % 128) != 0 || a.Cout <= 64) return hipErrorInvalidValue;
     *bp = 384;
-    if (conv_filter_layout(1, a.W, kb, a.Cout, a.M, a.is_dgrad) == 2) {
+    if (conv_filter_layout(1, a.W, kb, a.Cout, a.M, a.is_dgrad, (int)sizeof(T)) == 2) {
         if (sizeof(T) == 4) {     // the f32 epilogue patch of a 384 x 128 tile does not fit LDS
             *bp = 256;
             return haloq_pick1<T, 4, 2, 2, 2, true>(a, s);
@@ -624,23 +624,29 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
     }
     if (a.Cout > 64) {
         hipError_t e = hipErrorOutOfMemory;
-        if (a.M >= 384 * 8) {   // every fragment-filter layer (W <= 52): 384-pixel tiles measured best
-            *bp = 384;
-            const bool narrow = ((a.M + 383) / 384) * ((a.Cout + 127) / 128) < 160 && k128;
-            const bool m16 = conv_filter_layout(9, a.W, kb, a.Cout, a.M) == 2;   // filters packed for 16x16 tiles
-            if (narrow) e = haloq_pick<T, 4, 2, 3, 1, 128>(a, s);
-            else if (m16) {
-                // the filters are packed for 16-row fragments: ONLY a 16x16-tile kernel may run.  The f32 epilogue
-                // patch of a 384 x 128 tile does not fit LDS (209 KB): 256 x 128 there.  (Round 2 fell through to a
-                // 32x32-tile kernel on the 16-row pack in this case -- wrong outputs in the f32 mode whenever
-                // tiles x cout-tiles >= 160, i.e. from batch 24 up at 416x416; found by the f32 leg of the C5 test.)
-                if (sizeof(T) == 4) {
-                    *bp = 256;
-                    return haloq_pick<T, 4, 2, 2, 2, 128, true>(a, s);
-                }
-                return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s);
+        const int tile = haloq_tile_choice(a.W, kb, a.Cout, a.M, (int)sizeof(T));
+        if (tile != HQ_NONE) {
+            // the tile (and with it the filter pack: 16-row fragments for the _M16 kernels, 32-row ones otherwise) is
+            // decided by ONE function for bind and launch time (conv_halo.hip haloq_tile_choice).  (Round 2 fell through
+            // to a 32x32-tile kernel on the 16-row pack in the f32 mode -- wrong outputs from batch 24 up at 416x416.)
+            switch (tile) {
+                case HQ_384x128_M16:
+                    if constexpr (sizeof(T) == 2) { *bp = 384; return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s); }
+                    return hipErrorInvalidValue;
+                case HQ_256x128_M16: *bp = 256; return haloq_pick<T, 4, 2, 2, 2, 128, true>(a, s);
+                case HQ_384x64: *bp = 384; return haloq_pick<T, 4, 2, 3, 1, 128>(a, s);
+                case HQ_512x128:
+                    if constexpr (sizeof(T) == 2) { *bp = 512; return haloq_pick<T, 4, 2, 4, 2, 128>(a, s); }
+                    return hipErrorInvalidValue;
+                case HQ_256x128: *bp = 256; return haloq_pick<T, 4, 2, 2, 2, 128>(a, s);
+                case HQ_512x64: *bp = 512; return haloq_pick<T, 4, 2, 4, 1, 128>(a, s);
+                case HQ_256x64: *bp = 256; return haloq_pick<T, 4, 2, 2, 1, 128>(a, s);
             }
-            else e = k128 ? haloq_pick<T, 4, 2, 3, 2, 128>(a, s) : haloq_pick<T, 4, 2, 3, 2, 64>(a, s);
+            return hipErrorInvalidValue;
+        }
+        if (a.M >= 384 * 8) {   // what the cost model does not cover (64-byte K chunks; long rows that did not fit above)
+            *bp = 384;
+            e = k128 ? haloq_pick<T, 4, 2, 3, 2, 128>(a, s) : haloq_pick<T, 4, 2, 3, 2, 64>(a, s);
         } else if (a.M >= 256 * 8) {
             *bp = 256;
             e = k128 ? haloq_pick<T, 4, 2, 2, 2, 128>(a, s) : haloq_pick<T, 4, 2, 2, 2, 64>(a, s);

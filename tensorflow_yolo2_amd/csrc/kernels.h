@@ -36,11 +36,40 @@ struct ConvArgs {
     unsigned* nonfinite = nullptr;
     int xcd = 0;            // XCD-aware workgroup order (common.h xcd_block)
     int is_dgrad = 0;       // the launch computes an input gradient (filters from the dgrad copy): kernel policy only
+    // Inference-mode batch norm FOLDED into the epilogue (forward launches of un-pooled layers whose statistics are
+    // the moving ones: tf.layers.batch_normalization(training=False) is a fixed per-channel affine,
+    // src/yolo2_nets/darknet.py:39-46): the stored value is leaky(T(conv + bias) * scale + shift) -- the same
+    // arithmetic on the same rounded conv output as the two-pass form (bn_act_kernel), bit for bit -- written straight
+    // into the consumer's bordered tensor aff_out [N][H+2][W+2][ldy]; y is NOT written.  Set with conv_set_affine().
+    const float* aff_scale = nullptr;
+    const float* aff_shift = nullptr;
+    void* aff_out = nullptr;
+    uint32_t aff_magW = 0, aff_magH = 0;   // m / W = (m * magW) >> shW for m < 2^31 (Granlund-Montgomery), same for H
+    int aff_shW = 0, aff_shH = 0;
 };
+inline void conv_div_magic(uint32_t d, uint32_t* mag, int* sh) {
+    int l = 0;
+    while ((1u << l) < d) ++l;                    // ceil(log2 d)
+    *sh = 31 + l;
+    *mag = (uint32_t)((((uint64_t)1 << (31 + l)) + d - 1) / d);
+}
+inline void conv_set_affine(ConvArgs& a, const float* scale, const float* shift, void* out_bordered) {
+    a.aff_scale = scale; a.aff_shift = shift; a.aff_out = out_bordered;
+    conv_div_magic((uint32_t)a.W, &a.aff_magW, &a.aff_shW);
+    conv_div_magic((uint32_t)a.H, &a.aff_magH, &a.aff_shH);
+}
+// which launches take the folded form (else: y + the bn_act pass)
+bool conv_affine_ok(int dtype, const ConvArgs& a);
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
 hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels); // + filters via registers
-int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad = 0);   // filter layout launch_conv expects (0/1/2)
+int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad = 0, int elem_size = 2);   // filter layout launch_conv expects (0/1/2)
+// Pixel x cout tile of conv_haloq on the short-row 3x3 layers (W <= 52, more than 64 couts, 128-byte K chunks), chosen by
+// a cost model of the workgroup rounds on the 256 CUs (conv_halo.hip: haloq_tile_choice).  ONE function decides both the
+// kernel (launch time) and the filter pack it reads (bind time): HQ_384x128_M16 reads 16-row fragments (layout 2),
+// every other tile 32-row fragments (layout 1).
+enum HqTile { HQ_NONE = 0, HQ_384x128_M16, HQ_256x128_M16, HQ_384x64, HQ_512x128, HQ_256x128, HQ_512x64, HQ_256x64 };
+int haloq_tile_choice(int W, int row_bytes, int Cout, int M, int elem_size);
 // policy; *records = rows of the BN partial list written (one per pixel tile)
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels = nullptr, int* records = nullptr);
 // 3x3, filters resident in registers, persistent workgroups over the bordered pixel space (conv_rf.hip)

@@ -99,6 +99,7 @@ struct y2_ctx {
     bool fwd_saved = false;
     bool moving_pending = false;   // last forward ran with update_moving = 0
     std::vector<int> fwd_training;  // per layer BN mode of the last forward
+    std::vector<int> fwd_folded;    // per layer: the last forward folded BN + leaky into the conv epilogue (no y)
     // shared scratch offsets
     size_t o_part_scratch = 0;
     size_t o_part_cnt, o_part_mean, o_part_m2, o_psum, o_dA0, o_dA1, o_h32, o_dh32, o_xin_last_end;
@@ -352,6 +353,7 @@ int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers
     }
     plan(c);
     c->fwd_training.assign(c->L.size(), 0);
+    c->fwd_folded.assign(c->L.size(), 0);
     *out = c;
     return Y2_OK;
 }
@@ -479,8 +481,8 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
         p.wd = training ? (void*)(c->ws + y.wd) : nullptr;   // layer 0 too: y2_backward_input wants its dgrad
         p.taps = y.k * y.k; p.Cin = y.cin; p.Cout = y.cout; p.Cout_pad = y.cout_pad; p.Kc = y.cin_s;
         p.Cin_pad = y.cin_pad; p.Cdy = y.ldy;
-        p.wf_frag = conv_filter_layout(p.taps, y.W, y.cin_s * (int)c->sz(), y.cout, y.M);   // forward launch
-        p.wd_frag = conv_filter_layout(p.taps, y.W, y.ldy * (int)c->sz(), y.cin, y.M, 1);   // dgrad launch: Cout = cin
+        p.wf_frag = conv_filter_layout(p.taps, y.W, y.cin_s * (int)c->sz(), y.cout, y.M, 0, (int)c->sz());   // forward launch
+        p.wd_frag = conv_filter_layout(p.taps, y.W, y.ldy * (int)c->sz(), y.cin, y.M, 1, (int)c->sz());   // dgrad launch: Cout = cin
         pack_layer_plan(p, nb, (int)c->sz());
         nb += p.wf_blocks + p.wd_blocks;
         p.opt_first = ntile;
@@ -622,6 +624,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
         float* stat = (float*)(c->ws + y.stat);
         float *scale = stat, *shift = stat + y.ldy, *mean = stat + 2 * y.ldy, *invstd = stat + 3 * y.ldy;
         int P = 0;
+        bool folded = false;
         // pooled first layer: statistics-only conv, then conv again fused with BN + leaky + pool
         const bool pool1 = y.first3 && l + 1 < nl && y.ldy == 32 && conv1_pool_ok(y.H, y.W, y.pool, y.cout);
         if (y.first3) {
@@ -647,9 +650,19 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.cin_s; a.M = y.M; a.Cout = y.cout; a.ldy = y.ldy;
             a.taps = y.k * y.k;
             int bp = 0, rec = 0;
+            // inference statistics, no pool, a consumer layer: scale / shift / leaky ride in the conv epilogue and the
+            // activation goes straight into the consumer's bordered input (no y, no bn_act pass).  Training
+            // bindings keep y: a later y2_backward of a frozen-core graph reads it.
+            if (!training && !y.pool && l + 1 < nl && !c->bound_training && y.ldy == c->L[l + 1].cin_s &&
+                conv_affine_ok(c->dtype, a)) {
+                conv_set_affine(a, scale, shift, c->ws + c->L[l + 1].xin + c->in_geom(l + 1).base_off(sz));
+                folded = true;
+            }
             { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }
             P = rec;
         }
+        c->fwd_folded[l] = folded ? 1 : 0;
+        if (folded) continue;
         PROF(CAT_BN_FWD);
         BnFinalizeArgs f{};
         if (training) {
@@ -972,6 +985,9 @@ int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
         HIPCHK(launch_unpack_act(c->dtype, c->ws + y.xin + c->in_geom(l).base_off(sz), dst, c->N, y.H, y.W, C,
                                  y.cin_s, s));
     } else if (what == 1) {
+        if (c->fwd_folded[l])
+            return fail(Y2_ERR_STATE, "layer %d: inference batch norm was folded into the convolution, its conv output "
+                                      "is not stored (Y2_NO_INFER_FOLD=1 keeps the two-pass form)", l);
         if (y.first3 && !c->bound_training && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
             conv1_pool_ok(y.H, y.W, y.pool, y.cout))
             return fail(Y2_ERR_STATE, "inference binding: the pooled first layer does not store its conv output");
@@ -1231,7 +1247,7 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
     char* xp = ws + p.xp + g.base_off(sz);
     HIPCHK(op_pack_bordered(dtype, x, ws + p.xp, p.wf - p.xp, g, Cin, s));
     HIPCHK(launch_pack_weights(dtype, w, ws + p.wf, nullptr, k * k, Cin, Cout, p.Cout_pad, p.Cin_p, 0, 0,
-                               conv_filter_layout(k * k, W, p.Cin_p * (int)sz, Cout, N * H * W), s));
+                               conv_filter_layout(k * k, W, p.Cin_p * (int)sz, Cout, N * H * W, 0, (int)sz), s));
     ConvArgs a{};
     a.x = xp; a.w = ws + p.wf; a.y = ws + p.y; a.bias = bias;
     a.N = N; a.H = H; a.W = W; a.C = p.Cin_p; a.M = N * H * W; a.Cout = Cout; a.ldy = p.ldy; a.taps = k * k;
@@ -1255,7 +1271,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
     HIPCHK(op_pack_bordered(dtype, dy, ws + p.dyp, p.dx - p.dyp, gy, Cout, s));
     if (dx) {
         HIPCHK(launch_pack_weights(dtype, w, nullptr, ws + p.wd, k * k, Cin, Cout, 0, 0, p.Cin_pad, p.Cdy,
-                                   conv_filter_layout(k * k, W, p.Cdy * (int)sz, p.Cin_p, N * H * W, 1), s));
+                                   conv_filter_layout(k * k, W, p.Cdy * (int)sz, p.Cin_p, N * H * W, 1, (int)sz), s));
         ConvArgs a{};
         a.x = dyp; a.w = ws + p.wd; a.y = ws + p.dx;
         a.N = N; a.H = H; a.W = W; a.C = p.Cdy; a.M = N * H * W; a.Cout = p.Cin_p; a.ldy = p.Cin_p; a.taps = k * k;

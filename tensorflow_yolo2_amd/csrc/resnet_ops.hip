@@ -386,8 +386,7 @@ __global__ void rn_subsample_kernel(const float* __restrict__ x, float* __restri
 }
 
 // max_pool2d 3x3 stride 2 'SAME' (TF: pad_total = max((Ho-1)*2 + 3 - H, 0), pad_beg = pad_total / 2)
-__global__ void rn_maxpool3_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ dy,
-                                   float* __restrict__ dx, int N, int H, int W, int C) {
+__global__ void rn_maxpool3_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int ph = ((Ho - 1) * 2 + 3 - H > 0 ? (Ho - 1) * 2 + 3 - H : 0) / 2;
     const int pw = ((Wo - 1) * 2 + 3 - W > 0 ? (Wo - 1) * 2 + 3 - W : 0) / 2;
@@ -406,7 +405,41 @@ __global__ void rn_maxpool3_kernel(const float* __restrict__ x, float* __restric
                 if (x[j] > best) { best = x[j]; arg = j; }     // first maximum in row-major window order
             }
         if (y) y[i] = best;
-        if (dx) atomicAdd(dx + arg, dy[i]);                     // windows overlap (stride 2 < 3): dx pre-zeroed
+    }
+}
+// backward as a GATHER (the windows overlap, stride 2 < 3: the scatter form added into dx with float atomics, the one
+// order-dependent sum left in the ResNet swap): every input element looks at the <= 4 windows that contain it, finds
+// each window's first maximum in row-major order as the forward pass does, and takes dy where that is itself; the
+// contributions are added in window order.  No pre-zeroed dx.
+__global__ void rn_maxpool3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                       int N, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int ph = ((Ho - 1) * 2 + 3 - H > 0 ? (Ho - 1) * 2 + 3 - H : 0) / 2;
+    const int pw = ((Wo - 1) * 2 + 3 - W > 0 ? (Wo - 1) * 2 + 3 - W : 0) / 2;
+    const size_t total = (size_t)N * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
+        const float xv = x[i];
+        float g = 0.f;
+        // windows (ho, wo) with ho*2 - ph <= h <= ho*2 - ph + 2
+        const int ho_lo = (h + ph - 2 + 1) >> 1, ho_hi = (h + ph) >> 1;     // ceil((h + ph - 2) / 2) .. floor((h + ph) / 2)
+        const int wo_lo = (w + pw - 2 + 1) >> 1, wo_hi = (w + pw) >> 1;
+        for (int ho = ho_lo < 0 ? 0 : ho_lo; ho <= ho_hi && ho < Ho; ++ho)
+            for (int wo = wo_lo < 0 ? 0 : wo_lo; wo <= wo_hi && wo < Wo; ++wo) {
+                float best = -INFINITY;
+                size_t arg = 0;
+                for (int dh = 0; dh < 3; ++dh)
+                    for (int dw = 0; dw < 3; ++dw) {
+                        const int hh = ho * 2 + dh - ph, ww = wo * 2 + dw - pw;
+                        if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
+                        const size_t j = (((size_t)n * H + hh) * W + ww) * C + c;
+                        if (x[j] > best) { best = x[j]; arg = j; }
+                    }
+                if (arg == i && xv == best) g += dy[(((size_t)n * Ho + ho) * Wo + wo) * C + c];
+            }
+        dx[i] = g;
     }
 }
 
@@ -653,17 +686,14 @@ int y2_subsample(const float* x, float* y, int N, int H, int W, int C, int facto
 int y2_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, void* stream) {
     if (!x || !y) return rfail(Y2_ERR_ARG, "null tensor");
     const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
-    hipLaunchKernelGGL(rn_maxpool3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, nullptr, nullptr,
-                       N, H, W, C);
+    hipLaunchKernelGGL(rn_maxpool3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C);
     RCHK(hipGetLastError());
     return Y2_OK;
 }
 int y2_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
     if (!x || !dy || !dx) return rfail(Y2_ERR_ARG, "null tensor");
-    RCHK(hipMemsetAsync(dx, 0, (size_t)N * H * W * C * sizeof(float), (hipStream_t)stream));
-    const size_t total = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
-    hipLaunchKernelGGL(rn_maxpool3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, nullptr, dy, dx, N, H,
-                       W, C);
+    const size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(rn_maxpool3_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C);
     RCHK(hipGetLastError());
     return Y2_OK;
 }

@@ -475,8 +475,13 @@ static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s, int blocks_target = 
     const int tiles = nIT * nOT;
     if (a.splitk <= 0) {
         // short image rows (big dW, K = a few thousand steps): two blocks per CU measured best;
-        // long rows (tiny dW, K = 10^5 steps): ~3 blocks per CU to cover the HBM stream
-        long sk = a.W <= 26 ? (512 + tiles / 2) / tiles : (768 + tiles - 1) / tiles;
+        // long rows (tiny dW, K = 10^5 steps): ~3 blocks per CU to cover the HBM stream -- but never more blocks than
+        // LDS lets a CU hold at once (round 4: 28x28 128 -> 256 at batch 128 asked for 768 blocks of 64 KB, 1.5
+        // rounds of the chip: 91 us against 82 with 512)
+        int bpc = (int)((160 * 1024) / lds);
+        bpc = bpc > 3 ? 3 : (bpc < 1 ? 1 : bpc);
+        const long long_rows = 256L * bpc;
+        long sk = a.W <= 26 ? (512 + tiles / 2) / tiles : (long_rows + tiles - 1) / tiles;
         if (blocks_target > 0) sk = (blocks_target + tiles / 2) / tiles;
         const long maxsk = (ksteps + 7) / 8;
         if (sk > maxsk) sk = maxsk;
@@ -528,7 +533,17 @@ static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
             // 64 ci x 32 co tiles with 128-pixel K steps measured best at 52 and 104 (3-7 % over 64-pixel
             // steps); 32-channel inputs (208x208): 32 ci x 64 co tiles, 64-pixel steps
             if (a.Cin >= 64) e = wg9r_launch<T, 2, 1, 2, 2>(a, s);
-            else if (a.Cdy >= 64) e = wg9r_launch<T, 1, 2, 2>(a, s);
+            else if (a.Cdy >= 64) {
+                // 128-pixel K steps where the ring of that form still leaves two blocks per CU (112x112 at batch 128:
+                // 90 us against 129; at 208x208 its 96 KB allow one block and the 64-pixel form wins, 160 against 184)
+                typedef Wg9Cfg<T, 1, 2, 2, 2> C2;
+                const int wrows2 = C2::BKP + 2 * (a.W + 1) + 2;
+                const int G2 = (wrows2 + C2::BKP - 1) / C2::BKP;
+                int lg = 7;
+                while ((1 << lg) < C2::BKP * (G2 + 1)) ++lg;
+                const size_t lds2 = ((size_t)C2::ROWX << lg) + 2 * (size_t)C2::YS;
+                e = lds2 <= 80 * 1024 ? wg9r_launch<T, 1, 2, 2, 2>(a, s) : wg9r_launch<T, 1, 2, 2>(a, s);
+            }
             else e = wg9r_launch<T, 1, 1, 2>(a, s);
             if (e != hipErrorOutOfMemory) return e;
             (void)hipGetLastError();

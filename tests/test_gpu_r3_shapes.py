@@ -151,6 +151,8 @@ def test_c2_core_forward_inference_bn_416_bs32_f16():
     assert tuple(out.shape) == (n, 13, 13, 1024) and torch.isfinite(out).all()
     hw = size
     worst = {}
+    folded = []
+    from tensorflow_yolo2_amd import _lib
     for l, (k, ci, co, pool) in enumerate(spec):
         p = params[l]
         Wm = f16_representable(p["W"]).reshape(k * k * ci, co).astype(np.float64)
@@ -168,8 +170,14 @@ def test_c2_core_forward_inference_bn_416_bs32_f16():
         else:
             win = [pts_o]
         first_pooled = (l == 0)
-        if not first_pooled:
-            yl = net.debug_read(l, 1)
+        # round 4: un-pooled inference layers fold scale / shift / leaky into the conv epilogue and store no conv output
+        # (ConvArgs::aff_*): their two halves are checked as one, like the pooled first layer's
+        try:
+            yl = None if first_pooled else net.debug_read(l, 1)
+        except _lib.Y2Error:
+            yl = None
+            folded.append(l)
+        if yl is not None:
             pts = sample_pixels(n, hw, rng, 150)
             ref = gather_patches(xin, pts, hw, k) @ Wm + p["b"].astype(np.float64)
             ys = yl.reshape(-1, co)[torch.as_tensor(pts).cuda()].double().cpu().numpy()
@@ -194,7 +202,17 @@ def test_c2_core_forward_inference_bn_416_bs32_f16():
         del xin, nxt
         hw = Ho
     print("C2 core forward 32 x 416^2 f16, inference BN: per layer (conv, layer output) rel. to max:",
-          {l: "%.1e/%.1e" % v for l, v in worst.items()})
+          {l: "%.1e/%.1e" % v for l, v in worst.items()}, "folded layers:", folded)
+    assert len(folded) >= 10, folded                    # the fold is what runs (12 of the 13 un-pooled layers)
+    # the folded epilogue does the arithmetic of the two-pass form (bn_act_kernel) on the same rounded conv output:
+    # a training binding keeps y and the BN pass (a later backward reads y) -- the same forward, bit for bit
+    del net
+    torch.cuda.empty_cache()
+    two = E.Network(spec, n, size, size, dtype="f16", core_layers=18, training=True)
+    two.load_params(params)
+    out2 = two.forward(x, False, False)
+    two.debug_read(5, 1)                                # its conv outputs exist
+    assert torch.equal(out, out2)
 
 
 # ------------------------------------------------------------------------------------------------ C5

@@ -381,16 +381,21 @@ def test_resnet_backward_is_bit_reproducible():
         m = tf_resnet.ResNet50Yolo(n, size, dtype=dtype, seed=1, **kw)
         x = dev(synthetic.images(n, size, 5))
         lab = dev(synthetic.det_labels(n, size, size // 32, 6))
-        runs = []
-        for _ in range(3):
+        def grads_at(scale):
             m.drop_seed = 10                                    # the same dropout mask every time
             grid = m.forward(x, True, update_moving=False)
             _l, _i, _m, dnet = E.yolo_loss(grid, lab, 20, n, size, size // 32, 2)
             m.grads.zero_()
-            m.backward(dnet * m.loss_scale)                     # 1024 in f16 (tf_resnet.py), 1 in f32
+            m.backward(dnet * scale)
             torch.cuda.synchronize()
-            runs.append(m.grads.clone())
-        assert float(runs[0].abs().max()) > 0 and torch.isfinite(runs[0]).all()
+            return m.grads.clone()
+        # f16 at random initialisation: the default loss scale (1024) overflows some half-precision gradients -- the
+        # trainer's guard skips such steps and halves the scale (tf_resnet.py); take the largest scale that stays finite
+        scale = m.loss_scale
+        while scale > 1.0 and not torch.isfinite(grads_at(scale)).all():
+            scale /= 8.0
+        runs = [grads_at(scale) for _ in range(3)]
+        assert float(runs[0].abs().max()) > 0 and torch.isfinite(runs[0]).all(), (dtype, scale)
         assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), dtype
 
 
