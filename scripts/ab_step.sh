@@ -10,7 +10,7 @@ arms=("$@")
 for round in 1 2 3; do
   for arm in "${arms[@]}"; do
     name="${arm%%=*}"; envs="${arm#*=}"
-    env $envs python bench.py --no-cpu-baseline --no-f32-mode --fed-steps 0 --sustain-steps 200 > gpurun_out/ab/step_${name}_$round.json 2> gpurun_out/ab/step_${name}_$round.err
+    env $envs python bench.py --no-cpu-baseline --no-f32-mode --no-extra-legs --fed-steps 0 --sustain-steps 200 > gpurun_out/ab/step_${name}_$round.json 2> gpurun_out/ab/step_${name}_$round.err
   done
   arms=("${arms[@]:1}" "${arms[0]}")
 done

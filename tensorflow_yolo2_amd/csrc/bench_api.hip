@@ -14,7 +14,7 @@ hipError_t launch_wgrad_variant(int variant, const WgradArgs& a, hipStream_t s);
 hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp);
 static hipError_t run_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp, int* bc) {
     if (variant == 100) return launch_conv(1, a, s, bp);   // the product policy
-    if (variant >= 118 && variant < 140 && a.taps == 9) return launch_conv_haloq_variant(variant, a, s, bp);
+    if (variant >= 118 && variant < 150 && a.taps == 9) return launch_conv_haloq_variant(variant, a, s, bp);
     const bool halo_id = (variant >= 23 && variant < 100) || (variant >= 110 && variant < 118);
     if (halo_id && a.taps == 9) return launch_conv_halo_variant(variant, a, s, bp);
     if (halo_id) variant = 0;

@@ -382,7 +382,10 @@ constexpr int kLinAcc = 48 * 32 + 48 * 48;
 constexpr int kLinThreads = 256;   // measured: 512 threads + register prefetch of the next row pair 297 us, this form 252
 constexpr int kLinItems = 0;     // items (pooled pixel x chunk) per thread held in registers one row pair ahead
 
-template <typename T>
+// GRAM: the Gram matrix is accumulated here (rounds 2-3); false: the forward pass of this step left it in a.gram
+// (conv1_gram_kernel below: the batch-norm statistics of the layer come from it too) -- three of five MFMAs and the
+// tail masks drop out, the partial record shrinks from 15 KB to 6 KB
+template <typename T, bool GRAM>
 __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1WgradLinArgs a, float* part) {
     // also the BN-backward REDUCE of this layer, for free: dA and ysel pass through here anyway, and nothing in this
     // kernel needs the sums (S1 = sum g, S2 = sum g * ysel -> psum[block][2][32]; the finalize runs after it)
@@ -498,17 +501,19 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                     typename Elem<T>::frag fa2 = tr_frag<T>(pa2, pa2 + 4 * XP);
                     // Gram operands: the SAME registers serve as B (k = pixel on both sides); k-padding pixels of
                     // the last group hold the next row's data in the x image: masked out of one side
-                    typename Elem<T>::frag fg1 = fa1, fg2 = fa2;
-                    if (w0 + 16 > a.W) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (w0 + 8 * hh + j >= a.W) { fg1[j] = (T)0.f; fg2[j] = (T)0.f; }
-                    }
                     mma32(acc1, fa1, fb);
                     mma32(acc2, fa2, fb);
-                    mma32(g11, fa1, fg1);
-                    mma32(g12, fa1, fg2);
-                    mma32(g22, fa2, fg2);
+                    if constexpr (GRAM) {
+                        typename Elem<T>::frag fg1 = fa1, fg2 = fa2;
+                        if (w0 + 16 > a.W) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (w0 + 8 * hh + j >= a.W) { fg1[j] = (T)0.f; fg2[j] = (T)0.f; }
+                        }
+                        mma32(g11, fa1, fg1);
+                        mma32(g12, fa1, fg2);
+                        mma32(g22, fa2, fg2);
+                    }
                 } else {
 #pragma unroll
                     for (int k2 = 0; k2 < 8; ++k2) {
@@ -519,9 +524,11 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                         const float a2 = *(const float*)(x_l + (r + 2) * x_bytes + pix * XP + (r32 & 15) * 4);
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
                         acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b, acc2, 0, 0, 0);
-                        g11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1 * vm, g11, 0, 0, 0);
-                        g12 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a2 * vm, g12, 0, 0, 0);
-                        g22 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, a2 * vm, g22, 0, 0, 0);
+                        if constexpr (GRAM) {
+                            g11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1 * vm, g11, 0, 0, 0);
+                            g12 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a2 * vm, g12, 0, 0, 0);
+                            g22 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, a2 * vm, g22, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -529,7 +536,8 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
     }
     // ---- the waves through LDS, four at a time (fixed order) -> this block's partial: Xdz [48][32] then G [48][48]
     float* red = (float*)smem;   // [4][kLinAcc] (G's lower-left block is filled by symmetry in the finalize)
-    constexpr int PER = (kLinAcc + NTH - 1) / NTH;
+    constexpr int kAcc = GRAM ? kLinAcc : 48 * 32;      // entries of this block's record that carry sums
+    constexpr int PER = (kAcc + NTH - 1) / NTH;
     float tot[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) tot[k] = 0.f;
@@ -542,17 +550,19 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                 const int r = acc_row(q, hh);
                 o[r * 32 + r32] = acc1[q];
                 if (r < 16) o[(32 + r) * 32 + r32] = acc2[q];
-                float* g = o + 48 * 32;
-                g[r * 48 + r32] = g11[q];
-                if (r32 < 16) g[r * 48 + 32 + r32] = g12[q];
-                if (r < 16 && r32 < 16) g[(32 + r) * 48 + 32 + r32] = g22[q];
+                if constexpr (GRAM) {
+                    float* g = o + 48 * 32;
+                    g[r * 48 + r32] = g11[q];
+                    if (r32 < 16) g[r * 48 + 32 + r32] = g12[q];
+                    if (r < 16 && r32 < 16) g[(32 + r) * 48 + 32 + r32] = g22[q];
+                }
             }
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = tid + k * NTH;
-            if (i < kLinAcc) {
+            if (i < kAcc) {
                 bool used = true;
                 if (i >= 48 * 32) {
                     const int j = i - 48 * 32, r = j / 48, c = j % 48;
@@ -565,7 +575,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         const int i = tid + k * NTH;
-        if (i < kLinAcc) part[(size_t)blockIdx.x * kLinAcc + i] = tot[k];
+        if (i < kAcc) part[(size_t)blockIdx.x * kLinAcc + i] = tot[k];
     }
     // ---- BN-backward partial sums of this block: threads with the same chunk (tid % CPP) are CPP apart
     __syncthreads();
@@ -588,9 +598,10 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
 // block partials -> kLinMid slice sums (fixed order; a 2-D grid so that 512 partial records of 15 KB do not queue
 // behind one another in 15 blocks); the finalize adds the kLinMid slices
 constexpr int kLinMid = 16;
-__global__ __launch_bounds__(256) void conv1_lin_reduce_kernel(const float* part, int nblocks, float* mid) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kLinAcc) return;
+__global__ __launch_bounds__(256) void conv1_lin_reduce_kernel(const float* part, int nblocks, float* mid, int first,
+                                                               int count) {
+    const int i = first + blockIdx.x * 256 + threadIdx.x;      // entries [first, first + count) of the kLinAcc-float records
+    if (i >= first + count) return;
     const int per = (nblocks + kLinMid - 1) / kLinMid;
     const int b0 = blockIdx.y * per;
     int b1 = b0 + per;
@@ -617,7 +628,8 @@ __global__ __launch_bounds__(1024) void conv1_dw_finalize_kernel(Conv1DwFinalize
     };
     for (int i = tid; i < 48 * 48; i += 1024) {
         const int r = i / 48, c = i % 48;
-        G[r][c] = (r >= 32 && c < 32) ? total(48 * 32 + c * 48 + r) : total(48 * 32 + i);   // symmetry
+        if (a.gram) G[r][c] = a.gram[i];                      // complete [48][48] totals of the forward pass
+        else G[r][c] = (r >= 32 && c < 32) ? total(48 * 32 + c * 48 + r) : total(48 * 32 + i);   // symmetry
     }
     for (int i = tid; i < 48 * 32; i += 1024) {
         const int r = i >> 5, co = i & 31;
@@ -639,6 +651,218 @@ __global__ __launch_bounds__(1024) void conv1_dw_finalize_kernel(Conv1DwFinalize
     a.dW[tc * 32 + co] = (a.scale[co] * xdz - ka * x1 - kb * xy) * a.inv_grad_scale;
 }
 
+// ---------------------------------------------------------------------------
+// Round 4: the Gram matrix in the FORWARD pass.  G depends on the input alone, and with y = W^T p + b per pixel (p = the
+// 27-element input patch, its centre-tap channel 3 = 1) the batch-norm statistics of the layer follow from it:
+//     sum_p y = W^T s + M b,   sum_p (y - mean)^2 = W^T (G - s s^T / M) W,   s = G[ones][.],  M = G[ones][ones]
+// so the statistics-only convolution pass of the pooled first layer (conv1_stats_kernel: 97 us at 416x416x64, VALU- and
+// latency-bound on 7 vector operations per output element) becomes this MFMA-only sweep of the input (8 B per pixel),
+// and the backward pass (conv1_wgrad_lin_kernel<.., false>) no longer builds G.  The statistics are those of the
+// UN-ROUNDED conv output (the stored-value statistics of the other layers differ from them by the half-precision
+// rounding noise, ~2^-12 relative and unbiased); the centred form is evaluated in double.
+// ---------------------------------------------------------------------------
+constexpr int kGram = 48 * 48;
+constexpr int kGramMaxBlocks = 768;
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv1_gram_kernel(const void* x4, int N, int H, int W, float* part) {
+    constexpr int SZ = sizeof(T), XP = 4 * SZ;
+    constexpr int NTH = 256, NW = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Wp = (W + 15) & ~15;
+    const int x_bytes = ((Wp + 4) * XP + 15) & ~15;
+    const int x_chunks = x_bytes / 16;
+    char* x_l = smem;                    // [2 buffers][4 rows][x_bytes]
+    const int Ho = H / 2;
+    const int prs = N * Ho;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+    f32x16 g11, g12, g22;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g11[q] = g12[q] = g22[q] = 0.f;
+    auto stage = [&](int pr, int buf) {
+        const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho;
+        const char* xrow = (const char*)x4 + (bpix(n, h0, 0, H, W) - (size_t)(W + 2)) * XP;
+        const size_t xpitch = (size_t)(W + 1) * XP;
+        char* dst = x_l + buf * 4 * x_bytes;
+        for (int kh = 0; kh < 4; ++kh)
+            for (int i0 = w * 64; i0 < x_chunks; i0 += NTH) {
+                const int i = i0 + lane;
+                if (i < x_chunks) glds16(xrow + kh * xpitch + (size_t)i * 16, dst + kh * x_bytes + i0 * 16);
+            }
+    };
+    int buf = 0;
+    if ((int)blockIdx.x < prs) stage(blockIdx.x, 0);
+    for (int pr = blockIdx.x; pr < prs; pr += gridDim.x, buf ^= 1) {
+        __syncthreads();   // this row pair's rows have landed (vmcnt(0) before the barrier); the other buffer is free
+        if (pr + (int)gridDim.x < prs) stage(pr + gridDim.x, buf ^ 1);
+        const char* xb = x_l + buf * 4 * x_bytes;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            for (int s = w; s * 16 < W; s += NW) {
+                const int w0 = s * 16;
+                if constexpr (SZ == 2) {
+                    const int pix = w0 + 8 * hh + qq;
+                    const char* pa1 = xb + (r + g1) * x_bytes + (pix + pp) * XP;
+                    typename Elem<T>::frag fa1 = tr_frag<T>(pa1, pa1 + 4 * XP);
+                    const char* pa2 = xb + (r + 2) * x_bytes + (pix + pp) * XP;
+                    typename Elem<T>::frag fa2 = tr_frag<T>(pa2, pa2 + 4 * XP);
+                    // the SAME registers serve as B (k = pixel on both sides); k-padding pixels of the last group hold
+                    // the neighbouring data of the x image: masked out of one side
+                    typename Elem<T>::frag fg1 = fa1, fg2 = fa2;
+                    if (w0 + 16 > W) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (w0 + 8 * hh + j >= W) { fg1[j] = (T)0.f; fg2[j] = (T)0.f; }
+                    }
+                    mma32(g11, fa1, fg1);
+                    mma32(g12, fa1, fg2);
+                    mma32(g22, fa2, fg2);
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2) {
+                        const int pix = w0 + 2 * k2 + hh;
+                        const float vm = pix < W ? 1.f : 0.f;
+                        const float a1 = *(const float*)(xb + (r + (r32 >> 4)) * x_bytes + pix * XP + (r32 & 15) * 4);
+                        const float a2 = *(const float*)(xb + (r + 2) * x_bytes + pix * XP + (r32 & 15) * 4);
+                        g11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1 * vm, g11, 0, 0, 0);
+                        g12 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a2 * vm, g12, 0, 0, 0);
+                        g22 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, a2 * vm, g22, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- the four waves through LDS (fixed order) -> this block's partial G [48][48] (lower-left block by symmetry)
+    __syncthreads();
+    float* red = (float*)smem;   // [4][kGram]
+    {
+        float* g = red + w * kGram;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = acc_row(q, hh);
+            g[r * 48 + r32] = g11[q];
+            if (r32 < 16) g[r * 48 + 32 + r32] = g12[q];
+            if (r < 16 && r32 < 16) g[(32 + r) * 48 + 32 + r32] = g22[q];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kGram; i += NTH) {
+        const int r = i / 48, c = i % 48;
+        const int j = (r >= 32 && c < 32) ? c * 48 + r : i;
+        part[(size_t)blockIdx.x * kGram + i] = (red[j] + red[kGram + j]) + (red[2 * kGram + j] + red[3 * kGram + j]);
+    }
+}
+
+// slices of the block partials (fixed order), then one block: totals in double, batch-norm statistics of the layer
+__global__ __launch_bounds__(256) void conv1_gram_reduce_kernel(const float* part, int nblocks, float* mid) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kGram) return;
+    const int per = (nblocks + kLinMid - 1) / kLinMid;
+    const int b0 = blockIdx.y * per;
+    int b1 = b0 + per;
+    if (b1 > nblocks) b1 = nblocks;
+    float v4[4] = {0.f, 0.f, 0.f, 0.f};
+    int b = b0;
+    for (; b + 3 < b1; b += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v4[u] += part[(size_t)(b + u) * kGram + i];
+    for (; b < b1; ++b) v4[0] += part[(size_t)b * kGram + i];
+    mid[(size_t)blockIdx.y * kGram + i] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void conv1_gram_stats_kernel(Conv1GramStatsArgs a) {
+    __shared__ double G[48][49];
+    __shared__ float Wq[48][32];
+    __shared__ double t[48][33];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kGram; i += 1024) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < kLinMid; ++k) v += (double)a.mid[(size_t)k * kGram + i];
+        G[i / 48][i % 48] = v;
+        a.gram[i] = (float)v;                               // the backward pass of this step reads the totals
+    }
+    for (int i = tid; i < 48 * 32; i += 1024) {
+        const int r = i >> 5, co = i & 31;
+        const int kh = r >> 4, e = r & 15, kw = e >> 2, c = e & 3;
+        // the convolution multiplies the filter as PACKED (rounded to T): the statistics must see the same values
+        Wq[r][co] = (kw < 3 && c < 3) ? Elem<T>::to_f32(Elem<T>::from_f32(a.W[((kh * 3 + kw) * 3 + c) * 32 + co])) : 0.f;
+    }
+    __syncthreads();
+    constexpr int kOnes = 1 * 16 + 1 * 4 + 3;               // centre tap, channel 3 (= 1 inside the image)
+    const double M = G[kOnes][kOnes];
+    for (int i = tid; i < 48 * 32; i += 1024) {
+        const int r = i >> 5, co = i & 31;
+        const double sr = G[kOnes][r];
+        double v = 0.0;
+        for (int k = 0; k < 48; ++k) v += (G[r][k] - sr * G[kOnes][k] / M) * (double)Wq[k][co];
+        t[r][co] = v * (double)Wq[r][co];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int c = tid;
+        double m2 = 0.0, s = 0.0;
+        for (int r = 0; r < 48; ++r) {
+            m2 += t[r][c];
+            s += G[kOnes][r] * (double)Wq[r][c];
+        }
+        if (m2 < 0) m2 = 0;
+        const double mean = (double)a.bias[c] + s / M;
+        // the tail of bn_finalize_kernel (bn.hip), expression for expression
+        const float var = (float)(M > 0 ? m2 / M : 0.0);
+        const float meanf = (float)mean;
+        const float inv = 1.0f / sqrtf(var + a.eps);
+        const float sc = a.gamma[c] * inv;
+        a.scale[c] = sc;
+        a.shift[c] = a.beta[c] - meanf * sc;
+        a.mean[c] = meanf;
+        a.invstd[c] = inv;
+        float vu = var;
+        if (a.bessel && M > 1.0) vu = (float)(m2 / (M - 1.0));
+        if (a.var) a.var[c] = vu;
+        if (a.update_moving) {
+            const float dec = 1.0f - a.momentum;
+            a.moving_mean[c] -= (a.moving_mean[c] - meanf) * dec;
+            a.moving_var[c] -= (a.moving_var[c] - vu) * dec;
+        }
+    }
+}
+
+size_t conv1_gram_scratch_floats() { return (size_t)kGram * (1 + kLinMid + kGramMaxBlocks); }
+bool conv1_gram_ok(int H, int W, int elem_size) {
+    const int Wp = (W + 15) & ~15;
+    const size_t lds = 2 * 4 * (size_t)((((Wp + 4) * 4 * elem_size) + 15) & ~15);
+    return (H % 2) == 0 && lds <= 64 * 1024;
+}
+template <typename T>
+static hipError_t c1gram_T(const Conv1GramStatsArgs& a, hipStream_t s) {
+    const int Wp = (a.Wd + 15) & ~15;
+    size_t lds = 2 * 4 * (size_t)((((Wp + 4) * 4 * sizeof(T)) + 15) & ~15);
+    const size_t red = 4 * (size_t)kGram * sizeof(float);
+    if (lds < red) lds = red;
+    auto kern = conv1_gram_kernel<T>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const int prs = a.N * (a.H / 2);
+    const int nb = prs < kGramMaxBlocks ? prs : kGramMaxBlocks;
+    float* part = a.mid + (size_t)kLinMid * kGram;
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, a.x4, a.N, a.H, a.Wd, part);
+    hipLaunchKernelGGL(conv1_gram_reduce_kernel, dim3((kGram + 255) / 256, kLinMid), dim3(256), 0, s, part, nb, a.mid);
+    hipLaunchKernelGGL(conv1_gram_stats_kernel<T>, dim3(1), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_conv1_gram_stats(int dtype, const Conv1GramStatsArgs& a, hipStream_t s) {
+    switch (dtype) {
+        case 0: return c1gram_T<float>(a, s);
+        case 1: return c1gram_T<half_t>(a, s);
+        case 2: return c1gram_T<bf16_t>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <typename T>
 static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
     constexpr int SZ = sizeof(T);
@@ -649,15 +873,16 @@ static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
     if (red < red2) red = red2;
     if (lds < red) lds = red;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    auto kern = conv1_wgrad_lin_kernel<T>;
+    auto kern = a.gram ? conv1_wgrad_lin_kernel<T, false> : conv1_wgrad_lin_kernel<T, true>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int prs = a.N * (a.H / 2);
     const int nb = prs < 512 ? prs : 512;
     float* part = a.acc + (size_t)kLinMid * kLinAcc;        // [nb][kLinAcc] behind the slice sums
     if (a.nblocks_out) *a.nblocks_out = nb;
+    const int count = a.gram ? 48 * 32 : kLinAcc;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(kLinThreads), lds, s, a, part);
-    hipLaunchKernelGGL(conv1_lin_reduce_kernel, dim3((kLinAcc + 255) / 256, kLinMid), dim3(256), 0, s, part, nb, a.acc);
+    hipLaunchKernelGGL(conv1_lin_reduce_kernel, dim3((count + 255) / 256, kLinMid), dim3(256), 0, s, part, nb, a.acc, 0, count);
     return hipGetLastError();
 }
 

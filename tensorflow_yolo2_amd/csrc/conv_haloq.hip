@@ -713,6 +713,14 @@ hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t
         HQ(137, 8, 1, 2, 1, 128)      // 512 x 32
         HQ(138, 8, 1, 2, 1, 64)
         HQ(139, 4, 2, 4, 2, 64)       // 512 x 128, 64-byte chunks
+        // round 4: 64-cout layers on the long rows (104x104 128 -> 64 and the 64-cout dgrads): one wave column, every
+        // pixel fragment feeds TWO MFMAs (TC = 2) instead of one -- half the LDS reads per MFMA of <4,2,4,1>
+        HQ(140, 8, 1, 2, 2, 128)      // 512 x 64, 8 waves of 64 px x 64 co
+        HQ(141, 8, 1, 2, 2, 64)
+        HQ(142, 8, 1, 4, 2, 64)       // 1024 x 64, 8 waves of 128 px x 64 co
+        HQ(143, 4, 1, 4, 2, 128)      // 512 x 64, 4 waves of 128 px x 64 co
+        HQ(144, 4, 1, 4, 2, 64)
+        HQ(145, 8, 1, 3, 2, 128)      // 768 x 64
     }
 #undef HQ
     return hipErrorInvalidValue;

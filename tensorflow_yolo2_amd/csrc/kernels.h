@@ -157,6 +157,7 @@ struct Conv1WgradLinArgs {
     const void* ysel;           // [Mout][32] of T
     const unsigned short* idx;  // [Mout][chunks]
     const float *scale, *shift;
+    const float* gram = nullptr; // [48][48] totals of the forward pass's Gram matrix (launch_conv1_gram_stats): G is not rebuilt here
     float* acc;                 // 16 slice sums of [48*32 + 48*48], followed by the per-block partials (conv1_wgrad_lin_scratch_floats)
     float* psum;                // out: BN-backward partial sums [blocks][2][32] (S1, S2) -- the reduce pass rides here
     int* nblocks_out;           // host: number of partial records written
@@ -170,7 +171,27 @@ struct Conv1DwFinalizeArgs {
     const float* coef;          // [2][32] ka, kb
     float* dW;                  // out [3][3][3][32]
     float inv_grad_scale;
+    const float* gram = nullptr; // [48][48] Gram totals of the forward pass (else: the G part of acc)
 };
+// Forward pass of the pooled first layer, training: Gram matrix of the input patches -> batch-norm statistics of the
+// layer (conv1_wgrad.hip: replaces the statistics-only convolution pass + bn_finalize) and the totals the backward
+// pass reuses.  mid: conv1_gram_scratch_floats() floats = [1 + 16 + 768][48*48]: gram totals, slices, block partials.
+struct Conv1GramStatsArgs {
+    const void* x4;             // [N][H+2][W+2][4], channel 3 = 1 inside the image
+    int N, H, Wd;
+    const float* W;             // fp32 HWIO [3][3][3][32]
+    const float* bias;
+    const float *gamma, *beta;
+    float *moving_mean, *moving_var;
+    float *scale, *shift, *mean, *invstd, *var;
+    float eps, momentum;
+    int update_moving, bessel;
+    float* mid;                 // slices + partials (scratch)
+    float* gram;                // out: [48][48] totals
+};
+bool conv1_gram_ok(int H, int W, int elem_size);
+size_t conv1_gram_scratch_floats();
+hipError_t launch_conv1_gram_stats(int dtype, const Conv1GramStatsArgs& a, hipStream_t s);
 bool conv1_wgrad_lin_ok(int H, int W, int pool, int ldy, int elem_size);
 size_t conv1_wgrad_lin_scratch_floats();   // acc: totals + per-block partials
 hipError_t launch_conv1_wgrad_lin(int dtype, const Conv1WgradLinArgs& a, hipStream_t s);

@@ -111,6 +111,8 @@ struct y2_ctx {
     bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
     size_t o_infertab = 0;      // BnInferLayer per layer (one prepare launch for all inference-mode layers)
     size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0, o_slab = 0;
+    size_t o_gram = 0;          // first layer: Gram matrix of the input patches [48][48] + its slices / block partials
+    bool gram_valid = false;    // the last forward computed it (training mode, pooled first layer): backward reuses it
     size_t slab_floats = 0;     // split-K partial tiles of the weight gradients (WgradArgs::slab)
     int n_chkranges = 0, n_smallranges = 0, opt_tile_blocks = 0;
     // both range tables list the layers above the first one first: the optimizer step fused into the backward pass
@@ -229,6 +231,7 @@ static void plan(y2_ctx* c) {
         y.ysel = (y.pool && (!y.first3 || lin1)) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
         y.idx0 = lin1 ? take((size_t)c->N * y.Ho * y.Wo * (y.ldy * sz / 16) * sizeof(unsigned short) + 256) : 0;
         if (lin1) c->o_lin = take(conv1_wgrad_lin_scratch_floats() * sizeof(float));
+        if (lin1 && conv1_gram_ok(y.H, y.W, (int)sz)) c->o_gram = take(conv1_gram_scratch_floats() * sizeof(float));
     }
     // BN-backward partial sums [P][2][ldy]: P <= 2048 from the reduce kernel, or one record per 128+ pixel tile
     // of the dgrad above when the reduce is fused into that dgrad's epilogue
@@ -624,7 +627,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
         float* stat = (float*)(c->ws + y.stat);
         float *scale = stat, *shift = stat + y.ldy, *mean = stat + 2 * y.ldy, *invstd = stat + 3 * y.ldy;
         int P = 0;
-        bool folded = false;
+        bool folded = false, gram1 = false;
         // pooled first layer: statistics-only conv, then conv again fused with BN + leaky + pool
         const bool pool1 = y.first3 && l + 1 < nl && y.ldy == 32 && conv1_pool_ok(y.H, y.W, y.pool, y.cout);
         if (y.first3) {
@@ -641,7 +644,11 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             a.nblocks = nb > 1024 ? 1024 : nb;      // = statistics records (the plan reserves 2048 rows; 1024 vs 2048: -4 us)
             P = a.nblocks;
             a.stats_only = pool1 ? 1 : 0;
-            if (!pool1 || training) { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
+            // round 4: the statistics of the pooled first layer come from the Gram matrix of the input patches (below)
+            static const bool no_gram = getenv("Y2_NO_CONV1_GRAM") != nullptr;
+            gram1 = pool1 && training && c->lin1() && c->o_gram != 0 && !no_gram;
+            if ((!pool1 || training) && !gram1) { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
+            c->gram_valid = gram1;
         } else {
             if (l == 0) HIPCHK(launch_pack_act(c->dtype, images, xin, c->N, y.H, y.W, y.cin, y.cin_s, s));
             ConvArgs a{};
@@ -683,7 +690,16 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             t.C = y.cout; t.ldy = y.ldy; t.out_f32 = 0;
             fin_fused = bn_fin_act_ok(t, f);
         }
-        if (training && !fin_fused) HIPCHK(launch_bn_finalize(f, s));     // (inference: prepared for every layer above)
+        if (gram1) {
+            Conv1GramStatsArgs q{};
+            q.x4 = xin; q.N = c->N; q.H = y.H; q.Wd = y.W;
+            q.W = c->params + y.pW; q.bias = c->params + y.pb; q.gamma = f.gamma; q.beta = f.beta;
+            q.moving_mean = f.moving_mean; q.moving_var = f.moving_var;
+            q.scale = scale; q.shift = shift; q.mean = mean; q.invstd = invstd; q.var = f.var;
+            q.eps = f.eps; q.momentum = f.momentum; q.update_moving = f.update_moving; q.bessel = f.bessel;
+            q.gram = (float*)(c->ws + c->o_gram); q.mid = q.gram + 48 * 48;
+            HIPCHK(launch_conv1_gram_stats(c->dtype, q, s));
+        } else if (training && !fin_fused) HIPCHK(launch_bn_finalize(f, s));     // (inference: prepared for every layer above)
         if (pool1) {
             Conv1PoolArgs q{};
             q.x4 = xin; q.w = c->ws + y.wf; q.y = c->ws + y.y; q.bias = c->params + y.pb;
@@ -821,6 +837,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 g.x4 = c->ws + y.xin + c->in_geom(l).base_off(sz); g.dA = b.dA; g.ysel = c->ws + y.ysel;
                 g.idx = (const unsigned short*)(c->ws + y.idx0);
                 g.scale = b.scale; g.shift = b.shift; g.acc = (float*)(c->ws + c->o_lin); g.psum = psum;
+                if (c->gram_valid) g.gram = (const float*)(c->ws + c->o_gram);
                 int nbl = 0;
                 g.nblocks_out = &nbl;
                 g.N = c->N; g.H = y.H; g.W = y.W;
@@ -856,6 +873,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             Conv1DwFinalizeArgs f{};
             f.acc = (float*)(c->ws + c->o_lin); f.W = c->params + y.pW; f.bias = c->params + y.pb; f.scale = b.scale;
             f.coef = b.coef; f.dW = c->grads + y.pW; f.inv_grad_scale = inv_gs;
+            if (c->gram_valid) f.gram = (const float*)(c->ws + c->o_gram);
             PROF(CAT_CONV1_WGRAD);
             HIPCHK(launch_conv1_dw_finalize(f, s));
         } else if (fused1) {

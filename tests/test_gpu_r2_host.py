@@ -380,7 +380,8 @@ def test_ab_switches_select_equivalent_paths(tmp_path):
     assert tuple(base["ctrl"]) == (0, 1, 0)
     switches = [{"Y2_NO_CONV_RF": "1"}, {"Y2_NO_WGRAD_SLAB": "1"}, {"Y2_XCD_CONV": "0", "Y2_XCD_WGRAD": "0"},
                 {"Y2_NO_BN_FIN_FUSE": "1"}, {"Y2_NO_FUSED_TRAIN_OP": "1"}, {"Y2_NO_BNBWD_FUSE": "1"},
-                {"Y2_NO_WGRAD_OVERLAP": "1"}, {"Y2_HALO_COMPACT": "1"}, {"Y2_HALOQ_1X1": "1"}, {"Y2_NO_HALOQ_52": "1"}]
+                {"Y2_NO_WGRAD_OVERLAP": "1"}, {"Y2_HALO_COMPACT": "1"}, {"Y2_HALOQ_1X1": "1"}, {"Y2_NO_HALOQ_52": "1"},
+                {"Y2_NO_CONV1_GRAM": "1"}, {"Y2_LEGACY_TILES": "1"}]      # round 4: Gram-matrix statistics, tile cost model
     for sw in switches:
         r = run(sw, "_".join(sw))
         assert tuple(r["ctrl"]) == (0, 1, 0), sw

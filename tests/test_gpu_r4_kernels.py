@@ -1,0 +1,113 @@
+"""GPU tests (-m gpu) of round 4's kernels: the first layer's batch-norm statistics from the Gram matrix of the input
+patches (csrc/conv1_wgrad.hip conv1_gram_kernel / conv1_gram_stats_kernel), the tile choice of conv_haloq, the
+inference batch norm folded into the conv epilogue at odd geometries."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_ref as R
+
+pytestmark = pytest.mark.gpu
+
+from _shapes import TOL, f16_representable, rel_to_max     # noqa: E402
+import _obs                                                 # noqa: E402
+
+
+def _conv1_moments_float64(x, W, b, chunk=8):
+    """per-channel mean and biased variance of y = conv3x3_same(x, W) + b over all pixels, float64 (torch CPU)"""
+    import torch.nn.functional as F
+    wt = torch.as_tensor(W).double().permute(3, 2, 0, 1)
+    s1 = torch.zeros(W.shape[3], dtype=torch.float64)
+    s2 = torch.zeros(W.shape[3], dtype=torch.float64)
+    n = 0
+    for i in range(0, x.shape[0], chunk):
+        xi = torch.as_tensor(x[i:i + chunk]).double().permute(0, 3, 1, 2)
+        y = F.conv2d(xi, wt, torch.as_tensor(b).double(), padding=1)
+        s1 += y.sum((0, 2, 3))
+        s2 += (y * y).sum((0, 2, 3))
+        n += y.shape[0] * y.shape[2] * y.shape[3]
+    mean = s1 / n
+    return mean.numpy(), (s2 / n - mean * mean).numpy()
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f32"])
+@pytest.mark.parametrize("N,hw,kind", [(4, 64, "uniform"), (3, 50, "image"), (64, 416, "image"), (128, 224, "uniform")])
+def test_first_layer_statistics_from_the_gram_matrix(N, hw, kind, dtype):
+    """conv_bn_layer of the 3 -> 32 layer (darknet.py:150, 39-46) in training mode: the batch mean / variance the device
+    normalises with -- read back through the moving averages of ONE update from (0, 1): moving = 0.99 moving + 0.01 batch
+    -- against float64 moments of the exact conv output.  `image`: a smooth, strongly correlated input with a non-zero
+    mean (neighbouring pixels nearly equal, as in photographs): the case where sum y^2 - (sum y)^2 / M cancels and the
+    centred Gram form is needed.  Gate 1e-4 of the largest moment (observed ~1e-6; the round-3 statistics-only conv pass
+    it replaces is held to the same gate through Y2_NO_CONV1_GRAM in test_ab_switches_select_equivalent_paths)."""
+    if N * hw * hw > 3e6 and dtype != "f16":
+        pytest.skip("the large geometries run in the benchmarked type only")
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(N + hw)
+    spec = [(3, 3, 32, 1), (1, 32, 32, 0)]
+    if kind == "uniform":
+        x = rng.uniform(-1, 1, (N, hw, hw, 3))
+    else:
+        base = rng.uniform(-0.2, 0.9, (N, 1, 1, 3))
+        gy = np.linspace(0, 1, hw)[None, :, None, None]
+        gx = np.linspace(0, 1, hw)[None, None, :, None]
+        x = np.clip(base + 0.3 * np.sin(3 * gy + base) * np.cos(2 * gx) + 0.02 * rng.standard_normal((N, hw, hw, 3)), -1, 1)
+    x = f16_representable(x.astype(np.float32)) if dtype != "bf16" else \
+        torch.as_tensor(x.astype(np.float32)).bfloat16().float().numpy()
+    params = R.init_params(spec, seed=6)
+    q = (lambda a: f16_representable(a)) if dtype != "bf16" else (lambda a: torch.as_tensor(a).bfloat16().float().numpy())
+    params[0]["W"] = q(params[0]["W"])
+    params[0]["b"] = rng.uniform(-0.5, 0.5, 32).astype(np.float32)
+    net = E.Network(spec, N, hw, hw, dtype=dtype, training=True, grad_scale=1.0)
+    net.load_params(params)
+    out = net.forward(torch.as_tensor(x).cuda(), True, True, update_moving=True)
+    assert torch.isfinite(out).all()
+    st = net.export_params()[0]
+    mean_dev = st["moving_mean"].astype(np.float64) / 0.01
+    var_dev = (st["moving_var"].astype(np.float64) - 0.99) / 0.01
+    mean, var = _conv1_moments_float64(x, params[0]["W"], params[0]["b"])
+    e_m = np.abs(mean_dev - mean).max() / max(np.abs(mean).max(), np.sqrt(var.max()))
+    # the read-back itself costs ~6e-6 of the variance (0.99 + 0.01 var in float32)
+    e_v = np.abs(var_dev - var).max() / var.max()
+    print("conv1 statistics %s N=%d %dx%d %s: mean %.2e  var %.2e  (var range %.3g .. %.3g)" %
+          (kind, N, hw, hw, dtype, e_m, e_v, var.min(), var.max()))
+    _obs.gate("conv1 gram statistics mean %s %s" % (kind, dtype), e_m, 1e-4)
+    _obs.gate("conv1 gram statistics var %s %s" % (kind, dtype), e_v, 1e-4)
+
+
+@pytest.mark.parametrize("N,hw,cin,cout,k", [(128, 14, 256, 512, 3), (128, 7, 512, 1024, 3), (128, 7, 1024, 512, 3),
+                                             (128, 28, 256, 128, 3), (128, 14, 512, 256, 3), (24, 20, 256, 512, 3),
+                                             (48, 10, 512, 1024, 3)])
+def test_tile_choice_shapes_in_network_inference_fold(N, hw, cin, cout, k):
+    """The tiles the cost model of conv_haloq picks away from the 416x416 batch-64 defaults (512 x 128, 256 x 128,
+    512 x 64, 256 x 64: configs[2] at batch 128, the 320 / 608 maps of configs[4]) as LAYERS: a two-layer stack in
+    inference mode folds scale / shift / leaky into the first layer's epilogue (bordered output addressing for every
+    tile shape); the same stack on a training binding runs conv -> y -> bn_act: the same bits.  The per-shape float64
+    gates of these tiles are in test_gpu_r3_shapes.py (C3) and test_gpu_resnet.py."""
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(hw * 7 + cin)
+    spec = [(k, cin, cout, 0), (1, cout, 32, 0)]
+    x = torch.as_tensor(f16_representable(rng.uniform(-1, 1, (N, hw, hw, cin)).astype(np.float32))).cuda()
+    params = R.init_params(spec, seed=2)
+    for p in params:
+        p["moving_mean"] = rng.uniform(-0.5, 0.5, p["moving_mean"].shape).astype(np.float32)
+        p["moving_var"] = rng.uniform(0.5, 2.0, p["moving_var"].shape).astype(np.float32)
+        p["gamma"] = rng.uniform(0.5, 1.5, p["gamma"].shape).astype(np.float32)
+        p["beta"] = rng.uniform(-0.3, 0.3, p["beta"].shape).astype(np.float32)
+    outs = []
+    for training in (False, True):
+        net = E.Network(spec, N, hw, hw, dtype="f16", core_layers=2, training=training)
+        net.load_params(params)
+        outs.append((net.forward(x, False, False).clone(), net.debug_read(1, 0).clone()))
+        del net
+    assert torch.equal(outs[0][1], outs[1][1])          # the first layer's activation as the second layer reads it
+    assert torch.equal(outs[0][0], outs[1][0])
+    # and against float64 on the stored input: conv -> affine -> leaky at every pixel of a few images
+    W = f16_representable(params[0]["W"]).reshape(k * k * cin, cout).astype(np.float64)
+    sc = params[0]["gamma"].astype(np.float64) / np.sqrt(params[0]["moving_var"].astype(np.float64) + 1e-3)
+    sh = params[0]["beta"].astype(np.float64) - params[0]["moving_mean"].astype(np.float64) * sc
+    from _shapes import gather_patches, sample_pixels
+    pts = sample_pixels(N, hw, rng, 300)
+    z = (gather_patches(x, pts, hw, k) @ W + params[0]["b"].astype(np.float64)) * sc + sh
+    ref = np.maximum(0.1 * z, z)
+    got = outs[0][1].reshape(-1, cout)[torch.as_tensor(pts).cuda()].double().cpu().numpy()
+    _obs.gate("folded inference layer %dx%d %d->%d N=%d" % (hw, hw, cin, cout, N), rel_to_max(got, ref), TOL)
