@@ -413,8 +413,10 @@ bool conv_affine_ok(int dtype, const ConvArgs& a) {
     static const bool off = getenv("Y2_NO_INFER_FOLD") != nullptr;
     if (off || a.bw_psum || a.part_mean || a.is_dgrad) return false;
     const int rowb = a.C * (int)dtype_size(dtype);
-    if (dtype != 0 && (conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M) ||
-                       conv_rfn_config(a.taps, a.W, rowb, a.Cout, a.M, 0))) return false;
+    // conv_rf.hip: the 128-cout forward form stores wave-private row segments and folds too; the 208-wide
+    // 32 <-> 64 forms (pooled layers in Darknet-19) keep the two-pass form
+    if (dtype != 0 && conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M)) return false;
+    if (dtype != 0 && conv_rfn_config(a.taps, a.W, rowb, a.Cout, a.M, 0) && (a.ldy % 8) != 0) return false;
     return a.M > 0 && (unsigned)a.M < 0x7FFFFFFFu;
 }
 

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 
         // ---- the wave's 32-cout columns of its rows into the workgroup's patch
         int cntw = 0;
-        int pj[TP];
+        int pj[TP], pbj[TP];
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const bool valid = pcol[j] >= 1 && prow_[j] >= 1 && pimg[j] < a.N;
@@ -574,6 +574,9 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
             const int row = (wp * TP + j) * 32 + r32;
             if (!WPRIV && wn == 0 && hh == 0) ptab[row] = p;
             pj[j] = p;
+            // bordered position of this pixel in a tensor of the same H x W (the consumer's input): the folded
+            // inference batch norm stores there (ConvArgs::aff_out)
+            pbj[j] = (pimg[j] * gm.rows_img + prow_[j]) * pitch + pcol[j];
             cntw += __popcll(__ballot(valid && hh == 0));
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -626,6 +629,22 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
                 const int cch = n0 + ch * 8;
                 const bool st = pr >= 0 && cch < a.ldy;
                 char* dstp = st ? (char*)a.y + ((size_t)pr * a.ldy + cch) * SZ : ydump + (ch % (a.ldy / 8)) * 16;
+                if (a.aff_out) {
+                    // inference batch norm folded in (kernels.h ConvArgs::aff_*): leaky(T(conv + b) * scale + shift) into
+                    // the consumer's bordered tensor -- the arithmetic of bn_act_kernel on the same rounded value; the
+                    // per-channel constants come from L1 every sweep (the filter slice owns the registers)
+                    const int pb = __shfl(pbj[it >> 1], rloc, 64);
+                    if (st) {
+                        const f32x4 s0 = *(const f32x4*)(a.aff_scale + cch), s1 = *(const f32x4*)(a.aff_scale + cch + 4);
+                        const f32x4 h0 = *(const f32x4*)(a.aff_shift + cch), h1 = *(const f32x4*)(a.aff_shift + cch + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            c.v[e] = Elem<T>::from_f32(leaky01(Elem<T>::to_f32(c.v[e]) * s0[e] + h0[e]));
+                            c.v[4 + e] = Elem<T>::from_f32(leaky01(Elem<T>::to_f32(c.v[4 + e]) * s1[e] + h1[e]));
+                        }
+                        dstp = (char*)a.aff_out + ((size_t)pb * a.ldy + cch) * SZ;
+                    }
+                }
                 st_chunk<T>(dstp, c);
                 if (chk && st) {
 #pragma unroll

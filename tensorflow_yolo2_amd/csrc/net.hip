@@ -646,7 +646,12 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             a.stats_only = pool1 ? 1 : 0;
             // round 4: the statistics of the pooled first layer come from the Gram matrix of the input patches (below)
             static const bool no_gram = getenv("Y2_NO_CONV1_GRAM") != nullptr;
-            gram1 = pool1 && training && c->lin1() && c->o_gram != 0 && !no_gram;
+            // Half-precision modes only: their stored activations carry 5e-4 of rounding noise, against which the ~1e-6
+            // of the fp32 MFMA sums behind the Gram moments is nothing.  The f32 parity mode keeps the statistics-only
+            // convolution pass (moments of the exact fp32 outputs, double merge): a randomly initialised 20-layer
+            // stack amplifies a 1e-6 perturbation of the first scale / shift to 1e-3 at the top, enough to flip
+            // leaky / arg-max decisions the f32 tests compare element-wise with the oracle.
+            gram1 = pool1 && training && c->lin1() && c->o_gram != 0 && !no_gram && c->dtype != 0;
             if ((!pool1 || training) && !gram1) { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
             c->gram_valid = gram1;
         } else {

@@ -56,6 +56,17 @@ def rel_to_max(got, ref):
     return float(np.abs(np.asarray(got, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
+def rel_elementwise(got, ref, floor=0.05):
+    """largest ELEMENT-WISE relative error over the elements whose reference magnitude is at least `floor` of the
+    tensor's maximum (north_star's "1e-3 relative" read literally; below the floor a sum has cancelled
+    and only the rel_to_max bound is meaningful)"""
+    got = np.asarray(got, np.float64)
+    big = np.abs(ref) >= floor * max(np.abs(ref).max(), 1e-30)
+    if not big.any():
+        return 0.0
+    return float((np.abs(got - ref)[big] / np.abs(ref)[big]).max())
+
+
 def wgrad_reference(x, dy, k, ci_s, co_s):
     """dW[dh, dw, ci, co] = sum over ALL pixels of x[p + tap][ci] dy[p][co] in float64, for the sampled channels"""
     hw = x.shape[1]
@@ -88,6 +99,7 @@ def check_layer_shape(N, name, k, cin, cout, hw, tag="C4", dtype="f16", tol=TOL)
     y = E.conv2d(xd, wd, torch.as_tensor(b).cuda(), dtype=dtype).cpu().numpy().reshape(-1, cout)
     ref = gather_patches(x, pts, hw, k) @ w.reshape(k * k * cin, cout).astype(np.float64) + b.astype(np.float64)
     e_fwd = rel_to_max(y[pts], ref)
+    r_fwd = rel_elementwise(y[pts], ref)
 
     # ---- dgrad: dx = conv(dy, flip(W)^T) at the sampled pixels, every cin
     dx, dw = E.conv2d_backward(xd, wd, dyd, dtype=dtype)
@@ -95,6 +107,7 @@ def check_layer_shape(N, name, k, cin, cout, hw, tag="C4", dtype="f16", tol=TOL)
     wflip = w[::-1, ::-1].transpose(0, 1, 3, 2).reshape(k * k * cout, cin).astype(np.float64)
     ref = gather_patches(dy, pts, hw, k) @ wflip
     e_dx = rel_to_max(dx[pts], ref)
+    r_dx = rel_elementwise(dx[pts], ref)
 
     # ---- wgrad: dW[t, ci, co] = sum over ALL N*H*W pixels, for a sample of (ci, co) pairs
     ci_s = np.unique(np.r_[0, 1, 31, 32 % cin, 63 % cin, cin - 1, rng.integers(0, cin, 6)])
@@ -102,9 +115,14 @@ def check_layer_shape(N, name, k, cin, cout, hw, tag="C4", dtype="f16", tol=TOL)
     dw = dw.cpu().numpy()
     ref = wgrad_reference(x, dy, k, ci_s, co_s)
     e_dw = rel_to_max(dw[:, :, ci_s][:, :, :, co_s], ref)
-    print("%s %-13s N=%d %s vs float64 (rel. to max): forward %.2e  dgrad %.2e  wgrad %.2e" %
-          (tag, name, N, dtype, e_fwd, e_dx, e_dw))
+    r_dw = rel_elementwise(dw[:, :, ci_s][:, :, :, co_s], ref)
+    print("%s %-13s N=%d %s vs float64 (rel. to max): forward %.2e  dgrad %.2e  wgrad %.2e   element-wise relative on "
+          "|ref| >= 5%% of max: %.2e  %.2e  %.2e" % (tag, name, N, dtype, e_fwd, e_dx, e_dw, r_fwd, r_dx, r_dw))
     assert e_fwd < tol and e_dx < tol and e_dw < tol, (name, dtype, e_fwd, e_dx, e_dw)
+    # element-wise 1e-3 relative (north_star's wording) wherever the result has not cancelled: an f16 store alone is up to
+    # 2^-11 = 4.9e-4; the f32 mode is held to its own tolerance
+    rtol = max(tol, 1e-3) if dtype != "f32" else max(tol, 1e-4)
+    assert r_fwd < rtol and r_dx < rtol and r_dw < rtol, (name, dtype, "element-wise", r_fwd, r_dx, r_dw)
 
 
 def check_layer_in_network(N, name, k, cin, cout, hw, pool, tag="C4"):

@@ -163,14 +163,23 @@ def test_stack_backward(first3, dtype):
     # against the oracle with the same storage points quantised (oracle quantizer()).
     q = R.quantizer(dtype)
     ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q)
-    gate("stack forward vs quantised oracle %s" % dtype, l2err(out.cpu().numpy(), ref),
-         {"f32": 4e-6, "f16": 1e-3, "bf16": 1e-6}[dtype])       # observed 1.5e-6 / 7.3e-4 / 2.8e-7
+    # Without the 3-channel layer the device and the oracle take their batch moments from the SAME rounded values: the
+    # half modes then agree to fp32 round-off (bf16 2.8e-7).  The pooled 3-channel first layer takes its moments from
+    # the Gram matrix of the input patches since round 4 (fp32 MFMA sums, ~1e-6 relative): scale / shift differ from the
+    # float64 ones in the 6th digit, which moves a fraction of the STORED half-precision activations by one ulp
+    # (2^-8 in bf16) -- amplified by the three batch-normed toy layers behind it (8 pixels per channel at the end).
+    tol_q = {"f32": 4e-6, "f16": 1e-3, "bf16": 1e-6}[dtype]      # observed 1.5e-6 / 7.3e-4 / 2.8e-7
+    if first3 and dtype != "f32":
+        tol_q = {"f16": 2e-3, "bf16": 8e-3}[dtype]                # observed 2.2e-3 in bf16 (one-ulp flips)
+    gate("stack forward vs quantised oracle %s first3=%d" % (dtype, first3), l2err(out.cpu().numpy(), ref), tol_q)
     dout = rng.standard_normal(ref.shape).astype(np.float32)
     net.backward(dev(dout))
     _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,
                                      grad_scale=net.grad_scale)
     grads = net.export_grads()
     tol = {"f32": 5e-6, "f16": 4e-3, "bf16": 1e-2}[dtype]    # observed 1.7e-6 / 1.9e-3 / 4.3e-3
+    if first3 and dtype == "bf16":
+        tol = 3e-2                                            # the one-ulp flips above, through the backward pass
     for l in range(len(spec)):
         for k in ("W", "gamma", "beta"):
             gate("stack backward %s first3=%d" % (dtype, first3), l2err(grads[l][k], rgrads[l][k]), tol)
@@ -315,9 +324,13 @@ def test_first_layer_paths_odd_and_wide(shape, dtype):
     net.load_params(params)
     out = net.forward(dev(x), True, True)
     q = R.quantizer(dtype)
-    ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q)
+    # even sizes: the linear-form path, whose batch moments come from the Gram matrix (un-rounded conv output); odd sizes:
+    # conv1 + bn_act with the moments of the stored values -- the oracle is told which
+    gram = shape[1] % 2 == 0 and shape[2] % 2 == 0
+    ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q, first_stats_unrounded=gram and q is not None)
     assert out.shape == ref.shape
-    gate("first layer forward %s" % dtype, l2err(out.cpu().numpy(), ref), {"f32": 3e-6, "f16": 4e-4}[dtype])   # 9.5e-7 / 1.6e-4
+    gate("first layer forward %s gram=%d" % (dtype, gram), l2err(out.cpu().numpy(), ref),
+         {"f32": 3e-6, "f16": 1.5e-3 if gram else 4e-4}[dtype])   # 9.5e-7 / 1.6e-4 (one-ulp flips of stored f16 values with the Gram moments)
     dout = rng.standard_normal(ref.shape).astype(np.float32)
     net.backward(dev(dout))
     _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,

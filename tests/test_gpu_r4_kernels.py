@@ -41,6 +41,7 @@ def test_first_layer_statistics_from_the_gram_matrix(N, hw, kind, dtype):
     it replaces is held to the same gate through Y2_NO_CONV1_GRAM in test_ab_switches_select_equivalent_paths)."""
     if N * hw * hw > 3e6 and dtype != "f16":
         pytest.skip("the large geometries run in the benchmarked type only")
+    # (f32: the parity mode keeps the statistics-only convolution pass -- net.hip -- and is held to the same gate)
     from tensorflow_yolo2_amd import engine as E
     rng = np.random.default_rng(N + hw)
     spec = [(3, 3, 32, 1), (1, 32, 32, 0)]
