@@ -663,94 +663,94 @@ __global__ __launch_bounds__(1024) void conv1_dw_finalize_kernel(Conv1DwFinalize
 // ---------------------------------------------------------------------------
 constexpr int kGram = 48 * 48;
 constexpr int kGramMaxBlocks = 768;
+// Tile = RT output rows (4 where H % 4 == 0, else 2) x the whole image row: RT + 2 input rows in LDS (each input row is
+// staged (RT + 2) / RT times: 1.5x at RT = 4), double-buffered.  Work item = (32-pixel group, pair of output rows): four
+// input-row fragments X_q [16 patch elements (kw, c) x 32 pixels] by transposed LDS reads -- the 16 elements of one filter
+// row are contiguous in the 4-channel image, so a fragment is two ds_read_b64_tr_b16 of overlapping 32-byte windows --
+// and G_block(kh, kh') += X_{r+kh} X_{r+kh'}^T on 16x16x32 MFMAs with the SAME registers as both operands (six of the
+// nine 16x16 blocks: G is symmetric): 12 MFMAs of 16 cycles per 64 output pixels.
 template <typename T>
-__global__ __launch_bounds__(256, 2) void conv1_gram_kernel(const void* x4, int N, int H, int W, float* part) {
-    constexpr int SZ = sizeof(T), XP = 4 * SZ;
+__global__ __launch_bounds__(256, 2) void conv1_gram_kernel(const void* x4, int N, int H, int W, int RT, float* part) {
+    static_assert(sizeof(T) == 2, "half-precision modes only (the f32 parity mode keeps the statistics-only conv pass)");
+    constexpr int SZ = 2, XP = 4 * SZ;
     constexpr int NTH = 256, NW = 4;
+    typedef typename Elem<T>::frag frag_t;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Wp = (W + 15) & ~15;
+    const int Wp = (W + 31) & ~31;
     const int x_bytes = ((Wp + 4) * XP + 15) & ~15;
     const int x_chunks = x_bytes / 16;
-    char* x_l = smem;                    // [2 buffers][4 rows][x_bytes]
-    const int Ho = H / 2;
-    const int prs = N * Ho;
-    const int r32 = lane & 31, hh = lane >> 5;
-    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
-    f32x16 g11, g12, g22;
+    const int nrow = RT + 2;
+    char* x_l = smem;                    // [2 buffers][RT + 2 rows][x_bytes]
+    const int Ht = H / RT;
+    const int ntile = N * Ht;
+    const int g4 = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    f32x4 gb[6];                         // (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) g11[q] = g12[q] = g22[q] = 0.f;
-    auto stage = [&](int pr, int buf) {
-        const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho;
+    for (int k = 0; k < 6; ++k) gb[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int t, int buf) {
+        const int n = t / Ht, h0 = (t - n * Ht) * RT;
         const char* xrow = (const char*)x4 + (bpix(n, h0, 0, H, W) - (size_t)(W + 2)) * XP;
         const size_t xpitch = (size_t)(W + 1) * XP;
-        char* dst = x_l + buf * 4 * x_bytes;
-        for (int kh = 0; kh < 4; ++kh)
+        char* dst = x_l + buf * nrow * x_bytes;
+        for (int kh = 0; kh < nrow; ++kh)
             for (int i0 = w * 64; i0 < x_chunks; i0 += NTH) {
                 const int i = i0 + lane;
                 if (i < x_chunks) glds16(xrow + kh * xpitch + (size_t)i * 16, dst + kh * x_bytes + i0 * 16);
             }
     };
+    const int ngrp = (W + 31) / 32, nitem = ngrp * (RT / 2);
     int buf = 0;
-    if ((int)blockIdx.x < prs) stage(blockIdx.x, 0);
-    for (int pr = blockIdx.x; pr < prs; pr += gridDim.x, buf ^= 1) {
-        __syncthreads();   // this row pair's rows have landed (vmcnt(0) before the barrier); the other buffer is free
-        if (pr + (int)gridDim.x < prs) stage(pr + gridDim.x, buf ^ 1);
-        const char* xb = x_l + buf * 4 * x_bytes;
+    if ((int)blockIdx.x < ntile) stage(blockIdx.x, 0);
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x, buf ^= 1) {
+        __syncthreads();   // this tile's rows have landed (vmcnt(0) before the barrier); the other buffer is free
+        if (t + (int)gridDim.x < ntile) stage(t + gridDim.x, buf ^ 1);
+        const char* xb = x_l + buf * nrow * x_bytes;
+        for (int it = w; it < nitem; it += NW) {
+            const int s = it % ngrp, r0 = 2 * (it / ngrp);      // output rows r0, r0 + 1: input rows r0 .. r0 + 3
+            const int w0 = s * 32;
+            const int pix = w0 + 8 * g4 + qq;
+            frag_t X[4], B[4];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            for (int s = w; s * 16 < W; s += NW) {
-                const int w0 = s * 16;
-                if constexpr (SZ == 2) {
-                    const int pix = w0 + 8 * hh + qq;
-                    const char* pa1 = xb + (r + g1) * x_bytes + (pix + pp) * XP;
-                    typename Elem<T>::frag fa1 = tr_frag<T>(pa1, pa1 + 4 * XP);
-                    const char* pa2 = xb + (r + 2) * x_bytes + (pix + pp) * XP;
-                    typename Elem<T>::frag fa2 = tr_frag<T>(pa2, pa2 + 4 * XP);
-                    // the SAME registers serve as B (k = pixel on both sides); k-padding pixels of the last group hold
-                    // the neighbouring data of the x image: masked out of one side
-                    typename Elem<T>::frag fg1 = fa1, fg2 = fa2;
-                    if (w0 + 16 > W) {
+            for (int q = 0; q < 4; ++q) {
+                const char* pa = xb + (r0 + q) * x_bytes + (pix + pp) * XP;
+                X[q] = tr_frag<T>(pa, pa + 4 * XP);
+                B[q] = X[q];
+            }
+            if (w0 + 32 > W) {      // k-padding pixels of the last group hold neighbouring data: masked out of one side
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (w0 + 8 * hh + j >= W) { fg1[j] = (T)0.f; fg2[j] = (T)0.f; }
-                    }
-                    mma32(g11, fa1, fg1);
-                    mma32(g12, fa1, fg2);
-                    mma32(g22, fa2, fg2);
-                } else {
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int k2 = 0; k2 < 8; ++k2) {
-                        const int pix = w0 + 2 * k2 + hh;
-                        const float vm = pix < W ? 1.f : 0.f;
-                        const float a1 = *(const float*)(xb + (r + (r32 >> 4)) * x_bytes + pix * XP + (r32 & 15) * 4);
-                        const float a2 = *(const float*)(xb + (r + 2) * x_bytes + pix * XP + (r32 & 15) * 4);
-                        g11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1 * vm, g11, 0, 0, 0);
-                        g12 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a2 * vm, g12, 0, 0, 0);
-                        g22 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, a2 * vm, g22, 0, 0, 0);
-                    }
-                }
+                    for (int j = 0; j < 8; ++j)
+                        if (w0 + 8 * g4 + j >= W) B[q][j] = (T)0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                mma16(gb[0], X[r], B[r]);
+                mma16(gb[1], X[r], B[r + 1]);
+                mma16(gb[2], X[r], B[r + 2]);
+                mma16(gb[3], X[r + 1], B[r + 1]);
+                mma16(gb[4], X[r + 1], B[r + 2]);
+                mma16(gb[5], X[r + 2], B[r + 2]);
             }
         }
     }
-    // ---- the four waves through LDS (fixed order) -> this block's partial G [48][48] (lower-left block by symmetry)
+    // ---- the four waves through LDS (fixed order) -> this block's partial G [48][48] (lower blocks by symmetry)
     __syncthreads();
     float* red = (float*)smem;   // [4][kGram]
     {
         float* g = red + w * kGram;
+        const int bi[6] = {0, 0, 0, 1, 1, 2}, bj[6] = {0, 1, 2, 1, 2, 2};
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = acc_row(q, hh);
-            g[r * 48 + r32] = g11[q];
-            if (r32 < 16) g[r * 48 + 32 + r32] = g12[q];
-            if (r < 16 && r32 < 16) g[(32 + r) * 48 + 32 + r32] = g22[q];
-        }
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[(bi[k] * 16 + 4 * g4 + q) * 48 + bj[k] * 16 + (lane & 15)] = gb[k][q];
     }
     __syncthreads();
     for (int i = tid; i < kGram; i += NTH) {
         const int r = i / 48, c = i % 48;
-        const int j = (r >= 32 && c < 32) ? c * 48 + r : i;
+        const int j = (r / 16 > c / 16) ? c * 48 + r : i;       // blocks below the diagonal: the transposed entry
         part[(size_t)blockIdx.x * kGram + i] = (red[j] + red[kGram + j]) + (red[2 * kGram + j] + red[3 * kGram + j]);
     }
 }
@@ -794,11 +794,21 @@ __global__ __launch_bounds__(1024) void conv1_gram_stats_kernel(Conv1GramStatsAr
     __syncthreads();
     constexpr int kOnes = 1 * 16 + 1 * 4 + 3;               // centre tap, channel 3 (= 1 inside the image)
     const double M = G[kOnes][kOnes];
+    const double invM = M > 0 ? 1.0 / M : 0.0;
+    // centred Gram matrix in place: C = G - s s^T / M (the row of ones is read before anything is overwritten)
+    __shared__ double sv[48];
+    if (tid < 48) sv[tid] = G[kOnes][tid];
+    __syncthreads();
+    for (int i = tid; i < kGram; i += 1024) {
+        const int r = i / 48, c = i % 48;
+        G[r][c] -= sv[r] * sv[c] * invM;
+    }
+    __syncthreads();
     for (int i = tid; i < 48 * 32; i += 1024) {
         const int r = i >> 5, co = i & 31;
-        const double sr = G[kOnes][r];
         double v = 0.0;
-        for (int k = 0; k < 48; ++k) v += (G[r][k] - sr * G[kOnes][k] / M) * (double)Wq[k][co];
+#pragma unroll 8
+        for (int k = 0; k < 48; ++k) v += G[r][k] * (double)Wq[k][co];
         t[r][co] = v * (double)Wq[r][co];
     }
     __syncthreads();
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(1024) void conv1_gram_stats_kernel(Conv1GramStatsAr
         double m2 = 0.0, s = 0.0;
         for (int r = 0; r < 48; ++r) {
             m2 += t[r][c];
-            s += G[kOnes][r] * (double)Wq[r][c];
+            s += sv[r] * (double)Wq[r][c];
         }
         if (m2 < 0) m2 = 0;
         const double mean = (double)a.bias[c] + s / M;
@@ -833,30 +843,30 @@ __global__ __launch_bounds__(1024) void conv1_gram_stats_kernel(Conv1GramStatsAr
 
 size_t conv1_gram_scratch_floats() { return (size_t)kGram * (1 + kLinMid + kGramMaxBlocks); }
 bool conv1_gram_ok(int H, int W, int elem_size) {
-    const int Wp = (W + 15) & ~15;
-    const size_t lds = 2 * 4 * (size_t)((((Wp + 4) * 4 * elem_size) + 15) & ~15);
-    return (H % 2) == 0 && lds <= 64 * 1024;
+    const int Wp = (W + 31) & ~31;
+    const size_t lds = 2 * 6 * (size_t)((((Wp + 4) * 4 * elem_size) + 15) & ~15);
+    return elem_size == 2 && (H % 2) == 0 && lds <= 72 * 1024;
 }
 template <typename T>
 static hipError_t c1gram_T(const Conv1GramStatsArgs& a, hipStream_t s) {
-    const int Wp = (a.Wd + 15) & ~15;
-    size_t lds = 2 * 4 * (size_t)((((Wp + 4) * 4 * sizeof(T)) + 15) & ~15);
+    const int Wp = (a.Wd + 31) & ~31;
+    const int RT = (a.H % 4) == 0 ? 4 : 2;
+    size_t lds = 2 * (size_t)(RT + 2) * (size_t)((((Wp + 4) * 4 * sizeof(T)) + 15) & ~15);
     const size_t red = 4 * (size_t)kGram * sizeof(float);
     if (lds < red) lds = red;
     auto kern = conv1_gram_kernel<T>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int prs = a.N * (a.H / 2);
-    const int nb = prs < kGramMaxBlocks ? prs : kGramMaxBlocks;
+    const int ntile = a.N * (a.H / RT);
+    const int nb = ntile < kGramMaxBlocks ? ntile : kGramMaxBlocks;
     float* part = a.mid + (size_t)kLinMid * kGram;
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, a.x4, a.N, a.H, a.Wd, part);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, s, a.x4, a.N, a.H, a.Wd, RT, part);
     hipLaunchKernelGGL(conv1_gram_reduce_kernel, dim3((kGram + 255) / 256, kLinMid), dim3(256), 0, s, part, nb, a.mid);
     hipLaunchKernelGGL(conv1_gram_stats_kernel<T>, dim3(1), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_conv1_gram_stats(int dtype, const Conv1GramStatsArgs& a, hipStream_t s) {
     switch (dtype) {
-        case 0: return c1gram_T<float>(a, s);
         case 1: return c1gram_T<half_t>(a, s);
         case 2: return c1gram_T<bf16_t>(a, s);
     }
