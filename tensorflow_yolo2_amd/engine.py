@@ -48,6 +48,33 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class ForwardGraph:
+    """Network.forward captured into a HIP graph (Network.forward_graph)."""
+
+    def __init__(self, net, is_training_core, is_training_head, uint8):
+        self.net = net
+        shape = (net.batch, net.height, net.width, net.spec[0][1])
+        self.input = torch.zeros(shape, dtype=torch.uint8 if uint8 else torch.float32, device=net.device)
+        self.output = torch.empty(net.out_shape, dtype=torch.float32, device=net.device)
+        self._stream = torch.cuda.Stream(device=net.device)
+        self._stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._stream):
+            for _ in range(2):
+                net.forward(self.input, is_training_core, is_training_head, out=self.output, update_moving=False)
+        self._stream.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, stream=self._stream):
+            net.forward(self.input, is_training_core, is_training_head, out=self.output, update_moving=False)
+
+    def replay(self):
+        self._graph.replay()
+        return self.output
+
+    def __call__(self, images):
+        self.input.copy_(images, non_blocking=True)
+        return self.replay()
+
+
 class Network:
     """One conv-BN-leaky(-pool) stack bound to device buffers."""
 
@@ -201,6 +228,15 @@ class Network:
         check(fwd(self.h, _ptr(images), int(bool(is_training_core)), int(bool(is_training_head)),
                   int(bool(update_moving)), _ptr(out), _stream()))
         return out
+
+    def forward_graph(self, is_training_core=False, is_training_head=True, uint8=False):
+        """The forward pass as ONE HIP graph (serving: single-image detection is launch-bound -- ~40 kernels of 3-8 us
+        behind ~4 us of host work each; a replay is one host call).  Returns a ForwardGraph: write the batch into
+        `.input` (float32 NHWC, or uint8 BGR with uint8=True), call `.replay()`, read `.output` ([N,S,S,C] fp32; valid
+        after a synchronisation of the current stream).  Two eager passes run first on the capture stream (filter packs,
+        kernel attributes: neither may happen inside a capture).  The moving statistics are never updated by a replay.
+        A later load_params / optimizer step re-packs the filters outside the graph: call forward_graph again."""
+        return ForwardGraph(self, is_training_core, is_training_head, uint8)
 
     def update_moving_stats(self):
         check(self.lib.y2_update_moving_stats(self.h, _stream()))

@@ -28,3 +28,33 @@ def test_rccl_backend_runs_the_sliced_allreduce_path():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
     assert "rccl world-1 ok" in r.stdout
+
+
+def test_forward_graph_replays_the_detection_forward():
+    """engine.ForwardGraph: pascal_detect_darknet.py's forward (core with moving statistics, head with batch statistics,
+    one image) captured into ONE HIP graph -- replays on changing inputs give the bits of the eager launches, float32
+    and uint8 inputs, and leave the moving statistics alone."""
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    core = [(k, ci, co, int(p)) for (k, ci, co, p) in R.scaled_spec(R.CORE_SPEC, 4)]
+    head = [(3, core[-1][2], 256, 0), (1, 256, 30, 0)]
+    size = 224
+    for dtype in ("f16", "f32"):
+        net = E.Network(core + head, 1, size, size, dtype=dtype, core_layers=len(core), training=False)
+        net.init_params(3)
+        state0 = net.state.clone()
+        g = net.forward_graph(False, True)
+        gu = net.forward_graph(False, True, uint8=True)
+        rng = np.random.default_rng(0)
+        for i in range(3):
+            x = torch.as_tensor(synthetic.images(1, size, 50 + i)).cuda()
+            want = net.forward(x, False, True).clone()
+            got = g(x)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (dtype, i)
+            u = torch.as_tensor(rng.integers(0, 256, (1, size, size, 3), dtype=np.uint8)).cuda()
+            want_u = net.forward(u, False, True).clone()
+            got_u = gu(u)
+            torch.cuda.synchronize()
+            assert torch.equal(got_u, want_u), (dtype, i, "uint8")
+        assert torch.equal(net.state, state0)
