@@ -653,6 +653,14 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
         }
         if (e != hipErrorOutOfMemory) return e;
         (void)hipGetLastError();
+        // a handful of pixels (single-image detection: 49 at 7x7, 196 at 14x14): the launch is a stream of the FILTERS
+        // through a few workgroups -- 128 x 128 tiles give one pixel tile x Cout / 128 workgroups (8 for 1024 couts, each
+        // pulling 2.4 MB of filter fragments through one CU).  32-cout tiles: four times the workgroups on the same
+        // fragment pack (layout 1 is made of 32-cout tiles whatever the kernel's tile)
+        if (k128 && ((a.M + 127) / 128) * ((a.Cout + 127) / 128) < 64) {
+            *bp = 256;
+            return haloq_pick<T, 4, 1, 2, 1, 128>(a, s);
+        }
         *bp = 128;
         return haloq_pick<T, 2, 2, 2, 2, 64>(a, s);
     } else if (a.Cout > 32) {
