@@ -70,7 +70,11 @@ Y2_DEV u32x4 lds_read16(uint32_t lds_addr) {
     return *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)lds_addr;
 }
 
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT, int TAPS>
+// KS: the K range (input-channel chunks) is split over a.ks_splits workgroups per tile; every one leaves its fp32 partial
+// tile in a.ks_scratch [split][M][ldy] and conv_ks_finish_kernel adds them in split order (bias, rounding, statistics
+// or the folded inference batch norm there): launches of a few hundred pixels are bound by the SERIAL K loop of their
+// few workgroups (~110 ns per tap step, 72 us for K = 9216 whatever the tile), not by anything a roofline names.
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT, int TAPS, bool KS = false>
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int arows) {
     static_assert(TAPS == 9 || (TAPS == 1 && CPT), "1x1 filters run on the compact image (no halo, no border taps)");
     typedef typename Elem<T>::frag frag_t;
@@ -82,7 +86,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / WC, wc = w % WC;
     const int nCT = (a.Cout + BC - 1) / BC;
-    const int bx = xcd_block(blockIdx.x, gridDim.x, a.xcd);
+    int bx = xcd_block(blockIdx.x, gridDim.x, a.xcd);
+    int split = 0;
+    if constexpr (KS) {
+        const int tiles = ((a.M + BP - 1) / BP) * nCT;
+        split = bx / tiles;
+        bx -= split * tiles;
+    }
     const int ct = bx % nCT, pt = bx / nCT;
     const int m0 = pt * BP, n0 = ct * BC;
     const int pitch = a.W + 1, hw = a.H * a.W;
@@ -206,18 +216,26 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    const int nchunks = rowbytes / BKB;
-    const int steps = nchunks * TAPS;
+    int c_begin = 0, nchunks = rowbytes / BKB;     // this workgroup's chunk range [c_begin, nchunks)
+    if constexpr (KS) {
+        const int per = (nchunks + a.ks_splits - 1) / a.ks_splits;
+        c_begin = split * per;
+        nchunks = c_begin + per < nchunks ? c_begin + per : nchunks;
+        if (c_begin > nchunks) c_begin = nchunks;
+    }
+    const int steps = (nchunks - c_begin) * TAPS;
     u32x4 fbq[2][TC][KG];
     int aoffq[2][TP];                          // fragment-row addresses of the current / the next tap step
-    issueA(0, 0);
-    loadB(0, 0, fbq[0]);
-    tap_addr(0, 0, 0, aoffq[0]);
-    int c = 0, t = 0, kh = 0, kw = 0;
+    if (steps > 0) {
+        issueA(c_begin, ADB ? (c_begin & 1) : 0);
+        loadB(c_begin, 0, fbq[0]);
+    }
+    tap_addr(0, 0, c_begin, aoffq[0]);
+    int c = c_begin, t = 0, kh = 0, kw = 0;
     auto step = [&](auto par, int s) {
         constexpr int P = decltype(par)::value;
         if (t == 0) {
-            if (!ADB && c > 0) {
+            if (!ADB && c > c_begin) {
                 __builtin_amdgcn_s_barrier();      // everyone is done with the single image buffer
                 asm volatile("" ::: "memory");
                 issueA(c, 0);
@@ -283,8 +301,95 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         step(IntC<0>{}, s);
         if (s + 1 < steps) step(IntC<1>{}, s + 1);
     }
+    if constexpr (KS) {
+        // fp32 partial tile: 4 consecutive couts (registers 4 q4 .. 4 q4 + 3) per 16-byte store
+        float* const part = a.ks_scratch + (size_t)split * a.M * a.ldy;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int p = m0 + (wp * TP + j) * 32 + r32;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int co = n0 + (wc * TC + i) * 32 + 8 * q4 + 4 * hh;
+                    if (p < a.M && co < a.ldy)
+                        *(f32x4*)(part + (size_t)p * a.ldy + co) =
+                            f32x4{acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                }
+            }
+        return;
+    } else {
+        __syncthreads();
+        conv_epilogue<T, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    }
+}
+
+// K-split partial tiles -> the launch's result.  One thread = one pixel x 4 couts: the splits added in order, bias, the
+// rounding to T of the un-split epilogue; then either the folded inference batch norm into the consumer's bordered
+// tensor (ConvArgs::aff_*) or y [M][ldy].  Batch-norm statistics: conv_ks_stats_kernel over the stored y.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_ks_finish_kernel(ConvArgs a, int splits) {
+    const int c4n = a.ldy / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)a.M * c4n) return;
+    const int m = (int)(idx / c4n), co = (int)(idx % c4n) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < splits; ++sp) v += *(const f32x4*)(a.ks_scratch + ((size_t)sp * a.M + m) * a.ldy + co);
+    T o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float b = (a.bias && co + e < a.Cout) ? a.bias[co + e] : 0.f;
+        o[e] = Elem<T>::from_f32(v[e] + b);
+    }
+    if (a.aff_out) {
+        const uint32_t r = (uint32_t)(((uint64_t)(uint32_t)m * a.aff_magW) >> a.aff_shW);
+        const uint32_t n = (uint32_t)(((uint64_t)r * a.aff_magH) >> a.aff_shH);
+        const size_t bp = (size_t)m + r + (size_t)(n + 1) * (uint32_t)(a.W + 1) + 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = Elem<T>::from_f32(leaky01(Elem<T>::to_f32(o[e]) * a.aff_scale[co + e] + a.aff_shift[co + e]));
+        T* dst = (T*)a.aff_out + bp * a.ldy + co;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = o[e];
+    } else {
+        T* dst = (T*)a.y + (size_t)m * a.ldy + co;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = o[e];
+    }
+}
+// (count, mean, M2) records over the stored values, one per 128 pixels (bn_finalize merges them as it merges the tile
+// records of the un-split epilogue): block = 64 channels x 4 pixel slices of one 128-pixel group, sums about the bias
+constexpr int kKsRec = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void conv_ks_stats_kernel(ConvArgs a) {
+    __shared__ float red[4][64][2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * kKsRec;
+    const int m1 = m0 + kKsRec < a.M ? m0 + kKsRec : a.M;
+    const bool cv = c < a.ldy;
+    const float piv = (cv && a.bias && c < a.Cout) ? a.bias[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (cv) {
+        const T* yp = (const T*)a.y + c;
+#pragma unroll 8
+        for (int m = m0 + sl; m < m1; m += 4) {
+            const float d = Elem<T>::to_f32(yp[(size_t)m * a.ldy]) - piv;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+        }
+    }
+    red[sl][threadIdx.x & 63][0] = s1;
+    red[sl][threadIdx.x & 63][1] = s2;
     __syncthreads();
-    conv_epilogue<T, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    if (sl == 0 && cv) {
+        const int k = threadIdx.x & 63;
+        const double S1 = ((double)red[0][k][0] + red[1][k][0]) + ((double)red[2][k][0] + red[3][k][0]);
+        const double S2 = ((double)red[0][k][1] + red[1][k][1]) + ((double)red[2][k][1] + red[3][k][1]);
+        const double n = (double)(m1 - m0), md = S1 / n, m2 = S2 - S1 * md;
+        a.part_mean[(size_t)blockIdx.y * a.ldy + c] = (float)((double)piv + md);
+        a.part_m2[(size_t)blockIdx.y * a.ldy + c] = (float)(m2 > 0.0 ? m2 : 0.0);
+        if (c == 0) a.part_cnt[blockIdx.y] = (float)(m1 - m0);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -599,6 +704,58 @@ static hipError_t haloq_T1(const ConvArgs& a, hipStream_t s, int* bp) {
     return haloq_pick1<T, 4, 2, 3, 1, false>(a, s);
 }
 
+// K split of a small launch (see conv_haloq_kernel<.., KS>): fewer than 128 workgroups of the 256 x 64 tile and at least
+// four 128-byte K chunks; the depth fills ~one round of the chip.  hipErrorNotSupported: not this form.
+static int haloq_ks_depth(int M, int Cout, int nchunks) {
+    static const bool off = getenv("Y2_NO_KSPLIT") != nullptr;
+    const int wgs = ((M + 255) / 256) * ((Cout + 63) / 64);
+    if (off || wgs >= 128 || nchunks < 4) return 1;
+    int d = 256 / wgs;
+    d = d > 8 ? 8 : d;
+    d = d > nchunks / 2 ? nchunks / 2 : d;
+    return d < 2 ? 1 : d;
+}
+int conv_ks_depth(int taps, int M, int Cout, int row_bytes) {
+    if (taps != 9 || M >= 384 * 8 || (row_bytes % 128) != 0 || Cout <= 64 || halo_compact()) return 1;
+    return haloq_ks_depth(M, Cout, row_bytes / 128);
+}
+size_t conv_ks_scratch_floats(int taps, int M, int ldy, int row_bytes) {
+    if (taps != 9 || M >= 384 * 8 || (row_bytes % 128) != 0 || ldy <= 64) return 0;
+    return (size_t)8 * M * ldy;
+}
+template <typename T>
+static hipError_t haloq_ks(const ConvArgs& a0, hipStream_t s, int* bp) {
+    constexpr int WP = 4, WC = 2, TP = 2, TC = 1, BKB = 128, BP = WP * TP * 32, BC = WC * TC * 32, RPI = 64 / (BKB / 16);
+    const int nchunks = a0.C * (int)sizeof(T) / BKB;
+    int depth = haloq_ks_depth(a0.M, a0.Cout, nchunks);
+    if (depth < 2 || !a0.ks_scratch || a0.bw_psum || a0.nonfinite || halo_compact() || (a0.ldy % 4) != 0)
+        return hipErrorNotSupported;
+    while (depth > 1 && (size_t)depth * a0.M * a0.ldy > a0.ks_floats) --depth;
+    if (depth < 2) return hipErrorNotSupported;
+    ConvArgs a = a0;
+    a.ks_splits = depth;
+    const int arows = haloq_rows(a.H, a.W, BP, RPI);
+    const bool adb = (nchunks + depth - 1) / depth > 1 && 2 * (size_t)arows * BKB <= 150 * 1024;
+    const size_t lds = haloq_lds<BKB>(arows, adb, false);
+    if (lds > 160 * 1024) return hipErrorNotSupported;
+    void (*kern)(ConvArgs, int) = adb ? conv_haloq_kernel<T, WP, WC, TP, TC, BKB, true, false, 9, true>
+                                      : conv_haloq_kernel<T, WP, WC, TP, TC, BKB, false, false, 9, true>;
+    static size_t attr[2] = {0, 0};
+    if (lds > attr[adb]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr[adb] = lds;
+    }
+    const int tiles = ((a.M + BP - 1) / BP) * ((a.Cout + BC - 1) / BC);
+    hipLaunchKernelGGL(kern, dim3(tiles * depth), dim3(WP * WC * 64), lds, s, a, arows);
+    const long quads = (long)a.M * (a.ldy / 4);
+    hipLaunchKernelGGL(conv_ks_finish_kernel<T>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a, depth);
+    if (a.part_mean && !a.aff_out)
+        hipLaunchKernelGGL(conv_ks_stats_kernel<T>, dim3((a.ldy + 63) / 64, (a.M + kKsRec - 1) / kKsRec), dim3(256), 0, s, a);
+    *bp = kKsRec;    // batch-norm records of the launch (launch_conv: records = ceil(M / bp))
+    return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
     const int kb = a.C * (int)sizeof(T);
@@ -644,6 +801,17 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
             }
             return hipErrorInvalidValue;
         }
+        // Fewer than 3072 pixels (the reference's own training shape, 224x224 at batch 24: 1176 on the 7x7 maps; single
+        // images: 49): the launch is a stream of the FILTERS through a few workgroups, each bound by its serial K loop
+        // (~110 ns per tap step: 72 us for K = 9216 whatever the tile).  64-cout tiles double the workgroups of the 128 x 128
+        // form of rounds 1-3 on the same fragment pack: 7x7 1024 -> 1024 at batch 24 148 -> 81 us, one image 147 -> 72
+        // (profiles/r04_sweep_small_m.txt; 128 x 64, 256 x 32 and 256 x 64 tie -- what is left there is a K split)
+        if (k128 && a.M < 384 * 8) {
+            const hipError_t e = haloq_ks<T>(a, s, bp);
+            if (e != hipErrorNotSupported) return e;
+            *bp = 256;
+            return haloq_pick<T, 4, 2, 2, 1, 128>(a, s);
+        }
         if (a.M >= 384 * 8) {   // what the cost model does not cover (64-byte K chunks; long rows that did not fit above)
             *bp = 384;
             e = k128 ? haloq_pick<T, 4, 2, 3, 2, 128>(a, s) : haloq_pick<T, 4, 2, 3, 2, 64>(a, s);
@@ -653,14 +821,6 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
         }
         if (e != hipErrorOutOfMemory) return e;
         (void)hipGetLastError();
-        // a handful of pixels (single-image detection: 49 at 7x7, 196 at 14x14): the launch is a stream of the FILTERS
-        // through a few workgroups -- 128 x 128 tiles give one pixel tile x Cout / 128 workgroups (8 for 1024 couts, each
-        // pulling 2.4 MB of filter fragments through one CU).  32-cout tiles: four times the workgroups on the same
-        // fragment pack (layout 1 is made of 32-cout tiles whatever the kernel's tile)
-        if (k128 && ((a.M + 127) / 128) * ((a.Cout + 127) / 128) < 64) {
-            *bp = 256;
-            return haloq_pick<T, 4, 1, 2, 1, 128>(a, s);
-        }
         *bp = 128;
         return haloq_pick<T, 2, 2, 2, 2, 64>(a, s);
     } else if (a.Cout > 32) {
@@ -729,6 +889,11 @@ hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t
         HQ(143, 4, 1, 4, 2, 128)      // 512 x 64, 4 waves of 128 px x 64 co
         HQ(144, 4, 1, 4, 2, 64)
         HQ(145, 8, 1, 3, 2, 128)      // 768 x 64
+        // round 4: a few hundred to a few thousand pixels (224x224 at the reference's batch 24, single images)
+        HQ(146, 4, 1, 2, 1, 128)      // 256 x 32, 4 waves
+        HQ(147, 2, 2, 2, 1, 128)      // 128 x 64, 4 waves
+        HQ(148, 2, 1, 2, 1, 128)      // 128 x 32, 2 waves
+        HQ(149, 2, 2, 2, 2, 128)      // 128 x 128, 4 waves, 128-byte chunks
     }
 #undef HQ
     return hipErrorInvalidValue;

@@ -46,7 +46,16 @@ struct ConvArgs {
     void* aff_out = nullptr;
     uint32_t aff_magW = 0, aff_magH = 0;   // m / W = (m * magW) >> shW for m < 2^31 (Granlund-Montgomery), same for H
     int aff_shW = 0, aff_shH = 0;
+    // K split over workgroups for launches of a few hundred to a few thousand pixels (conv_haloq.hip: haloq_ks): the
+    // caller lends ks_floats floats of scratch; the launcher decides whether and how deep to split (ks_splits is its own)
+    float* ks_scratch = nullptr;
+    size_t ks_floats = 0;
+    int ks_splits = 0;
 };
+// scratch floats a launch of M pixels x ldy couts may ask for (0: the K split never applies)
+size_t conv_ks_scratch_floats(int taps, int M, int ldy, int row_bytes);
+// split depth a launch of this shape takes when it is lent scratch (< 2: it runs un-split)
+int conv_ks_depth(int taps, int M, int Cout, int row_bytes);
 inline void conv_div_magic(uint32_t d, uint32_t* mag, int* sh) {
     int l = 0;
     while ((1u << l) < d) ++l;                    // ceil(log2 d)

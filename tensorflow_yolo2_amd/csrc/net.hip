@@ -111,6 +111,7 @@ struct y2_ctx {
     bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
     size_t o_infertab = 0;      // BnInferLayer per layer (one prepare launch for all inference-mode layers)
     size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0, o_slab = 0;
+    size_t o_ks = 0, ks_floats = 0;   // K-split partial tiles of small convolution launches (ConvArgs::ks_scratch)
     size_t o_gram = 0;          // first layer: Gram matrix of the input patches [48][48] + its slices / block partials
     bool gram_valid = false;    // the last forward computed it (training mode, pooled first layer): backward reuses it
     size_t slab_floats = 0;     // split-K partial tiles of the weight gradients (WgradArgs::slab)
@@ -221,6 +222,16 @@ static void plan(y2_ctx* c) {
     c->o_chkranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
     c->o_smallranges = take((c->L.size() + 1) * 2 * sizeof(unsigned));
     c->o_nfflag = take(256);
+    {   // K-split partial tiles of the small launches (conv_haloq.hip haloq_ks): forward and dgrad of every layer
+        size_t ks = 0;
+        for (auto& y : c->L) {
+            if (y.first3) continue;
+            ks = std::max(ks, conv_ks_scratch_floats(y.k * y.k, y.M, y.ldy, y.cin_s * (int)sz));
+            ks = std::max(ks, conv_ks_scratch_floats(y.k * y.k, y.M, y.cin, y.ldy * (int)sz));
+        }
+        c->ks_floats = ks;
+        c->o_ks = take(ks * sizeof(float));
+    }
     c->total_infer = off;
     // ---- training-only buffers
     for (size_t l = 0; l < c->L.size(); ++l) c->L[l].dyp = take(c->dy_geom((int)l).bytes(sz));
@@ -661,6 +672,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             if (training) { a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2; }
             a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.cin_s; a.M = y.M; a.Cout = y.cout; a.ldy = y.ldy;
             a.taps = y.k * y.k;
+            if (c->ks_floats) { a.ks_scratch = (float*)(c->ws + c->o_ks); a.ks_floats = c->ks_floats; }
             int bp = 0, rec = 0;
             // inference statistics, no pool, a consumer layer: scale / shift / leaky ride in the conv epilogue and the
             // activation goes straight into the consumer's bordered input (no y, no bn_act pass).  Training
@@ -919,12 +931,16 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.ldy; a.M = y.M; a.Cout = y.cin; a.ldy = y.cin;
                 a.taps = y.k * y.k;
                 a.is_dgrad = 1;
+                if (c->ks_floats) { a.ks_scratch = (float*)(c->ws + c->o_ks); a.ks_floats = c->ks_floats; }
                 int bp = 0;
                 const Layer& z = c->L[l > 0 ? l - 1 : 0];
                 // the BN-backward reduce of the layer below rides in this dgrad's epilogue (it needs that layer's
                 // conv output, scale and shift beside the dA tile the epilogue holds anyway); the first layer
                 // keeps its own recomputing reduce
-                const bool fuse = !no_fuse && l > 0 && l - 1 >= layer_lo && !z.first3 && z.ldy == y.cin;
+                // (a launch of a few hundred pixels splits its K range over workgroups instead -- conv_haloq.hip haloq_ks --
+                //  and leaves the reduce to the standalone kernel: 7x7 1024 -> 512 at batch 24: 81 us fused and un-split)
+                const bool ks = c->ks_floats && conv_ks_depth(a.taps, a.M, a.Cout, a.C * (int)sz) >= 2;
+                const bool fuse = !no_fuse && !ks && l > 0 && l - 1 >= layer_lo && !z.first3 && z.ldy == y.cin;
                 if (l == 1 && z.first3 && c->fopt.on && c->fopt.ctrl && c->lin1() && forked)
                     a.nonfinite = (unsigned*)(c->ws + c->o_nfflag);   // this launch stores dA_0: the early guard's view of layer 0
                 if (fuse) {
@@ -1215,7 +1231,7 @@ int y2_momentum_step(float* params, float* accum, const float* grads, size_t n, 
 // ---------------------------------------------------------------------------
 struct OpPlan {
     int Cin_p, Cdy, Cout_pad, Cin_pad, ldy;
-    size_t xp, wf, wd, y, dyp, dx, dw, slab, total;
+    size_t xp, wf, wd, y, dyp, dx, dw, slab, ks, ks_floats, total;
 };
 // split-K partial tiles of the op-level weight gradient (WgradArgs::slab): at most ~1,000 workgroups x one 64 x 32 x 9
 // (or 128 x 128) tile, as in the network plan -- the op-level gradients are then summed in a fixed order too
@@ -1239,6 +1255,9 @@ static OpPlan op_plan(int N, int H, int W, int Cin, int Cout, int k, int dtype) 
     p.dx = take((size_t)N * H * W * p.Cin_p * sz + 256);
     p.dw = take((size_t)k * k * p.Cin_p * Cout * sizeof(float));
     p.slab = take(kOpSlabFloats * sizeof(float));
+    p.ks_floats = std::max(conv_ks_scratch_floats(k * k, N * H * W, p.ldy, p.Cin_p * (int)sz),
+                           conv_ks_scratch_floats(k * k, N * H * W, p.Cin_p, p.Cdy * (int)sz));
+    p.ks = take(p.ks_floats * sizeof(float));
     p.total = off;
     return p;
 }
@@ -1274,6 +1293,7 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
     ConvArgs a{};
     a.x = xp; a.w = ws + p.wf; a.y = ws + p.y; a.bias = bias;
     a.N = N; a.H = H; a.W = W; a.C = p.Cin_p; a.M = N * H * W; a.Cout = Cout; a.ldy = p.ldy; a.taps = k * k;
+    if (p.ks_floats) { a.ks_scratch = (float*)(ws + p.ks); a.ks_floats = p.ks_floats; }
     HIPCHK(launch_conv(dtype, a, s));
     HIPCHK(launch_cast_to_f32(dtype, ws + p.y, y, (size_t)N * H * W, Cout, p.ldy, s));
     return Y2_OK;
@@ -1299,6 +1319,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
         a.x = dyp; a.w = ws + p.wd; a.y = ws + p.dx;
         a.N = N; a.H = H; a.W = W; a.C = p.Cdy; a.M = N * H * W; a.Cout = p.Cin_p; a.ldy = p.Cin_p; a.taps = k * k;
         a.is_dgrad = 1;
+        if (p.ks_floats) { a.ks_scratch = (float*)(ws + p.ks); a.ks_floats = p.ks_floats; }
         HIPCHK(launch_conv(dtype, a, s));
         HIPCHK(launch_cast_to_f32(dtype, ws + p.dx, dx, (size_t)N * H * W, Cin, p.Cin_p, s));
     }

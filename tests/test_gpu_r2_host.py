@@ -381,7 +381,7 @@ def test_ab_switches_select_equivalent_paths(tmp_path):
     switches = [{"Y2_NO_CONV_RF": "1"}, {"Y2_NO_WGRAD_SLAB": "1"}, {"Y2_XCD_CONV": "0", "Y2_XCD_WGRAD": "0"},
                 {"Y2_NO_BN_FIN_FUSE": "1"}, {"Y2_NO_FUSED_TRAIN_OP": "1"}, {"Y2_NO_BNBWD_FUSE": "1"},
                 {"Y2_NO_WGRAD_OVERLAP": "1"}, {"Y2_HALO_COMPACT": "1"}, {"Y2_HALOQ_1X1": "1"}, {"Y2_NO_HALOQ_52": "1"},
-                {"Y2_NO_CONV1_GRAM": "1"}, {"Y2_LEGACY_TILES": "1"}]      # round 4: Gram-matrix statistics, tile cost model
+                {"Y2_NO_CONV1_GRAM": "1"}, {"Y2_LEGACY_TILES": "1"}, {"Y2_NO_KSPLIT": "1"}]   # round 4: Gram-matrix statistics, tile cost model, K split of small launches
     for sw in switches:
         r = run(sw, "_".join(sw))
         assert tuple(r["ctrl"]) == (0, 1, 0), sw
@@ -398,9 +398,13 @@ def test_ab_switches_select_equivalent_paths(tmp_path):
         assert el < 3e-2 and eg < 0.5 and ep < 2e-2, (sw, el, eg, ep)
         # (Y2_HALO_COMPACT: the conflict-free LDS image of conv_haloq -- other addresses, the same products in the
         #  same order)
-        if any(k in sw for k in ("Y2_NO_FUSED_TRAIN_OP", "Y2_XCD_CONV", "Y2_NO_WGRAD_OVERLAP", "Y2_NO_BN_FIN_FUSE",
-                                 "Y2_HALO_COMPACT")):
+        if any(k in sw for k in ("Y2_NO_FUSED_TRAIN_OP", "Y2_XCD_CONV", "Y2_NO_WGRAD_OVERLAP", "Y2_NO_BN_FIN_FUSE")):
             assert el == 0.0 and eg == 0.0 and ep == 0.0, sw      # scheduling / same-order switches: the same bits
+        if "Y2_HALO_COMPACT" in sw:
+            # the same products in the same order in every launch it touches -- but the compact image has no K-split form
+            # (round 4: the 13x13 dgrads of this batch-16 step split their K range and leave the BN-backward reduce to the
+            # standalone kernel): other partial sums in the backward pass, the forward pass bit-identical
+            assert el == 0.0 and eg < 1e-2, sw
         if "Y2_NO_WGRAD_SLAB" in sw:
             assert el == 0.0 and eg < 1e-5, sw                    # float atomics: summation order only (observed 2.6e-7)
         if "Y2_NO_BNBWD_FUSE" in sw:

@@ -78,7 +78,10 @@ def test_first_layer_statistics_from_the_gram_matrix(N, hw, kind, dtype):
 
 @pytest.mark.parametrize("N,hw,cin,cout,k", [(128, 14, 256, 512, 3), (128, 7, 512, 1024, 3), (128, 7, 1024, 512, 3),
                                              (128, 28, 256, 128, 3), (128, 14, 512, 256, 3), (24, 20, 256, 512, 3),
-                                             (48, 10, 512, 1024, 3)])
+                                             (48, 10, 512, 1024, 3),
+                                             # K split over workgroups (fewer than 3072 pixels): single images, batch 24
+                                             (1, 7, 1024, 1024, 3), (1, 14, 256, 512, 3), (24, 7, 512, 1024, 3),
+                                             (3, 13, 1024, 1024, 3)])
 def test_tile_choice_shapes_in_network_inference_fold(N, hw, cin, cout, k):
     """The tiles the cost model of conv_haloq picks away from the 416x416 batch-64 defaults (512 x 128, 256 x 128,
     512 x 64, 256 x 64: configs[2] at batch 128, the 320 / 608 maps of configs[4]) as LAYERS: a two-layer stack in
@@ -115,3 +118,25 @@ def test_tile_choice_shapes_in_network_inference_fold(N, hw, cin, cout, k):
     ref = np.maximum(0.1 * z, z)
     got = outs[0][1].reshape(-1, cout)[torch.as_tensor(pts).cuda()].double().cpu().numpy()
     _obs.gate("folded inference layer %dx%d %d->%d N=%d" % (hw, hw, cin, cout, N), rel_to_max(got, ref), TOL)
+
+
+SMALL_M = [(1, 7, 1024, 1024), (1, 14, 256, 512), (24, 7, 512, 1024), (24, 7, 1024, 1024), (4, 14, 512, 256), (2, 26, 256, 512),
+           (1, 13, 1024, 1024), (16, 7, 128, 256)]
+
+
+@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("f32", 1e-5)])
+@pytest.mark.parametrize("N,hw,cin,cout", SMALL_M, ids=["%dx%d^2_%d-%d" % s for s in SMALL_M])
+def test_small_launches_k_split_vs_float64(N, hw, cin, cout, dtype, tol):
+    """3x3 layers with fewer than 3072 pixels (single-image detection, the reference's training batch 24 at 224x224:
+    src/pascal/pascal_train_darknet.py:26) run conv_haloq with the K range split over workgroups, fp32 partial tiles added
+    in split order (conv_haloq.hip haloq_ks): forward, dgrad and wgrad against float64 (tests/_shapes.py)"""
+    from _shapes import check_layer_shape
+    check_layer_shape(N, "small-M", 3, cin, cout, hw, "K-split", dtype=dtype, tol=tol)
+
+
+@pytest.mark.parametrize("N,hw,cin,cout,pool", [(24, 7, 512, 1024, 0), (1, 14, 256, 512, 1), (2, 13, 1024, 1024, 0)])
+def test_small_launches_k_split_in_network(N, hw, cin, cout, pool):
+    """the same as LAYERS in training mode: the batch statistics of a K-split launch come from one record over the stored
+    values (conv_ks_stats_kernel), then BN + leaky (+ pool) and the backward pass (tests/_shapes.py)"""
+    from _shapes import check_layer_in_network
+    check_layer_in_network(N, "small-M", 3, cin, cout, hw, pool, "K-split")
