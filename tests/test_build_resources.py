@@ -1,0 +1,65 @@
+"""CPU test of the BUILT code objects (no GPU): the register-level assumptions of the hand-scheduled kernels.
+
+csrc/conv_haloq.hip loads its filter fragments with inline-asm `global_load_dwordx4` and counts `s_waitcnt vmcnt(N)` by
+hand (the compiler would drain them behind every LDS-DMA).  The compiler believes the destination registers are valid
+when the asm statement ends, so a spill or re-materialisation of those registers between the load and the counted wait
+would read stale data.  A kernel that spills nothing and owns no scratch cannot do that: this test carves
+the gfx950 code object out of the fat binary of the built object and checks the kernels' metadata."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_metadata(obj):
+    """[(name, vgpr_count, vgpr_spill_count, private_segment_fixed_size)] of the gfx950 code object inside `obj`"""
+    tmp = obj + ".fatbin.tmp"
+    try:
+        subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", obj, tmp], check=True)
+        d = open(tmp, "rb").read()
+        assert d.startswith(b"__CLANG_OFFLOAD_BUNDLE__")
+        n = struct.unpack_from("<Q", d, 24)[0]
+        off, co = 32, None
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", d, off)
+            off += 24
+            triple = d[off:off + tl].decode()
+            off += tl
+            if "gfx950" in triple:
+                co = d[o:o + sz]
+        assert co is not None, "no gfx950 code object in " + obj
+        open(tmp, "wb").write(co)
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", tmp], check=True, capture_output=True, text=True).stdout
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    out = []
+    for block in notes.split("- .agpr_count:")[1:]:
+        g = lambda key: re.search(r"\.%s:\s+(\S+)" % key, block)
+        name = g("name")
+        if name:
+            out.append((name.group(1), int(g("vgpr_count").group(1)), int(g("vgpr_spill_count").group(1)),
+                        int(g("private_segment_fixed_size").group(1))))
+    return out
+
+
+def test_hand_counted_fragment_loads_never_meet_a_spill():
+    obj = os.path.join(ROOT, "tensorflow_yolo2_amd", "csrc", "conv_haloq.o")
+    if not (os.path.exists(obj) and os.path.exists(os.path.join(LLVM, "llvm-readelf"))):
+        pytest.skip("conv_haloq.o not built here (run __graft_entry__.build())")
+    meta = kernel_metadata(obj)
+    kernels = [m for m in meta if "conv_haloq" in m[0] and "kernel" in m[0]]
+    assert len(kernels) > 100, len(kernels)
+    bad = []
+    for name, vgpr, spill, scratch in kernels:
+        m = re.search(r"ELb([01])ELb([01])ELi(\d)E", name)
+        compact = bool(m and m.group(2) == "1")          # Y2_HALO_COMPACT / Y2_HALOQ_1X1: opt-in variants, not the default path
+        if (spill or scratch) and not compact:
+            bad.append((name, vgpr, spill, scratch))
+        assert vgpr <= 512, (name, vgpr)                  # the unified VGPR / AGPR file of a SIMD
+    assert not bad, "default-path conv_haloq kernels must not spill or own scratch: %r" % bad[:4]
