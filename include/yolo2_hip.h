@@ -69,6 +69,15 @@ int y2_bind(y2_ctx* ctx, float* params, float* grads, float* state, void* worksp
             int training, void* stream);
 /* loss-scale applied to half-precision gradients (1 = none); moving-variance Bessel switch */
 int y2_set_options(y2_ctx* ctx, float grad_scale, int bessel_moving_var);
+/* Round 4.  Per-layer activation slopes (max(slope*z, z): 0.1 = the reference's leaky ReLU, src/yolo2_nets/darknet.py:5,45;
+ * 0 = ReLU, 1 = no activation) and the batch-norm constants of the stack (defaults: tf.layers.batch_normalization's
+ * eps 1e-3 / momentum 0.99, darknet.py:39-44).  For stacks that restate slim's resnet_v1 bottleneck
+ * (src/slim_dir/nets/resnet_v1.py:99-112; arg scope src/slim_dir/nets/resnet_utils.py:230-257: conv2d without bias +
+ * batch_norm(decay 0.997, epsilon 1e-5) + ReLU, the unit's last conv without activation): slopes {0, 0, 1}, eps 1e-5,
+ * momentum 0.997, zero_bias_grad = 1 (the bias slots stay in the flat parameter layout; the caller keeps them at zero
+ * and they receive no gradient).  slopes == NULL keeps the current slopes; the 3-channel image layer only takes 0.1. */
+int y2_set_layer_options(y2_ctx* ctx, const float* slopes, int num_layers, float bn_eps, float bn_momentum,
+                         int zero_bias_grad);
 /* weight_variable / bias_variable / BN initial values (darknet.py:10-17): truncated
  * normal(0.1) re-drawn beyond 2 sigma, 0.1, gamma 1, beta 0, moving 0 / 1 */
 int y2_init_params(y2_ctx* ctx, uint64_t seed, void* stream);
@@ -157,6 +166,10 @@ int y2_passthrough_concat_backward(const float* dout, float* dfine, float* dcoar
 /* dst += src on fp32 buffers: the gradient of a tensor with two consumers (the 26x26x512 activation feeds the pool
  * and the passthrough) */
 int y2_accumulate(float* dst, const float* src, size_t n, void* stream);
+/* Round 4.  The join of a bottleneck unit, output = tf.nn.relu(shortcut + residual) (src/slim_dir/nets/resnet_v1.py:112),
+ * and its backward g = dout * [out > 0] (the gradient of both addends); fp32 tensors of n elements, 16-byte aligned. */
+int y2_add_relu(const float* a, const float* b, float* out, size_t n, void* stream);
+int y2_add_relu_backward(const float* dout, const float* out, float* g, size_t n, void* stream);
 /* scores [rows][classes] -> best score and class index per row (the class choice in front of the NMS of the YOLOv2
  * detector; ties: smallest index, as np.argmax in net_utils.py:418) */
 int y2_class_argmax(const float* scores, float* best, int* cls, int rows, int classes, void* stream);

@@ -31,14 +31,12 @@ print("loss", _l.cpu().numpy(), "dnet finite", torch.isfinite(dnet).all().item()
 m.grads.zero_()
 m.backward(dnet)
 torch.cuda.synchronize()
-off = 0
 bad = []
 for (name, shape, tr) in m.vars:
     if not tr:
         continue
-    k = int(np.prod(shape))
+    off, k = m.offset[name]
     g = m.grads[off:off + k]
     if not torch.isfinite(g).all():
         bad.append((name, int((~torch.isfinite(g)).sum()), k))
-    off += k
 print("non-finite gradient tensors:", bad[:12], "of", len(bad))

@@ -42,6 +42,7 @@ SIGNATURES = {
     "y2_workspace_bytes": (_sz, [_vp, _i]),
     "y2_bind": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "y2_set_options": (_i, [_vp, _f, _i]),
+    "y2_set_layer_options": (_i, [_vp, _vp, _i, _f, _f, _i]),
     "y2_init_params": (_i, [_vp, _u64, _vp]),
     "y2_params_changed": (_i, [_vp]),
     "y2_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
@@ -68,6 +69,8 @@ SIGNATURES = {
     "y2_passthrough_concat": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_passthrough_concat_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_accumulate": (_i, [_vp, _vp, _sz, _vp]),
+    "y2_add_relu": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "y2_add_relu_backward": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "y2_scale": (_i, [_vp, _sz, _f, _vp]),
     "y2_class_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "y2_decode_anchors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
                                              (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
-                        const float act = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+                        const float act = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
                         if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
                     }
                 }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
         } else {
             Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) r[e] = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+            for (int e = 0; e < EPC; ++e) r[e] = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
         }
         if (OUTF32) {
             float* o = (float*)a.out + (size_t)po * a.C;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalize
                     Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
-                        const float act = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+                        const float act = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
                         if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
                     }
                 }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalize
         } else {
             Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) r[e] = leaky01(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e]);
+            for (int e = 0; e < EPC; ++e) r[e] = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
         }
         Chunk<T> o;
 #pragma unroll
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                         for (int e = 0; e < EPC; ++e) {
                             // the pooled quantity is leaky(z): compare what the forward pass compared
                             const float yv = Elem<T>::to_f32(yc[d].v[e]);
-                            const float act = leaky01(fmaf(yv, sc[e], sh[e]));
+                            const float act = leaky_s(fmaf(yv, sc[e], sh[e]), a.slope);
                             if (act > amax[e]) {
                                 amax[e] = act;
                                 yb[e] = yv;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                     }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yb[e], sc[e], sh[e]));
+                    gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yb[e], sc[e], sh[e]), a.slope);
                     if (!APPLY) {
                         s1[e] += gz[e];
                         s2[e] = fmaf(gz[e], yb[e], s2[e]);
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float yv = Elem<T>::to_f32(v.v[e]);
-                    const float gz = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yv, sc[e], sh[e]));
+                    const float gz = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yv, sc[e], sh[e]), a.slope);
                     if (APPLY) {
                         o.v[e] = Elem<T>::from_f32(fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e])));
                     } else {
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         const float yv = Elem<T>::to_f32(yc[d].v[e]);
-                        const float act = leaky01(fmaf(yv, sc[e], sh[e]));
+                        const float act = leaky_s(fmaf(yv, sc[e], sh[e]), a.slope);
                         if (act > amax[e]) {
                             amax[e] = act;
                             yb[e] = yv;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
                     }
                 }
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yb[e], sc[e], sh[e]));
+            for (int e = 0; e < EPC; ++e) gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yb[e], sc[e], sh[e]), a.slope);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 if (!valid[d]) continue;
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const float yv = Elem<T>::to_f32(v.v[e]);
-                const float gz = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yv, sc[e], sh[e]));
+                const float gz = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yv, sc[e], sh[e]), a.slope);
                 o.v[e] = Elem<T>::from_f32(fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e])));
             }
             const size_t off = (bpix(n, ho, wo, a.H, a.W) * a.ldy + c0) * sizeof(T);

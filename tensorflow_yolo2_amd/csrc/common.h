@@ -133,6 +133,10 @@ Y2_DEV void glds16(const void* gptr, void* lds_wave_base) {
 Y2_DEV float wave_sum_xor(float v, int mask) { return v + __shfl_xor(v, mask, 64); }
 
 Y2_DEV float leaky01(float z) { return fmaxf(0.1f * z, z); }
+// the same with the slope as a parameter (round 4: layer options -- 0.1 the reference's leaky ReLU, darknet.py:5,45;
+// 0 = ReLU and 1 = no activation for slim's resnet_v1 bottlenecks, slim_dir/nets/resnet_v1.py:99-112)
+Y2_DEV float leaky_s(float z, float s) { return fmaxf(s * z, z); }
+Y2_DEV float leaky_slope_s(float z, float s) { return (s * z >= z) ? s : 1.0f; }
 // TF maximum(alpha*z, z): gradient to alpha*z where alpha*z >= z, i.e. z <= 0
 Y2_DEV float leaky01_slope(float z) { return (0.1f * z >= z) ? 0.1f : 1.0f; }
 

@@ -157,7 +157,7 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
                 const size_t bp = (size_t)m + r + (size_t)(n + 1) * (uint32_t)(a.W + 1) + 1;
                 Chunk<T> o;
 #pragma unroll
-                for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(leaky01(Elem<T>::to_f32(c.v[e]) * sc[e] + sh[e]));
+                for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(leaky_s(Elem<T>::to_f32(c.v[e]) * sc[e] + sh[e], a.aff_slope));
                 st_chunk<T>((char*)a.aff_out + (bp * a.ldy + cch) * SZ, o);
             }
         }
@@ -229,7 +229,7 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float yf = Elem<T>::to_f32(yv[it].v[e]);
-                    const float g = Elem<T>::to_f32(c.v[e]) * leaky01_slope(fmaf(yf, sc[e], sh[e]));
+                    const float g = Elem<T>::to_f32(c.v[e]) * leaky_slope_s(fmaf(yf, sc[e], sh[e]), a.bw_slope);
                     s1[e] += g;
                     s2[e] = fmaf(g, yf, s2[e]);
                 }

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_ks_finish_kernel(ConvArgs a, int spl
         const size_t bp = (size_t)m + r + (size_t)(n + 1) * (uint32_t)(a.W + 1) + 1;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            o[e] = Elem<T>::from_f32(leaky01(Elem<T>::to_f32(o[e]) * a.aff_scale[co + e] + a.aff_shift[co + e]));
+            o[e] = Elem<T>::from_f32(leaky_s(Elem<T>::to_f32(o[e]) * a.aff_scale[co + e] + a.aff_shift[co + e], a.aff_slope));
         T* dst = (T*)a.aff_out + bp * a.ldy + co;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dst[e] = o[e];

@@ -639,8 +639,8 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
                         const f32x4 h0 = *(const f32x4*)(a.aff_shift + cch), h1 = *(const f32x4*)(a.aff_shift + cch + 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            c.v[e] = Elem<T>::from_f32(leaky01(Elem<T>::to_f32(c.v[e]) * s0[e] + h0[e]));
-                            c.v[4 + e] = Elem<T>::from_f32(leaky01(Elem<T>::to_f32(c.v[4 + e]) * s1[e] + h1[e]));
+                            c.v[e] = Elem<T>::from_f32(leaky_s(Elem<T>::to_f32(c.v[e]) * s0[e] + h0[e], a.aff_slope));
+                            c.v[4 + e] = Elem<T>::from_f32(leaky_s(Elem<T>::to_f32(c.v[4 + e]) * s1[e] + h1[e], a.aff_slope));
                         }
                         dstp = (char*)a.aff_out + ((size_t)pb * a.ldy + cch) * SZ;
                     }
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float yf = Elem<T>::to_f32(yv.v[e]);
-                        const float g = Elem<T>::to_f32(c.v[e]) * leaky01_slope(fmaf(yf, bsc[e], bsh[e]));
+                        const float g = Elem<T>::to_f32(c.v[e]) * leaky_slope_s(fmaf(yf, bsc[e], bsh[e]), a.bw_slope);
                         s1[e] += g;
                         s2[e] = fmaf(g, yf, s2[e]);
                     }

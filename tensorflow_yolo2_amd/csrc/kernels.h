@@ -31,6 +31,7 @@ struct ConvArgs {
     const float* bw_scale = nullptr;
     const float* bw_shift = nullptr;
     float* bw_psum = nullptr;
+    float bw_slope = 0.1f;            // activation slope of that layer (leaky_slope_s)
     // non-null (plain-store launches): set to 1 when a stored value is inf / NaN -- the early overflow guard of
     // y2_backward_adam / _momentum watches the dgrad that feeds the first layer this way
     unsigned* nonfinite = nullptr;
@@ -44,6 +45,7 @@ struct ConvArgs {
     const float* aff_scale = nullptr;
     const float* aff_shift = nullptr;
     void* aff_out = nullptr;
+    float aff_slope = 0.1f;           // activation slope of this layer
     uint32_t aff_magW = 0, aff_magH = 0;   // m / W = (m * magW) >> shW for m < 2^31 (Granlund-Montgomery), same for H
     int aff_shW = 0, aff_shH = 0;
     // K split over workgroups for launches of a few hundred to a few thousand pixels (conv_haloq.hip: haloq_ks): the
@@ -319,6 +321,7 @@ struct BnActArgs {
     int N, H, W, C, ldy;
     int pool;             // 2x2/2 SAME max pool after the activation
     int out_f32;
+    float slope = 0.1f;   // activation: max(slope * z, z)
     void* ysel = nullptr; // pooled layers, training: the conv output at the window's (first) arg-max, [Mout][ldy] of T --
                           // what the BN-backward reduce needs of y (fused into the dgrad epilogue above this layer)
 };
@@ -345,6 +348,7 @@ struct BnBwdArgs {
     int training;         // batch statistics (1) or moving statistics (0)
     float inv_grad_scale;
     int P;                // number of partial blocks (set by launcher)
+    float slope = 0.1f;   // activation slope of the forward pass
 };
 int bn_bwd_partials(const BnBwdArgs& a);
 hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s);

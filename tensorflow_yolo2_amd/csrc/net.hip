@@ -54,8 +54,6 @@ static inline size_t part_rows_bound(int N, int H, int W, int cout) {
     return ((size_t)N * (H + 1) * (W + 1) + bp - 1) / bp;
 }
 
-constexpr float kBnEps = 1e-3f;       // tf.layers.batch_normalization defaults
-constexpr float kBnMomentum = 0.99f;
 
 // zero-bordered NHWC tensor with guard bands (see wgrad.hip): geometry helper
 struct PadGeom {
@@ -75,6 +73,7 @@ struct Layer {
     int cout_pad;    // rows of packed forward filter
     int cin_pad;     // rows of packed dgrad filter
     bool first3;     // Cin = 3 special layer
+    float slope = 0.1f;   // activation slope (y2_set_layer_options): 0.1 leaky (the reference), 0 ReLU, 1 none
     size_t pW, pb, pg, pbeta;  // float offsets into params / grads
     size_t smm, smv;           // float offsets into state
     // byte offsets into the workspace
@@ -88,6 +87,8 @@ struct y2_ctx {
     int outN, outH, outW, outC;
     float grad_scale = 1.f;
     int bessel = 0;
+    float bn_eps = 1e-3f, bn_momentum = 0.99f;   // tf.layers.batch_normalization defaults (y2_set_layer_options)
+    int zero_bias_grad = 0;                       // the conv biases are not variables of the graph (slim conv2d + batch_norm)
     // bound memory
     float* params = nullptr;
     float* grads = nullptr;
@@ -564,6 +565,28 @@ int y2_set_options(y2_ctx* c, float grad_scale, int bessel) {
     return Y2_OK;
 }
 
+// Per-layer activation slopes and the batch-norm constants of the stack (round 4).  Defaults = the reference's
+// darknet.py: leaky 0.1 (:5,45), tf.layers.batch_normalization eps 1e-3 / momentum 0.99 (:39-44), a conv bias per layer
+// (:33-35).  slim's resnet_v1 bottlenecks (src/slim_dir/nets/resnet_v1.py:99-112, resnet_utils.py:230-257 arg scope) are
+// conv2d(no bias) + batch_norm(decay 0.997, epsilon 1e-5) + ReLU, the last one of a unit without activation: slopes 0
+// (ReLU) / 1 (none), eps 1e-5, momentum 0.997, zero_bias_grad = 1 (the bias slots stay in the flat layout, the caller
+// keeps them at zero and they receive no gradient).  slopes == NULL keeps the current slopes.
+int y2_set_layer_options(y2_ctx* c, const float* slopes, int num_layers, float bn_eps, float bn_momentum,
+                         int zero_bias_grad) {
+    if (slopes && num_layers != (int)c->L.size()) return fail(Y2_ERR_ARG, "one slope per layer (%d layers)", (int)c->L.size());
+    if (!(bn_eps > 0.f) || !(bn_momentum >= 0.f && bn_momentum < 1.f)) return fail(Y2_ERR_ARG, "bad batch-norm constants");
+    if (slopes)
+        for (size_t l = 0; l < c->L.size(); ++l) {
+            if (!(slopes[l] >= 0.f && slopes[l] <= 1.f)) return fail(Y2_ERR_ARG, "layer %d: slope must be in [0, 1]", (int)l);
+            if (c->L[l].first3 && slopes[l] != 0.1f)
+                return fail(Y2_ERR_ARG, "the 3-channel image layer's kernels implement the reference's leaky 0.1 only");
+        }
+    if (slopes)
+        for (size_t l = 0; l < c->L.size(); ++l) c->L[l].slope = slopes[l];
+    c->bn_eps = bn_eps; c->bn_momentum = bn_momentum; c->zero_bias_grad = zero_bias_grad ? 1 : 0;
+    return Y2_OK;
+}
+
 int y2_init_params(y2_ctx* c, uint64_t seed, void* stream) {
     if (!c->params) return fail(Y2_ERR_STATE, "bind buffers first");
     hipStream_t s = (hipStream_t)stream;
@@ -627,7 +650,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
         int max_c = 0;
         for (const Layer& y : c->L) max_c = y.cout > max_c ? y.cout : max_c;
         HIPCHK(launch_bn_infer_prepare_all((const BnInferLayer*)(c->ws + c->o_infertab), nl, max_c, train_core, train_head,
-                                           kBnEps, s));
+                                           c->bn_eps, s));
     }
     for (int l = 0; l < nl; ++l) {
         c->prof_layer = l;
@@ -680,6 +703,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             if (!training && !y.pool && l + 1 < nl && !c->bound_training && y.ldy == c->L[l + 1].cin_s &&
                 conv_affine_ok(c->dtype, a)) {
                 conv_set_affine(a, scale, shift, c->ws + c->L[l + 1].xin + c->in_geom(l + 1).base_off(sz));
+                a.aff_slope = y.slope;
                 folded = true;
             }
             { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }
@@ -697,7 +721,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd;
             f.var = stat + 6 * y.ldy;
             f.scratch = (float*)(c->ws + c->o_part_scratch);
-            f.eps = kBnEps; f.momentum = kBnMomentum; f.update_moving = update_moving ? 1 : 0; f.bessel = c->bessel;
+            f.eps = c->bn_eps; f.momentum = c->bn_momentum; f.update_moving = update_moving ? 1 : 0; f.bessel = c->bessel;
         }
         // short partial lists: the merge rides in the apply pass (bn.hip bn_fin_act_kernel)
         static const bool no_fin_fuse = getenv("Y2_NO_BN_FIN_FUSE") != nullptr;
@@ -733,6 +757,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
         BnActArgs b{};
         b.y = c->ws + y.y; b.scale = scale; b.shift = shift;
         b.N = c->N; b.H = y.H; b.W = y.W; b.C = y.cout; b.ldy = y.ldy; b.pool = y.pool;
+        b.slope = y.slope;
         if (l + 1 < nl) {
             b.out = c->ws + c->L[l + 1].xin + c->in_geom(l + 1).base_off(sz);
             b.out_f32 = 0;
@@ -767,7 +792,7 @@ int y2_update_moving_stats(y2_ctx* c, void* stream) {
         const Layer& y = c->L[l];
         const float* stat = (const float*)(c->ws + y.stat);
         HIPCHK(launch_bn_update_moving(stat + 2 * y.ldy, stat + 6 * y.ldy, c->state + y.smm, c->state + y.smv, y.cout,
-                                       kBnMomentum, s));
+                                       c->bn_momentum, s));
     }
     c->moving_pending = false;
     return Y2_OK;
@@ -833,6 +858,8 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         b.N = c->N; b.H = y.H; b.W = y.W; b.C = y.cout; b.ldy = y.ldy;
         b.ldd = y.ldy;
         b.pool = y.pool; b.training = c->fwd_training[l]; b.inv_grad_scale = inv_gs;
+        b.slope = y.slope;
+        if (c->zero_bias_grad) b.dbias = nullptr;      // stays zero from y2_bind: the bias is not a variable of this graph
         const bool fused1 = y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz());
         const bool rec1 = y.first3 && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
                           conv1_pool_ok(y.H, y.W, y.pool, y.cout);
@@ -947,6 +974,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                     float* zs = (float*)(c->ws + z.stat);
                     a.bw_y = c->ws + (z.pool ? z.ysel : z.y);   // same pixel grid as this launch's output either way
                     a.bw_scale = zs; a.bw_shift = zs + z.ldy; a.bw_psum = psum;
+                    a.bw_slope = z.slope;
                 }
                 int rec = 0;
                 { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }

@@ -407,12 +407,33 @@ __global__ void rn_maxpool3_kernel(const float* __restrict__ x, float* __restric
         if (y) y[i] = best;
     }
 }
-// backward as a GATHER (the windows overlap, stride 2 < 3: the scatter form added into dx with float atomics, the one
-// order-dependent sum left in the ResNet swap): every input element looks at the <= 4 windows that contain it, finds
-// each window's first maximum in row-major order as the forward pass does, and takes dy where that is itself; the
-// contributions are added in window order.  No pre-zeroed dx.
-__global__ void rn_maxpool3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
-                                       int N, int H, int W, int C) {
+// backward as a GATHER in two passes (the windows overlap, stride 2 < 3: the scatter form added into dx with float
+// atomics, the one order-dependent sum left in the ResNet swap).  Pass 1: every window's first maximum in row-major
+// order, as the forward pass finds it, as a byte 3 * dh + dw.  Pass 2: every input element looks at the <= 4 windows
+// that contain it and takes dy where the window's byte names it; contributions added in window order.  No pre-zeroed dx.
+__global__ void rn_maxpool3_arg_kernel(const float* __restrict__ x, unsigned char* __restrict__ arg, int N, int H, int W, int C) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int ph = ((Ho - 1) * 2 + 3 - H > 0 ? (Ho - 1) * 2 + 3 - H : 0) / 2;
+    const int pw = ((Wo - 1) * 2 + 3 - W > 0 ? (Wo - 1) * 2 + 3 - W : 0) / 2;
+    const size_t total = (size_t)N * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t p = i / C;
+        const int wo = (int)(p % Wo), ho = (int)((p / Wo) % Ho), n = (int)(p / ((size_t)Wo * Ho));
+        float best = -INFINITY;
+        int a = 0;
+        for (int dh = 0; dh < 3; ++dh)
+            for (int dw = 0; dw < 3; ++dw) {
+                const int h = ho * 2 + dh - ph, w = wo * 2 + dw - pw;
+                if (h < 0 || h >= H || w < 0 || w >= W) continue;
+                const float v = x[(((size_t)n * H + h) * W + w) * C + c];
+                if (v > best) { best = v; a = 3 * dh + dw; }
+            }
+        arg[i] = (unsigned char)a;
+    }
+}
+__global__ void rn_maxpool3_bwd_kernel(const unsigned char* __restrict__ arg, const float* __restrict__ dy,
+                                       float* __restrict__ dx, int N, int H, int W, int C) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int ph = ((Ho - 1) * 2 + 3 - H > 0 ? (Ho - 1) * 2 + 3 - H : 0) / 2;
     const int pw = ((Wo - 1) * 2 + 3 - W > 0 ? (Wo - 1) * 2 + 3 - W : 0) / 2;
@@ -421,23 +442,14 @@ __global__ void rn_maxpool3_bwd_kernel(const float* __restrict__ x, const float*
         const int c = (int)(i % C);
         const size_t p = i / C;
         const int w = (int)(p % W), h = (int)((p / W) % H), n = (int)(p / ((size_t)W * H));
-        const float xv = x[i];
         float g = 0.f;
-        // windows (ho, wo) with ho*2 - ph <= h <= ho*2 - ph + 2
         const int ho_lo = (h + ph - 2 + 1) >> 1, ho_hi = (h + ph) >> 1;     // ceil((h + ph - 2) / 2) .. floor((h + ph) / 2)
         const int wo_lo = (w + pw - 2 + 1) >> 1, wo_hi = (w + pw) >> 1;
         for (int ho = ho_lo < 0 ? 0 : ho_lo; ho <= ho_hi && ho < Ho; ++ho)
             for (int wo = wo_lo < 0 ? 0 : wo_lo; wo <= wo_hi && wo < Wo; ++wo) {
-                float best = -INFINITY;
-                size_t arg = 0;
-                for (int dh = 0; dh < 3; ++dh)
-                    for (int dw = 0; dw < 3; ++dw) {
-                        const int hh = ho * 2 + dh - ph, ww = wo * 2 + dw - pw;
-                        if (hh < 0 || hh >= H || ww < 0 || ww >= W) continue;
-                        const size_t j = (((size_t)n * H + hh) * W + ww) * C + c;
-                        if (x[j] > best) { best = x[j]; arg = j; }
-                    }
-                if (arg == i && xv == best) g += dy[(((size_t)n * Ho + ho) * Wo + wo) * C + c];
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * C + c;
+                const int a = arg[o];
+                if (ho * 2 + a / 3 - ph == h && wo * 2 + a % 3 - pw == w) g += dy[o];
             }
         dx[i] = g;
     }
@@ -673,6 +685,45 @@ int y2_batch_norm_backward(const float* dy, const float* y, const float* x, floa
     return Y2_OK;
 }
 
+// relu(a + b) and its backward g = dout * [out > 0] (the join of a bottleneck unit: resnet_v1.py:112 output =
+// tf.nn.relu(shortcut + residual)); fp32, 16-byte accesses
+__global__ void rn_add_relu_kernel(const float4* __restrict__ a, const float4* __restrict__ b, float4* __restrict__ o,
+                                   size_t n4, const float* as, const float* bs, float* os, size_t tail0, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 x = a[i], y = b[i];
+        o[i] = make_float4(fmaxf(x.x + y.x, 0.f), fmaxf(x.y + y.y, 0.f), fmaxf(x.z + y.z, 0.f), fmaxf(x.w + y.w, 0.f));
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) os[i] = fmaxf(as[i] + bs[i], 0.f);
+}
+__global__ void rn_add_relu_bwd_kernel(const float4* __restrict__ d, const float4* __restrict__ out, float4* __restrict__ g,
+                                       size_t n4, const float* ds, const float* os, float* gs, size_t tail0, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 x = d[i], y = out[i];
+        g[i] = make_float4(y.x > 0.f ? x.x : 0.f, y.y > 0.f ? x.y : 0.f, y.z > 0.f ? x.z : 0.f, y.w > 0.f ? x.w : 0.f);
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) gs[i] = os[i] > 0.f ? ds[i] : 0.f;
+}
+int y2_add_relu(const float* a, const float* b, float* out, size_t n, void* stream) {
+    if (!a || !b || !out) return rfail(Y2_ERR_ARG, "null tensor");
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) != 0) return rfail(Y2_ERR_ARG, "tensors must be 16-byte aligned");
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(rn_add_relu_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)a,
+                       (const float4*)b, (float4*)out, n4, a, b, out, n4 * 4, n);
+    RCHK(hipGetLastError());
+    return Y2_OK;
+}
+int y2_add_relu_backward(const float* dout, const float* out, float* g, size_t n, void* stream) {
+    if (!dout || !out || !g) return rfail(Y2_ERR_ARG, "null tensor");
+    if ((((uintptr_t)dout | (uintptr_t)out | (uintptr_t)g) & 15) != 0) return rfail(Y2_ERR_ARG, "tensors must be 16-byte aligned");
+    const size_t n4 = n / 4;
+    hipLaunchKernelGGL(rn_add_relu_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
+                       (const float4*)out, (float4*)g, n4, dout, out, g, n4 * 4, n);
+    RCHK(hipGetLastError());
+    return Y2_OK;
+}
+
 int y2_subsample(const float* x, float* y, int N, int H, int W, int C, int factor, int forward, void* stream) {
     if (!x || !y || factor < 1) return rfail(Y2_ERR_ARG, "bad arguments");
     const int Ho = (H + factor - 1) / factor, Wo = (W + factor - 1) / factor;
@@ -692,8 +743,11 @@ int y2_maxpool3x3s2(const float* x, float* y, int N, int H, int W, int C, void* 
 }
 int y2_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, int H, int W, int C, void* stream) {
     if (!x || !dy || !dx) return rfail(Y2_ERR_ARG, "null tensor");
-    const size_t total = (size_t)N * H * W * C;
-    hipLaunchKernelGGL(rn_maxpool3_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, N, H, W, C);
+    const size_t total = (size_t)N * H * W * C, outs = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    unsigned char* arg = (unsigned char*)op_scratch((hipStream_t)stream, outs);
+    if (!arg) return rfail(Y2_ERR_HIP, "max pool backward: no scratch memory for the arg-max bytes");
+    hipLaunchKernelGGL(rn_maxpool3_arg_kernel, dim3(grid_for(outs)), dim3(256), 0, (hipStream_t)stream, x, arg, N, H, W, C);
+    hipLaunchKernelGGL(rn_maxpool3_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, arg, dy, dx, N, H, W, C);
     RCHK(hipGetLastError());
     return Y2_OK;
 }

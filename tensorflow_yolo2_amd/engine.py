@@ -152,6 +152,16 @@ class Network:
         check(self.lib.y2_bind(self.h, _ptr(self.params), _ptr(self.grads), _ptr(self.state), _ptr(self.workspace),
                                self.ws_bytes, int(self.training), _stream()))
 
+    def set_layer_options(self, slopes=None, bn_eps=1e-3, bn_momentum=0.99, zero_bias_grad=False):
+        """per-layer activation slopes (0.1 leaky = the reference, 0 ReLU, 1 none) and the stack's batch-norm constants
+        (y2_set_layer_options; defaults = tf.layers.batch_normalization's)"""
+        arr = None
+        if slopes is not None:
+            assert len(slopes) == self.num_layers
+            arr = (C.c_float * self.num_layers)(*[float(v) for v in slopes])
+        check(self.lib.y2_set_layer_options(self.h, arr, self.num_layers, float(bn_eps), float(bn_momentum),
+                                            int(bool(zero_bias_grad))))
+
     def set_grad_scale(self, grad_scale):
         self.grad_scale = float(grad_scale)
         check(self.lib.y2_set_options(self.h, self.grad_scale, int(self._bessel)))
@@ -617,6 +627,24 @@ def passthrough_concat_backward(dout, cf):
     dcoarse = torch.empty((n, h, w, cc), dtype=torch.float32, device=dout.device)
     check(lib.y2_passthrough_concat_backward(_ptr(dout), _ptr(dfine), _ptr(dcoarse), n, h, w, cf, cc, _stream()))
     return dfine, dcoarse
+
+
+def add_relu(a, b):
+    """relu(a + b): the join of a ResNet bottleneck unit (slim_dir/nets/resnet_v1.py:112)"""
+    lib = _lib.load()
+    assert a.is_cuda and a.dtype == b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    out = torch.empty_like(a)
+    check(lib.y2_add_relu(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream()))
+    return out
+
+
+def add_relu_backward(dout, out):
+    """dout * [out > 0]: the gradient of both addends of add_relu"""
+    lib = _lib.load()
+    assert dout.is_cuda and dout.dtype == out.dtype == torch.float32 and dout.is_contiguous() and out.is_contiguous()
+    g = torch.empty_like(dout)
+    check(lib.y2_add_relu_backward(_ptr(dout), _ptr(out), _ptr(g), dout.numel(), _stream()))
+    return g
 
 
 def accumulate(dst, src):

@@ -384,18 +384,16 @@ def save_resnet_variables(model, path, with_optimizer=True):
     blob = {}
     if getattr(model, "graph", False):
         model._follow_ctrl()
-    t_off = 0
     m_host = model.m.detach().cpu().numpy() if with_optimizer else None
     v_host = model.v.detach().cpu().numpy() if with_optimizer else None
     for (name, shape, trainable) in model.vars:
         tfname = resnet_tf_name(name)
         blob[tfname] = model.p[name].detach().cpu().numpy().copy()
         if trainable:
-            n = int(np.prod(shape))
+            t_off, n = model.offset[name]                   # the flat layout may hold slots that are not variables
             if with_optimizer:
                 blob[tfname + "/Adam"] = m_host[t_off:t_off + n].reshape(shape).copy()
                 blob[tfname + "/Adam_1"] = v_host[t_off:t_off + n].reshape(shape).copy()
-            t_off += n
     if with_optimizer:
         blob["beta1_power"] = np.float32(np.float64(0.9) ** (model.t + 1))       # TF1: beta^(t+1) after t applies
         blob["beta2_power"] = np.float32(np.float64(0.999) ** (model.t + 1))
@@ -427,14 +425,12 @@ def restore_resnet_variables(model, path, exclude=(), with_optimizer=True):
     trainable = [(n, sh) for (n, sh, t) in model.vars if t]
     if with_optimizer and all(resnet_tf_name(n) + "/Adam" in have and resnet_tf_name(n) + "/Adam_1" in have
                               for n, _ in trainable):
-        m_host = np.empty(model.m.numel(), np.float32)
-        v_host = np.empty(model.v.numel(), np.float32)
-        off = 0
+        m_host = np.zeros(model.m.numel(), np.float32)
+        v_host = np.zeros(model.v.numel(), np.float32)
         for n, sh in trainable:
-            k = int(np.prod(sh))
+            off, k = model.offset[n]
             m_host[off:off + k] = np.asarray(snap[resnet_tf_name(n) + "/Adam"], np.float32).reshape(-1)
             v_host[off:off + k] = np.asarray(snap[resnet_tf_name(n) + "/Adam_1"], np.float32).reshape(-1)
-            off += k
         model.m.copy_(torch.as_tensor(m_host).to(model.m.device))
         model.v.copy_(torch.as_tensor(v_host).to(model.v.device))
         if "adam_step" in have:
@@ -444,6 +440,8 @@ def restore_resnet_variables(model, path, exclude=(), with_optimizer=True):
                                       snap["beta2_power"] if "beta2_power" in have else None)
         model.t = t
         model.ctrl[1] = t                               # the guarded update keeps its step count on the device
+    if hasattr(model, "params_changed"):
+        model.params_changed()                          # fused stacks re-pack their filters from the restored values
     return restored, kept
 
 

@@ -25,8 +25,13 @@ BLOCKS_50 = [("block1", [(256, 64, 1)] * 2 + [(256, 64, 2)]),
              ("block4", [(2048, 512, 1)] * 3)]
 
 
-def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, feat_hw=7):
-    """(name, shape, trainable) in slim's creation order"""
+HIDDEN = "/_unused_bias"      # flat-layout slot behind a bottleneck filter (fused stacks: see ResNet50Yolo), never a variable
+
+
+def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, feat_hw=7, hidden_bias=False):
+    """(name, shape, trainable) in slim's creation order.  hidden_bias: every bottleneck convolution is followed by a
+    slot of `cout` floats named <conv>/_unused_bias -- the conv-bias position of the library's [W, b, gamma, beta] layer
+    layout, kept at zero (slim's conv2d has no bias under batch_norm); such entries are layout only, not variables"""
     def bn(scope, c):
         s = scope.rstrip("/") + "/BatchNorm/"
         return [(s + "gamma", (c,), True), (s + "beta", (c,), True), (s + "moving_mean", (c,), False),
@@ -36,11 +41,12 @@ def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, 
     for bname, units in blocks:
         for i, (depth, db, _stride) in enumerate(units):
             p = "%s/unit_%d/bottleneck_v1/" % (bname, i + 1)
+            def conv(scope, k, ci, co):
+                hb = [(p + scope + HIDDEN, (co,), True)] if hidden_bias else []
+                return [(p + scope + "/weights", (k, k, ci, co), True)] + hb + bn(p + scope, co)
             if depth != cin:
-                out += [(p + "shortcut/weights", (1, 1, cin, depth), True)] + bn(p + "shortcut", depth)
-            out += [(p + "conv1/weights", (1, 1, cin, db), True)] + bn(p + "conv1", db)
-            out += [(p + "conv2/weights", (3, 3, db, db), True)] + bn(p + "conv2", db)
-            out += [(p + "conv3/weights", (1, 1, db, depth), True)] + bn(p + "conv3", depth)
+                out += conv("shortcut", 1, cin, depth)
+            out += conv("conv1", 1, cin, db) + conv("conv2", 3, db, db) + conv("conv3", 1, db, depth)
             cin = depth
     flat = feat_hw * feat_hw * cin
     out += [("yolo_fc1/weights", (flat, fc_hidden), True), ("yolo_fc1/biases", (fc_hidden,), True),
@@ -53,7 +59,7 @@ class ResNet50Yolo:
 
     def __init__(self, batch, image_size=224, B=2, num_class=20, dtype="f32", blocks=None, root_depth=64,
                  fc_hidden=4096, seed=0, device="cuda:0", learning_rate=0.0005, keep_prob=0.5, loss_scale=None,
-                 graph=False, graph_check_every=16):
+                 graph=False, graph_check_every=16, fused=None):
         """dtype: arithmetic of the convolution / FC contractions.  "f32" (default: the reference's precision).  With
         "f16" the gradient of the loss is multiplied by a dynamic loss scale before the backward pass (activation
         gradients 50 layers deep at batch 4 fall below f16's normal range otherwise), the scale is divided out inside
@@ -64,23 +70,39 @@ class ResNet50Yolo:
         self.dtype, self.device, self.keep_prob = dtype, torch.device(device), keep_prob
         self.blocks = blocks or BLOCKS_50
         self.out_c = 5 * B + num_class
+        # fused (round 4; default in the half-precision modes when every channel count fits the stack executor): the
+        # stride-1 bottleneck units run as native conv-BN-activation STACKS of the library (engine.Network on views of
+        # the flat buffers: conv1 1x1 ReLU, conv2 3x3 ReLU, conv3 1x1 without activation; the projection shortcut a
+        # one-layer stack) -- half-precision bordered activations between the three convolutions, batch statistics
+        # from the conv epilogues, BN-backward sums in the dgrad epilogues, split-K slab weight gradients -- joined by
+        # add + ReLU.  The three stride-2 units, the root and the FC head stay on the graph-level operators.
+        if fused is None:
+            fused = dtype != "f32" and self._stacks_fit(self.blocks, root_depth)
+        self.fused = bool(fused)
         self.vars = variable_list(self.blocks, root_depth, fc_hidden, self.S * self.S * self.out_c, self.S)
-        n_train = sum(int(np.prod(s)) for (_n, s, t) in self.vars if t)
-        n_state = sum(int(np.prod(s)) for (_n, s, t) in self.vars if not t)
+        self.layout = variable_list(self.blocks, root_depth, fc_hidden, self.S * self.S * self.out_c, self.S,
+                                    hidden_bias=self.fused)
+        n_train = sum(int(np.prod(s)) for (_n, s, t) in self.layout if t)
+        n_state = sum(int(np.prod(s)) for (_n, s, t) in self.layout if not t)
         self.params = torch.zeros(n_train, dtype=torch.float32, device=self.device)      # ONE flat buffer: one Adam
         self.grads = torch.zeros(n_train, dtype=torch.float32, device=self.device)
         self.state = torch.zeros(n_state, dtype=torch.float32, device=self.device)
         self.p, self.g = {}, {}
+        self.offset, self.state_offset = {}, {}          # name -> (start, count) in params / grads / m / v, in state
         ot = os_ = 0
-        for (name, shape, trainable) in self.vars:
+        for (name, shape, trainable) in self.layout:
             n = int(np.prod(shape))
             if trainable:
-                self.p[name] = self.params[ot:ot + n].view(shape)
-                self.g[name] = self.grads[ot:ot + n].view(shape)
+                self.offset[name] = (ot, n)
+                if not name.endswith(HIDDEN):
+                    self.p[name] = self.params[ot:ot + n].view(shape)
+                    self.g[name] = self.grads[ot:ot + n].view(shape)
                 ot += n
             else:
+                self.state_offset[name] = (os_, n)
                 self.p[name] = self.state[os_:os_ + n].view(shape)
                 os_ += n
+        self._stacks = {}                                 # unit scope -> (main stack, projection stack or None)
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.t = 0
@@ -101,6 +123,46 @@ class ResNet50Yolo:
         self._eager_on_gstream, self._since_check, self._skipped_seen = 0, 0, 0
         self.graph_check_every = int(graph_check_every)
         self._seed_dev = torch.tensor([self.drop_seed], dtype=torch.int64, device=self.device) if self.graph else None
+
+    # ---- fused bottleneck units -----------------------------------------------
+    @staticmethod
+    def _stacks_fit(blocks, root_depth):
+        """channel rules of the stack executor (csrc/net.hip y2_ctx_create): inputs in multiples of 32, above 128 in
+        multiples of 128"""
+        ok = lambda c: c % 32 == 0 and (c <= 128 or c % 128 == 0)
+        cin = root_depth
+        for _b, units in blocks:
+            for (depth, db, _st) in units:
+                if not (ok(cin) and ok(db) and ok(depth) and depth <= 2048):
+                    return False
+                cin = depth
+        return True
+
+    def _stack_for(self, scope, hw, cin, depth, db):
+        """(main stack, projection stack) of a stride-1 unit at hw x hw, created on first use"""
+        key = (scope, hw)
+        if key not in self._stacks:
+            def make(first, last, spec, slopes):
+                p0 = self.offset[scope + first + "/weights"][0]
+                pe = sum(self.offset[scope + last + "/BatchNorm/beta"])
+                s0 = self.state_offset[scope + first + "/BatchNorm/moving_mean"][0]
+                se = sum(self.state_offset[scope + last + "/BatchNorm/moving_variance"])
+                net = E.Network(spec, self.batch, hw, hw, dtype=self.dtype, core_layers=len(spec), training=True,
+                                device=str(self.device), grad_scale=1.0,
+                                buffers=(self.params[p0:pe], self.grads[p0:pe], self.state[s0:se]))
+                net.set_layer_options(slopes, BN_EPS, BN_DECAY, zero_bias_grad=True)
+                return net
+            main = make("conv1", "conv3", [(1, cin, db, 0), (3, db, db, 0), (1, db, depth, 0)], [0.0, 0.0, 1.0])
+            proj = make("shortcut", "shortcut", [(1, cin, depth, 0)], [1.0]) if depth != cin else None
+            self._stacks[key] = (main, proj)
+        return self._stacks[key]
+
+    def params_changed(self):
+        """the flat parameter buffer moved (optimizer step, load, restore): the stacks re-pack their filters"""
+        for main, proj in self._stacks.values():
+            main.params_changed()
+            if proj is not None:
+                proj.params_changed()
 
     # ---- variables ---------------------------------------------------------
     def init_params(self, seed=0):
@@ -124,10 +186,12 @@ class ResNet50Yolo:
             else:
                 val = np.zeros(shape, np.float32)
             self.p[name].copy_(torch.as_tensor(val))
+        self.params_changed()
 
     def load_params(self, params):
         for name, val in params.items():
             self.p[name].copy_(torch.as_tensor(np.asarray(val, np.float32)).to(self.device))
+        self.params_changed()
 
     def export_params(self):
         return {k: v.detach().cpu().numpy().copy() for k, v in self.p.items()}
@@ -192,6 +256,15 @@ class ResNet50Yolo:
         for bname, units in self.blocks:
             for i, (depth, db, stride) in enumerate(units):                                  # resnet_v1.py:99-112
                 sc = "%s/unit_%d/bottleneck_v1/" % (bname, i + 1)
+                if self.fused and stride == 1:
+                    main, proj = self._stack_for(sc, int(x.shape[1]), int(x.shape[3]), depth, db)
+                    xin = x.contiguous()
+                    r = main.forward(xin, is_training, is_training, update_moving=update_moving)
+                    short = proj.forward(xin, is_training, is_training, update_moving=update_moving) if proj is not None else xin
+                    out = E.add_relu(r, short)
+                    tape.append(("fused", main, proj, out))
+                    x = out
+                    continue
                 unit = {"in": x, "stride": stride}
                 if depth == x.shape[3]:
                     shortcut = E.subsample(x, stride)
@@ -238,7 +311,13 @@ class ResNet50Yolo:
                                               dw_out=self.g["yolo_fc1/weights"])
         dx = dflat.reshape(feat.shape).contiguous()
         for rec in reversed(self.tape[:-1]):
-            if rec[0] == "unit":
+            if rec[0] == "fused":
+                _k, main, proj, out = rec
+                g = E.add_relu_backward(dx.contiguous(), out)          # d(relu(r + s)) = dout * [out > 0], to both branches
+                dxin = main.backward_input(g)
+                dsx = proj.backward_input(g) if proj is not None else g
+                dx = E.accumulate(dxin, dsx)
+            elif rec[0] == "unit":
                 u = rec[1]
                 c1, b1, c2, b2, c3, b3 = u["res"]
                 da, dshort = self._bn_backward(b3, dx)
@@ -296,6 +375,7 @@ class ResNet50Yolo:
         E.check(lib.y2_grad_check_full(E._ptr(self.grads), n, E._ptr(self.ctrl), E._stream()))
         E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
                                          E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+        self.params_changed()       # the fused stacks re-pack their filters at the top of the next forward (captured with it)
         self.tape = None
         return loss, ious, mask
 
@@ -366,12 +446,14 @@ class ResNet50Yolo:
             self.t += 1
             E.check(lib.y2_adam_step(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n, self.t,
                                      self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+            self.params_changed()
             return loss, ious, mask
         # half precision: full overflow scan, then the guarded update (skipped as a whole on the device when any
         # gradient is inf / NaN; the step counter and TF's lr_t live in ctrl)
         E.check(lib.y2_grad_check_full(E._ptr(self.grads), n, E._ptr(self.ctrl), E._stream()))
         E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
                                          E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+        self.params_changed()
         c = self.ctrl.cpu()                      # this untuned batch-4 path can afford the host read every step
         self.t = int(c[1])
         if int(c[0]):

@@ -140,3 +140,59 @@ def test_small_launches_k_split_in_network(N, hw, cin, cout, pool):
     values (conv_ks_stats_kernel), then BN + leaky (+ pool) and the backward pass (tests/_shapes.py)"""
     from _shapes import check_layer_in_network
     check_layer_in_network(N, "small-M", 3, cin, cout, hw, pool, "K-split")
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 2e-3)])
+def test_layer_options_relu_and_linear_stack_vs_torch(dtype, tol):
+    """y2_set_layer_options: a bottleneck-shaped stack (1x1 ReLU, 3x3 ReLU, 1x1 without activation; batch norm with slim's
+    eps 1e-5 / decay 0.997; the conv-bias slots held at zero and given no gradient) against float64 autograd: output,
+    input gradient, every parameter gradient, moving statistics (src/slim_dir/nets/resnet_v1.py:99-112)."""
+    import torch.nn.functional as F
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(3)
+    N, hw, cin, db, depth = 4, 12, 64, 32, 128
+    spec = [(1, cin, db, 0), (3, db, db, 0), (1, db, depth, 0)]
+    slopes = [0.0, 0.0, 1.0]
+    net = E.Network(spec, N, hw, hw, dtype=dtype, training=True, grad_scale=1.0)
+    net.set_layer_options(slopes, 1e-5, 0.997, zero_bias_grad=True)
+    params = R.init_params(spec, seed=8)
+    for p in params:
+        p["b"] = np.zeros_like(p["b"])
+        p["gamma"] = rng.uniform(0.6, 1.4, p["gamma"].shape).astype(np.float32)
+        p["beta"] = rng.uniform(-0.3, 0.3, p["beta"].shape).astype(np.float32)
+    net.load_params(params)
+    x = rng.uniform(-1, 1, (N, hw, hw, cin)).astype(np.float32)
+    out = net.forward(torch.as_tensor(x).cuda(), True, True, update_moving=True).clone()
+    dout = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    dx = net.backward_input(torch.as_tensor(dout).cuda())
+    g = net.export_grads()
+    # float64 reference
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tp = [{k: torch.tensor(p[k], dtype=torch.float64, requires_grad=True) for k in ("W", "gamma", "beta")} for p in params]
+    h = xt.permute(0, 3, 1, 2)
+    mv = []
+    for (k, _ci, _co, _p), p, s in zip(spec, tp, slopes):
+        h = F.conv2d(h, p["W"].permute(3, 2, 0, 1), padding=k // 2)
+        mean, var = h.mean((0, 2, 3)), h.var((0, 2, 3), unbiased=False)
+        mv.append((0.003 * mean.detach().numpy(), 0.997 + 0.003 * var.detach().numpy()))
+        z = (h - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5) * p["gamma"][None, :, None, None] \
+            + p["beta"][None, :, None, None]
+        h = torch.maximum(s * z, z)
+    ref = h.permute(0, 2, 3, 1)
+    ref.backward(torch.tensor(dout, dtype=torch.float64))
+    # f32: element-wise gates.  f16: the forward pass is gated; its gradients are the exact gradients of a function that
+    # differs from the float64 one at ReLU decisions (y is STORED in half precision: a few of the 18,432 activations sit
+    # within its rounding of zero and fall the other way, each moving single gradient entries by O(1) -- the same stack
+    # with slopes 1, 1, 1 has no decisions and matches to 7e-4, scripts/diag_layer_options.py), so they are held in l2
+    l2 = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+    err = rel_to_max if dtype == "f32" else l2
+    gtol = tol if dtype == "f32" else 0.15
+    _obs.gate("layer-options stack forward %s" % dtype, rel_to_max(out.cpu().numpy(), ref.detach().numpy()), tol)
+    _obs.gate("layer-options stack input gradient %s" % dtype, err(dx.cpu().numpy(), xt.grad.numpy()), gtol)
+    for l in range(3):
+        for k in ("W", "gamma", "beta"):
+            _obs.gate("layer-options stack d%s %s" % (k, dtype), err(g[l][k], tp[l][k].grad.numpy()), gtol)
+        assert float(np.abs(g[l]["b"]).max()) == 0.0                    # not a variable of this graph
+    st = net.export_params()
+    for l in range(3):
+        assert rel_to_max(st[l]["moving_mean"], mv[l][0]) < max(tol, 1e-3) and rel_to_max(st[l]["moving_var"], mv[l][1]) < max(tol, 1e-3)
