@@ -167,9 +167,10 @@ int y2_passthrough_concat_backward(const float* dout, float* dfine, float* dcoar
  * and the passthrough) */
 int y2_accumulate(float* dst, const float* src, size_t n, void* stream);
 /* Round 4.  The join of a bottleneck unit, output = tf.nn.relu(shortcut + residual) (src/slim_dir/nets/resnet_v1.py:112),
- * and its backward g = dout * [out > 0] (the gradient of both addends); fp32 tensors of n elements, 16-byte aligned. */
+ * and its backward g = (dout + dout2) * [out > 0] (the gradient of both addends; dout2 nullable: the incoming gradient
+ * as the two branch gradients of the unit above, never summed in memory); fp32 tensors of n elements, 16-byte aligned. */
 int y2_add_relu(const float* a, const float* b, float* out, size_t n, void* stream);
-int y2_add_relu_backward(const float* dout, const float* out, float* g, size_t n, void* stream);
+int y2_add_relu_backward(const float* dout, const float* dout2, const float* out, float* g, size_t n, void* stream);
 /* scores [rows][classes] -> best score and class index per row (the class choice in front of the NMS of the YOLOv2
  * detector; ties: smallest index, as np.argmax in net_utils.py:418) */
 int y2_class_argmax(const float* scores, float* best, int* cls, int rows, int classes, void* stream);

@@ -696,14 +696,21 @@ __global__ void rn_add_relu_kernel(const float4* __restrict__ a, const float4* _
     if (blockIdx.x == 0)
         for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) os[i] = fmaxf(as[i] + bs[i], 0.f);
 }
-__global__ void rn_add_relu_bwd_kernel(const float4* __restrict__ d, const float4* __restrict__ out, float4* __restrict__ g,
-                                       size_t n4, const float* ds, const float* os, float* gs, size_t tail0, size_t n) {
+// d2 (nullable): a second addend of the incoming gradient (the two branches of the unit above: their sum never exists)
+__global__ void rn_add_relu_bwd_kernel(const float4* __restrict__ d, const float4* __restrict__ d2,
+                                       const float4* __restrict__ out, float4* __restrict__ g, size_t n4, const float* ds,
+                                       const float* d2s, const float* os, float* gs, size_t tail0, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const float4 x = d[i], y = out[i];
+        float4 x = d[i];
+        const float4 y = out[i];
+        if (d2) {
+            const float4 z = d2[i];
+            x.x += z.x; x.y += z.y; x.z += z.z; x.w += z.w;
+        }
         g[i] = make_float4(y.x > 0.f ? x.x : 0.f, y.y > 0.f ? x.y : 0.f, y.z > 0.f ? x.z : 0.f, y.w > 0.f ? x.w : 0.f);
     }
     if (blockIdx.x == 0)
-        for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) gs[i] = os[i] > 0.f ? ds[i] : 0.f;
+        for (size_t i = tail0 + threadIdx.x; i < n; i += blockDim.x) gs[i] = os[i] > 0.f ? ds[i] + (d2s ? d2s[i] : 0.f) : 0.f;
 }
 int y2_add_relu(const float* a, const float* b, float* out, size_t n, void* stream) {
     if (!a || !b || !out) return rfail(Y2_ERR_ARG, "null tensor");
@@ -714,12 +721,13 @@ int y2_add_relu(const float* a, const float* b, float* out, size_t n, void* stre
     RCHK(hipGetLastError());
     return Y2_OK;
 }
-int y2_add_relu_backward(const float* dout, const float* out, float* g, size_t n, void* stream) {
+int y2_add_relu_backward(const float* dout, const float* dout2, const float* out, float* g, size_t n, void* stream) {
     if (!dout || !out || !g) return rfail(Y2_ERR_ARG, "null tensor");
-    if ((((uintptr_t)dout | (uintptr_t)out | (uintptr_t)g) & 15) != 0) return rfail(Y2_ERR_ARG, "tensors must be 16-byte aligned");
+    if ((((uintptr_t)dout | (uintptr_t)dout2 | (uintptr_t)out | (uintptr_t)g) & 15) != 0)
+        return rfail(Y2_ERR_ARG, "tensors must be 16-byte aligned");
     const size_t n4 = n / 4;
     hipLaunchKernelGGL(rn_add_relu_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
-                       (const float4*)out, (float4*)g, n4, dout, out, g, n4 * 4, n);
+                       (const float4*)dout2, (const float4*)out, (float4*)g, n4, dout, dout2, out, g, n4 * 4, n);
     RCHK(hipGetLastError());
     return Y2_OK;
 }

@@ -638,12 +638,13 @@ def add_relu(a, b):
     return out
 
 
-def add_relu_backward(dout, out):
-    """dout * [out > 0]: the gradient of both addends of add_relu"""
+def add_relu_backward(dout, out, dout2=None):
+    """(dout + dout2) * [out > 0]: the gradient of both addends of add_relu (dout2: a second part of the incoming gradient)"""
     lib = _lib.load()
     assert dout.is_cuda and dout.dtype == out.dtype == torch.float32 and dout.is_contiguous() and out.is_contiguous()
+    assert dout2 is None or (dout2.is_contiguous() and dout2.dtype == torch.float32 and dout2.shape == dout.shape)
     g = torch.empty_like(dout)
-    check(lib.y2_add_relu_backward(_ptr(dout), _ptr(out), _ptr(g), dout.numel(), _stream()))
+    check(lib.y2_add_relu_backward(_ptr(dout), _ptr(dout2), _ptr(out), _ptr(g), dout.numel(), _stream()))
     return g
 
 

@@ -310,13 +310,16 @@ class ResNet50Yolo:
         dflat, _ = E.fully_connected_backward(flat, self.p["yolo_fc1/weights"], dz1, self.dtype,
                                               dw_out=self.g["yolo_fc1/weights"])
         dx = dflat.reshape(feat.shape).contiguous()
-        for rec in reversed(self.tape[:-1]):
+        dx2 = None          # a fused unit leaves its input gradient as two addends (main branch, shortcut): the unit below
+        for rec in reversed(self.tape[:-1]):    # folds their sum into its own join's backward, anything else adds them first
+            if rec[0] != "fused" and dx2 is not None:
+                dx = E.accumulate(dx, dx2)
+                dx2 = None
             if rec[0] == "fused":
                 _k, main, proj, out = rec
-                g = E.add_relu_backward(dx.contiguous(), out)          # d(relu(r + s)) = dout * [out > 0], to both branches
-                dxin = main.backward_input(g)
-                dsx = proj.backward_input(g) if proj is not None else g
-                dx = E.accumulate(dxin, dsx)
+                g = E.add_relu_backward(dx.contiguous(), out, dx2)     # d(relu(r + s)) = dout * [out > 0], to both branches
+                dx = main.backward_input(g)
+                dx2 = proj.backward_input(g) if proj is not None else g
             elif rec[0] == "unit":
                 u = rec[1]
                 c1, b1, c2, b2, c3, b3 = u["res"]
