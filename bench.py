@@ -275,6 +275,33 @@ def c3_classifier_leg(args, device):
     return out
 
 
+def c5_resnet50_leg(args, device):
+    """BASELINE.json configs[4], second half: the reference's ResNet-50 backbone swap (slim resnet_v1_50 + the YOLO FC
+    head, src/pascal/pascal_train_resnet.py:37-50) -- one train step at batch 32, 224x224, replayed from ONE HIP graph
+    (forward, loss, backward, overflow scan, guarded Adam); the stride-1 bottleneck units run on the native stack executor"""
+    import torch
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.yolo2_nets.tf_resnet import ResNet50Yolo
+    bs, size = 32, 224
+    m = ResNet50Yolo(bs, size, dtype=args.dtype, device=device, seed=0, graph=True)
+    x = torch.as_tensor(synthetic.images(bs, size, 1234)).to(device)
+    lab = torch.as_tensor(synthetic.det_labels(bs, size, size // 32, 4321)).to(device)
+    for _ in range(4):                      # two eager steps, the capture, one replay
+        m.step(x, lab)
+    torch.cuda.synchronize()
+    n = 10
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m.step(x, lab)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    flops = m.flops_per_step()
+    return {"workload": "configs[4]: ResNet-50 backbone swap train step 224x224 batch 32 (HIP-graph replay)", "dtype": args.dtype,
+            "batch": bs, "image_size": size, "steps": n, "warmup": 4, "ms_per_step": ms, "images_per_s": bs / (ms * 1e-3),
+            "whole_step_tflops": flops / (ms * 1e-3) / 1e12,
+            "whole_step_frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], "fused_stacks": bool(m.fused)}
+
+
 def fed_input(args, tr, device, resident_ms):
     """the fed loop: uint8 batches assembled in pinned memory and uploaded on their own stream while the previous
     step runs (utils/feeder.py), the float conversion inside the input pack kernel (y2_forward_u8).  The producer
@@ -448,7 +475,7 @@ def main():
     ap.add_argument("--fed-steps", type=int, default=30, help="fed-input leg: uint8 upload pipeline (0: skip)")
     ap.add_argument("--forward-only", action="store_true", help="configs[1]: core forward only (inference BN)")
     ap.add_argument("--no-extra-legs", action="store_true",
-                    help="skip the c1_detect (configs[0]), c2_forward (configs[1]) and c3_classifier (configs[2]) legs of the default line")
+                    help="skip the c1_detect (configs[0]), c2_forward (configs[1]), c3_classifier (configs[2]) and c5_resnet50 (configs[4]) legs of the default line")
     ap.add_argument("--model", default="detector", choices=["detector", "yolov2", "resnet50", "classifier"],
                     help="detector: the reference's Darknet-19 grid detector (the headline); yolov2: the north star's "
                          "anchor model (passthrough + anchor loss), not in the reference")
@@ -651,7 +678,8 @@ def main():
             del tr, net, run
             torch.cuda.empty_cache()
             tr = net = run = None
-            for key, leg in (("c1_detect", c1_detect_leg), ("c2_forward", c2_forward_leg), ("c3_classifier", c3_classifier_leg)):
+            for key, leg in (("c1_detect", c1_detect_leg), ("c2_forward", c2_forward_leg), ("c3_classifier", c3_classifier_leg),
+                             ("c5_resnet50", c5_resnet50_leg)):
                 try:
                     out[key] = leg(args, device)
                 except Exception as e:
