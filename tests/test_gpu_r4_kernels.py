@@ -121,7 +121,8 @@ def test_tile_choice_shapes_in_network_inference_fold(N, hw, cin, cout, k):
 
 
 SMALL_M = [(1, 7, 1024, 1024), (1, 14, 256, 512), (24, 7, 512, 1024), (24, 7, 1024, 1024), (4, 14, 512, 256), (2, 26, 256, 512),
-           (1, 13, 1024, 1024), (16, 7, 128, 256)]
+           (1, 13, 1024, 1024), (16, 7, 128, 256),
+           (2, 10, 640, 256), (5, 9, 384, 128), (3, 11, 1152, 384)]     # K chunks that do not divide by the split depth
 
 
 @pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("f32", 1e-5)])
