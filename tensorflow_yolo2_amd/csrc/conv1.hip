@@ -282,7 +282,12 @@ hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
 // A wave tile is 2 image rows x 32 columns: two accumulators share the four input rows; the
 // wave-private LDS patch [64 px][32 co] feeds both the 1-KiB row stores of y and the 2x2 windows.
 // ---------------------------------------------------------------------------
-template <typename T, bool STOREY>
+// TRACK: the window's arg-max and its conv output are kept for the backward pass (a.ysel / a.idx).  Without them
+// (inference, or a training binding that stores y) the window maximum is taken BEFORE the activation -- leaky is
+// non-decreasing, so leaky(max z) = max leaky(z) bit for bit -- and the per-element select chain (88 v_cndmask + 32
+// v_bfi + 31 compares of the ~400 vector instructions a tile costs; the kernel is bound by vector issue, not by HBM)
+// drops out.
+template <typename T, bool STOREY, bool TRACK>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
     typedef typename Elem<T>::frag frag_t;
     struct __attribute__((packed, aligned(8))) UFrag { frag_t v; };
@@ -322,17 +327,20 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
     const int ntiles = a.N * Ho * nseg;
     const int nwaves = gridDim.x * 4;
     const int rowpitch = (a.W + 1) * 4 * SZ;
-    for (int tile = blockIdx.x * 4 + w; tile < ntiles; tile += nwaves) {
+    auto load_tile = [&](int tile, frag_t (&fx)[4][KGC]) {
         const int sg = tile % nseg, pr = tile / nseg;
         const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho, w0 = sg * 32;
         const int wc = (w0 + r32 < a.W) ? w0 + r32 : a.W - 1;      // clamp (masked at the stores)
         const uint32_t base = (uint32_t)(bpix(n, h0, wc, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(4 * SZ);
-        frag_t fx[4][KGC];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int g = 0; g < KGC; ++g)
                 fx[r][g] = ((const UFrag*)((const char*)a.x4 + base + r * rowpitch + 32 * g + 16 * hh))->v;
+    };
+    auto body = [&](int tile, frag_t (&fx)[4][KGC]) {
+        const int sg = tile % nseg, pr = tile / nseg;
+        const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho, w0 = sg * 32;
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -381,13 +389,21 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
                 Chunk<T> c = ld_chunk<T>(ew + ((d >> 1) * 32 + 2 * j + (d & 1)) * EROW + ch * 16);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const float act = leaky01(fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]));
-                    if (act > m[e]) {          // first maximum in row-major window order
-                        m[e] = act;
-                        ys.v[e] = c.v[e];
-                        arg = (arg & ~(3u << (2 * e))) | ((unsigned)d << (2 * e));
+                    if constexpr (TRACK) {
+                        const float act = leaky01(fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]));
+                        if (act > m[e]) {          // first maximum in row-major window order
+                            m[e] = act;
+                            ys.v[e] = c.v[e];
+                            arg = (arg & ~(3u << (2 * e))) | ((unsigned)d << (2 * e));
+                        }
+                    } else {
+                        m[e] = fmaxf(m[e], fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]));   // NaN: skipped, as by `>`
                     }
                 }
+            }
+            if constexpr (!TRACK) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) m[e] = leaky01(m[e]);
             }
             const int wo = w0 / 2 + j;
             if (wo < Wo) {
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(m[e]);
                 st_chunk<T>((char*)a.out + (bpix(n, ho, wo, Ho, Wo) * 32 + ch * EPC) * SZ, o);
-                if (a.ysel) {
+                if (TRACK && a.ysel) {
                     const size_t pix = ((size_t)n * Ho + ho) * Wo + wo;
                     st_chunk<T>((char*)a.ysel + (pix * 32 + ch * EPC) * SZ, ys);
                     a.idx[pix * CPR + ch] = (unsigned short)arg;
@@ -404,27 +420,52 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
+    };
+    int tile = blockIdx.x * 4 + w;
+    if constexpr (!TRACK) {
+        for (; tile < ntiles; tile += nwaves) {
+            frag_t fx[4][KGC];
+            load_tile(tile, fx);
+            body(tile, fx);
+        }
+    } else {
+        // training form (more stores per tile): the input rows of a tile are requested one tile ahead, in two register
+        // sets with the loop unrolled over them (a rotating copy costs 16 v_mov per tile).  Measured on one box, layer 0
+        // forward at 416x416x64: 207 us against 212-216 with the loads in place; the inference form gains nothing
+        frag_t fxa[4][KGC], fxb[4][KGC];
+        if (tile < ntiles) load_tile(tile, fxa);
+        while (tile < ntiles) {
+            const int t2 = tile + nwaves, t3 = t2 + nwaves;
+            if (t2 < ntiles) load_tile(t2, fxb);
+            body(tile, fxa);
+            if (t2 >= ntiles) break;
+            if (t3 < ntiles) load_tile(t3, fxa);
+            body(t2, fxb);
+            tile = t3;
+        }
     }
 }
 
 bool conv1_pool_ok(int H, int W, int pool, int cout) { return pool && (H % 2) == 0 && (W % 2) == 0 && cout == 32; }
 
-hipError_t launch_conv1_pool(int dtype, const Conv1PoolArgs& a, hipStream_t s) {
+template <typename T>
+static void conv1_pool_T(const Conv1PoolArgs& a, hipStream_t s) {
     dim3 g(a.nblocks), b(256);
     if (a.store_y) {
-        switch (dtype) {
-            case 0: hipLaunchKernelGGL((conv1_pool_kernel<float, true>), g, b, 0, s, a); break;
-            case 1: hipLaunchKernelGGL((conv1_pool_kernel<half_t, true>), g, b, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((conv1_pool_kernel<bf16_t, true>), g, b, 0, s, a); break;
-            default: return hipErrorInvalidValue;
-        }
+        if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((conv1_pool_kernel<T, true, false>), g, b, 0, s, a);
     } else {
-        switch (dtype) {
-            case 0: hipLaunchKernelGGL((conv1_pool_kernel<float, false>), g, b, 0, s, a); break;
-            case 1: hipLaunchKernelGGL((conv1_pool_kernel<half_t, false>), g, b, 0, s, a); break;
-            case 2: hipLaunchKernelGGL((conv1_pool_kernel<bf16_t, false>), g, b, 0, s, a); break;
-            default: return hipErrorInvalidValue;
-        }
+        if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((conv1_pool_kernel<T, false, false>), g, b, 0, s, a);
+    }
+}
+
+hipError_t launch_conv1_pool(int dtype, const Conv1PoolArgs& a, hipStream_t s) {
+    switch (dtype) {
+        case 0: conv1_pool_T<float>(a, s); break;
+        case 1: conv1_pool_T<half_t>(a, s); break;
+        case 2: conv1_pool_T<bf16_t>(a, s); break;
+        default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
