@@ -92,6 +92,12 @@ int y2_params_changed(y2_ctx* ctx);
  * detect time, but nothing updates).  y2_update_moving_stats applies the skipped update afterwards, once. */
 int y2_forward(y2_ctx* ctx, const float* images, int is_training_core, int is_training_head, int update_moving,
                float* out, void* stream);
+/* Round 4.  The stack as the residual branch of a bottleneck unit (src/slim_dir/nets/resnet_v1.py:99-112: output =
+ * tf.nn.relu(shortcut + residual)): out = max(join + stack(images), 0), join [like out] fp32 -- the values of y2_forward
+ * followed by y2_add_relu, bit for bit; the branch output is never stored.  y2_backward* then takes
+ * y2_add_relu_backward's result (the gradient of the branch output), as after the two-call form. */
+int y2_forward_join(y2_ctx* ctx, const float* images, const float* join, int is_training_core, int is_training_head,
+                    int update_moving, float* out, void* stream);
 /* y2_forward fed with what image_read holds BEFORE its float conversion (src/img_dataset/pascal_voc.py:60-67:
  * cv2.imread + cv2.resize give uint8 BGR): images_u8 [N,H,W,3] uint8; the conversion
  * image.astype(float32) / 255.0 * 2.0 - 1.0 (pascal_voc.py:63-64, same fp32 operation order) runs inside the

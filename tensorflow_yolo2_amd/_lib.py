@@ -47,6 +47,7 @@ SIGNATURES = {
     "y2_params_changed": (_i, [_vp]),
     "y2_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "y2_forward_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "y2_forward_join": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "y2_update_moving_stats": (_i, [_vp, _vp]),
     "y2_backward": (_i, [_vp, _vp, _i, _i, _vp]),
     "y2_backward_marks": (_i, [_vp, _vp, _i, _pi, _vp]),

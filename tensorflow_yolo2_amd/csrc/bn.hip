@@ -256,9 +256,16 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
         }
         if (OUTF32) {
             float* o = (float*)a.out + (size_t)po * a.C;
+            if (a.join) {
+                const float* j = a.join + (size_t)po * a.C;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e)
-                if (c0 + e < a.C) o[c0 + e] = r[e];
+                for (int e = 0; e < EPC; ++e)
+                    if (c0 + e < a.C) o[c0 + e] = fmaxf(r[e] + j[c0 + e], 0.f);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (c0 + e < a.C) o[c0 + e] = r[e];
+            }
         } else {
             Chunk<T> o;
 #pragma unroll

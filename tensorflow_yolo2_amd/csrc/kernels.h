@@ -324,6 +324,8 @@ struct BnActArgs {
     float slope = 0.1f;   // activation: max(slope * z, z)
     void* ysel = nullptr; // pooled layers, training: the conv output at the window's (first) arg-max, [Mout][ldy] of T --
                           // what the BN-backward reduce needs of y (fused into the dgrad epilogue above this layer)
+    const float* join = nullptr;   // out_f32 only, [M][C] like out: the stored value is max(act + join, 0) -- the join of a
+                                   // ResNet bottleneck unit (y2_forward_join)
 };
 hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t s);
 // merge of a short partial list (P <= 128) + apply in one launch (64-channel slabs); bn_fin_act_ok says whether it applies

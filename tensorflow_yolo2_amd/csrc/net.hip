@@ -619,11 +619,21 @@ static int pack_all_weights(y2_ctx* c, hipStream_t s) {
 }
 
 static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8, int train_core, int train_head,
-                        int update_moving, float* out, void* stream);
+                        int update_moving, float* out, void* stream, const float* join = nullptr);
 int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, int update_moving, float* out,
                void* stream) {
     if (!images) return fail(Y2_ERR_ARG, "null tensor");
     return forward_impl(c, images, nullptr, train_core, train_head, update_moving, out, stream);
+}
+// The stack as the residual branch of a ResNet bottleneck unit: out = relu(join + stack(images)) written by the last
+// layer's apply pass (src/slim_dir/nets/resnet_v1.py:112) -- the same values as y2_forward followed by y2_add_relu, bit
+// for bit, without storing and re-reading the branch output
+int y2_forward_join(y2_ctx* c, const float* images, const float* join, int train_core, int train_head, int update_moving,
+                    float* out, void* stream) {
+    if (!images || !join) return fail(Y2_ERR_ARG, "null tensor");
+    if (c->tail == Y2_TAIL_AVGPOOL) return fail(Y2_ERR_ARG, "y2_forward_join: not for the average-pool tail");
+    if (join == out) return fail(Y2_ERR_ARG, "y2_forward_join: join and out must not alias");
+    return forward_impl(c, images, nullptr, train_core, train_head, update_moving, out, stream, join);
 }
 int y2_forward_u8(y2_ctx* c, const uint8_t* images_u8, int train_core, int train_head, int update_moving, float* out,
                   void* stream) {
@@ -633,7 +643,7 @@ int y2_forward_u8(y2_ctx* c, const uint8_t* images_u8, int train_core, int train
     return forward_impl(c, nullptr, images_u8, train_core, train_head, update_moving, out, stream);
 }
 static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8, int train_core, int train_head,
-                        int update_moving, float* out, void* stream) {
+                        int update_moving, float* out, void* stream, const float* join) {
     if (!c->ws) return fail(Y2_ERR_STATE, "bind buffers first");
     if (!out) return fail(Y2_ERR_ARG, "null tensor");
     hipStream_t s = (hipStream_t)stream;
@@ -764,6 +774,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
         } else {
             b.out = (c->tail == Y2_TAIL_AVGPOOL) ? (void*)(c->ws + c->o_h32) : (void*)out;
             b.out_f32 = 1;
+            b.join = join;
         }
         if (y.pool && c->bound_training && y.ysel) b.ysel = c->ws + y.ysel;
         if (fin_fused) HIPCHK(launch_bn_fin_act(c->dtype, b, f, s));

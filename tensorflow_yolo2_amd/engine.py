@@ -224,8 +224,10 @@ class Network:
         check(self.lib.y2_params_changed(self.h))
 
     # ---- execution -------------------------------------------------------
-    def forward(self, images, is_training_core=True, is_training_head=True, out=None, update_moving=False):
+    def forward(self, images, is_training_core=True, is_training_head=True, out=None, update_moving=False, join=None):
         """images: float32 NHWC in [-1, 1) (the reference's placeholder), or uint8 NHWC BGR pixels.
+        join (fp32, the output's shape): the stack is the residual branch of a bottleneck unit and the result is
+        relu(join + stack(images)) (slim_dir/nets/resnet_v1.py:112), written by the last layer's apply pass.
         update_moving: fold the BN moving-statistics update of the training-mode layers into this pass
         (the train step: UPDATE_OPS under train_op, pascal_train_darknet.py:49-51); False leaves them alone,
         as a sess.run that fetches only the output or the loss does (update_moving_stats() applies it later)."""
@@ -234,6 +236,12 @@ class Network:
         out = self._out if out is None else out
         # uint8 BGR pixels (what cv2.imread + cv2.resize hand to image_read, pascal_voc.py:60-62): the conversion
         # x / 255 * 2 - 1 runs in the input pack kernel
+        if join is not None:
+            assert images.dtype == torch.float32 and join.is_cuda and join.dtype == torch.float32 and join.is_contiguous()
+            assert join.numel() == out.numel() and join.data_ptr() != out.data_ptr()
+            check(self.lib.y2_forward_join(self.h, _ptr(images), _ptr(join), int(bool(is_training_core)),
+                                           int(bool(is_training_head)), int(bool(update_moving)), _ptr(out), _stream()))
+            return out
         fwd = self.lib.y2_forward_u8 if images.dtype == torch.uint8 else self.lib.y2_forward
         check(fwd(self.h, _ptr(images), int(bool(is_training_core)), int(bool(is_training_head)),
                   int(bool(update_moving)), _ptr(out), _stream()))

@@ -11,6 +11,8 @@ convolution, bias + ReLU and dropout.  Variable names are slim's (checkpoints of
 one to one).  The reference trains this model at batch 4 and 224x224 (the FC head fixes the input size): the
 operator-level composition is written for parity, the Darknet path is the tuned one.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -52,6 +54,9 @@ def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, 
     out += [("yolo_fc1/weights", (flat, fc_hidden), True), ("yolo_fc1/biases", (fc_hidden,), True),
             ("yolo_fc2/weights", (fc_hidden, fc_out), True), ("yolo_fc2/biases", (fc_out,), True)]
     return out
+
+
+_TWO_CALL_JOIN = bool(os.environ.get("Y2_RESNET_TWO_CALL_JOIN"))
 
 
 class ResNet50Yolo:
@@ -259,9 +264,12 @@ class ResNet50Yolo:
                 if self.fused and stride == 1:
                     main, proj = self._stack_for(sc, int(x.shape[1]), int(x.shape[3]), depth, db)
                     xin = x.contiguous()
-                    r = main.forward(xin, is_training, is_training, update_moving=update_moving)
                     short = proj.forward(xin, is_training, is_training, update_moving=update_moving) if proj is not None else xin
-                    out = E.add_relu(r, short)
+                    # relu(shortcut + residual) in the last layer's apply pass of the main stack (its own output buffer)
+                    if _TWO_CALL_JOIN:      # A/B: the branch output stored, then y2_add_relu
+                        out = E.add_relu(main.forward(xin, is_training, is_training, update_moving=update_moving), short)
+                    else:
+                        out = main.forward(xin, is_training, is_training, update_moving=update_moving, join=short)
                     tape.append(("fused", main, proj, out))
                     x = out
                     continue

@@ -197,3 +197,36 @@ def test_layer_options_relu_and_linear_stack_vs_torch(dtype, tol):
     st = net.export_params()
     for l in range(3):
         assert rel_to_max(st[l]["moving_mean"], mv[l][0]) < max(tol, 1e-3) and rel_to_max(st[l]["moving_var"], mv[l][1]) < max(tol, 1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "f32"])
+def test_forward_join_equals_forward_then_add_relu(dtype):
+    """y2_forward_join writes relu(join + stack(x)) from the last layer's apply pass (the join of a bottleneck unit,
+    slim_dir/nets/resnet_v1.py:112): the bits of y2_forward followed by y2_add_relu, in training and in inference mode,
+    and the backward pass from y2_add_relu_backward's gradient is the same afterwards"""
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(11)
+    N, hw, cin, db, depth = 3, 14, 256, 64, 256
+    spec = [(1, cin, db, 0), (3, db, db, 0), (1, db, depth, 0)]
+    params = R.init_params(spec, seed=5)
+    x = torch.as_tensor(f16_representable(rng.uniform(-1, 1, (N, hw, hw, cin)).astype(np.float32))).cuda()
+    join = torch.as_tensor(rng.uniform(-1, 1, (N, hw, hw, depth)).astype(np.float32)).cuda()
+    net = E.Network(spec, N, hw, hw, dtype=dtype, core_layers=3, training=True, grad_scale=1.0)
+    net.load_params(params)
+    net.set_layer_options([0.0, 0.0, 1.0], 1e-5, 0.997, zero_bias_grad=True)
+    for training in (True, False):
+        two = E.add_relu(net.forward(x, training, training).clone(), join)
+        one = net.forward(x, training, training, join=join).clone()
+        assert torch.isfinite(one).all() and (one == 0).any() and (one > 0).any()
+        assert torch.equal(one, two), training
+    # backward after the joined forward (training statistics): the same gradients as after the two-call form
+    dout = torch.as_tensor(rng.uniform(-1, 1, tuple(join.shape)).astype(np.float32)).cuda()
+    res = []
+    for joined in (False, True):
+        out = net.forward(x, True, True, join=join) if joined else E.add_relu(net.forward(x, True, True).clone(), join)
+        g = E.add_relu_backward(dout, out.clone())
+        dx = net.backward_input(g).clone()
+        res.append((dx, net.grads.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    with pytest.raises(Exception):
+        net.forward(x, True, True, join=join[:1].contiguous())
