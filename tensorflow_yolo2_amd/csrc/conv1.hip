@@ -287,7 +287,8 @@ hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
 // non-decreasing, so leaky(max z) = max leaky(z) bit for bit -- and the per-element select chain (88 v_cndmask + 32
 // v_bfi + 31 compares of the ~400 vector instructions a tile costs; the kernel is bound by vector issue, not by HBM)
 // drops out.
-template <typename T, bool STOREY, bool TRACK>
+// TRACK 2 (Conv1PoolArgs::idx3): the arg-max position and the activation's branch only, no conv output kept
+template <typename T, bool STOREY, int TRACK>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
     typedef typename Elem<T>::frag frag_t;
     struct __attribute__((packed, aligned(8))) UFrag { frag_t v; };
@@ -384,45 +385,67 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
             unsigned arg = 0;
 #pragma unroll
             for (int e = 0; e < EPC; ++e) m[e] = -INFINITY;
+            if constexpr (TRACK == 2) {
+                // the maximum first (as the untracked form: on z, leaky is non-decreasing), then WHICH position holds
+                // it by equality, first in window order: 6 vector operations per element instead of 5 per position
+                float z[4][EPC];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                Chunk<T> c = ld_chunk<T>(ew + ((d >> 1) * 32 + 2 * j + (d & 1)) * EROW + ch * 16);
+                for (int d = 0; d < 4; ++d) {
+                    Chunk<T> c = ld_chunk<T>(ew + ((d >> 1) * 32 + 2 * j + (d & 1)) * EROW + ch * 16);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) z[d][e] = fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    if constexpr (TRACK) {
-                        const float act = leaky01(fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]));
-                        if (act > m[e]) {          // first maximum in row-major window order
-                            m[e] = act;
-                            ys.v[e] = c.v[e];
-                            arg = (arg & ~(3u << (2 * e))) | ((unsigned)d << (2 * e));
+                    const float zm = fmaxf(fmaxf(fmaxf(m[e], z[0][e]), z[1][e]), fmaxf(z[2][e], z[3][e]));   // NaN: skipped
+                    const unsigned d = z[0][e] == zm ? 0u : (z[1][e] == zm ? 1u : (z[2][e] == zm ? 2u : 3u));
+                    m[e] = leaky01(zm);
+                    // leaky01_slope(z) = 0.1 exactly where 0.1 * z >= z, i.e. where max(0.1 z, z) <= 0
+                    arg |= (d | (m[e] <= 0.f ? 4u : 0u)) << (3 * e);
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    Chunk<T> c = ld_chunk<T>(ew + ((d >> 1) * 32 + 2 * j + (d & 1)) * EROW + ch * 16);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        if constexpr (TRACK == 1) {
+                            const float act = leaky01(fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]));
+                            if (act > m[e]) {          // first maximum in row-major window order
+                                m[e] = act;
+                                ys.v[e] = c.v[e];
+                                arg = (arg & ~(3u << (2 * e))) | ((unsigned)d << (2 * e));
+                            }
+                        } else {
+                            m[e] = fmaxf(m[e], fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]));   // NaN: skipped, as by `>`
                         }
-                    } else {
-                        m[e] = fmaxf(m[e], fmaf(Elem<T>::to_f32(c.v[e]), sc[e], sh[e]));   // NaN: skipped, as by `>`
                     }
                 }
             }
-            if constexpr (!TRACK) {
+            if constexpr (TRACK == 0) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) m[e] = leaky01(m[e]);
             }
+
             const int wo = w0 / 2 + j;
             if (wo < Wo) {
                 Chunk<T> o;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(m[e]);
                 st_chunk<T>((char*)a.out + (bpix(n, ho, wo, Ho, Wo) * 32 + ch * EPC) * SZ, o);
-                if (TRACK && a.ysel) {
+                if (TRACK == 1 && a.ysel) {
                     const size_t pix = ((size_t)n * Ho + ho) * Wo + wo;
                     st_chunk<T>((char*)a.ysel + (pix * 32 + ch * EPC) * SZ, ys);
                     a.idx[pix * CPR + ch] = (unsigned short)arg;
                 }
+                if (TRACK == 2) a.idx3[(((size_t)n * Ho + ho) * Wo + wo) * CPR + ch] = arg;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
     int tile = blockIdx.x * 4 + w;
-    if constexpr (!TRACK) {
+    if constexpr (TRACK == 0) {
         for (; tile < ntiles; tile += nwaves) {
             frag_t fx[4][KGC];
             load_tile(tile, fx);
@@ -452,11 +475,13 @@ template <typename T>
 static void conv1_pool_T(const Conv1PoolArgs& a, hipStream_t s) {
     dim3 g(a.nblocks), b(256);
     if (a.store_y) {
-        if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, true, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((conv1_pool_kernel<T, true, false>), g, b, 0, s, a);
+        if (a.idx3) hipLaunchKernelGGL((conv1_pool_kernel<T, true, 2>), g, b, 0, s, a);
+        else if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, true, 1>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((conv1_pool_kernel<T, true, 0>), g, b, 0, s, a);
     } else {
-        if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, false, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((conv1_pool_kernel<T, false, false>), g, b, 0, s, a);
+        if (a.idx3) hipLaunchKernelGGL((conv1_pool_kernel<T, false, 2>), g, b, 0, s, a);
+        else if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, false, 1>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((conv1_pool_kernel<T, false, 0>), g, b, 0, s, a);
     }
 }
 

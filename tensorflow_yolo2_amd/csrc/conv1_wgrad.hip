@@ -385,7 +385,10 @@ constexpr int kLinItems = 0;     // items (pooled pixel x chunk) per thread held
 // GRAM: the Gram matrix is accumulated here (rounds 2-3); false: the forward pass of this step left it in a.gram
 // (conv1_gram_kernel below: the batch-norm statistics of the layer come from it too) -- three of five MFMAs and the
 // tail masks drop out, the partial record shrinks from 15 KB to 6 KB
-template <typename T, bool GRAM>
+// NOSEL (kernels.h Conv1PoolArgs::idx3): no conv output is read; the slope of the activation at the arg-max comes with
+// the position (3 bits per channel), and this kernel's S2 records stay zero -- conv1_lin_s2_kernel adds sum g * y as one
+// record from the reduced X(dz)
+template <typename T, bool GRAM, bool NOSEL>
 __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1WgradLinArgs a, float* part) {
     // also the BN-backward REDUCE of this layer, for free: dA and ysel pass through here anyway, and nothing in this
     // kernel needs the sums (S1 = sum g, S2 = sum g * ysel -> psum[block][2][32]; the finalize runs after it)
@@ -437,8 +440,12 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
             const int item = tid + k * NTH;
             if (item < nitems) {
                 pda[k] = *(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16);
-                pys[k] = *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16);
-                pix_[k] = a.idx[prow * CPP + item];
+                if constexpr (NOSEL) {
+                    pix_[k] = a.idx3[prow * CPP + item];
+                } else {
+                    pys[k] = *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16);
+                    pix_[k] = a.idx[prow * CPP + item];
+                }
             }
         }
     };
@@ -448,19 +455,25 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
         *(u32x4*)dav.v = dar;
         *(u32x4*)ysv.v = ysr;
         T gz[EPC];
+        constexpr int IB = NOSEL ? 3 : 2;      // index bits per channel
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            const float yf = Elem<T>::to_f32(ysv.v[e]);
-            const float g = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yf, sc[e], sh[e]));
+            float g;
+            if constexpr (NOSEL) {
+                g = Elem<T>::to_f32(dav.v[e]) * (((ix >> (3 * e + 2)) & 1u) ? 0.1f : 1.0f);
+            } else {
+                const float yf = Elem<T>::to_f32(ysv.v[e]);
+                g = Elem<T>::to_f32(dav.v[e]) * leaky01_slope(fmaf(yf, sc[e], sh[e]));
+                s2[e] = fmaf(g, yf, s2[e]);
+            }
             s1[e] += g;
-            s2[e] = fmaf(g, yf, s2[e]);
             gz[e] = Elem<T>::from_f32(g);
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             Chunk<T> o;
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) o.v[e] = (((ix >> (2 * e)) & 3u) == (unsigned)d) ? gz[e] : Elem<T>::from_f32(0.f);
+            for (int e = 0; e < EPC; ++e) o.v[e] = (((ix >> (IB * e)) & 3u) == (unsigned)d) ? gz[e] : Elem<T>::from_f32(0.f);
             st_chunk<T>(dz_l + (d >> 1) * dz_bytes + (size_t)(2 * wo + (d & 1)) * DYP + ch * 16, o);
         }
     };
@@ -481,9 +494,11 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
             const int item = tid + k * NTH;
             if (item < nitems) process(pda[k], pys[k], pix_[k], item);
         }
-        for (int item = tid + kLinItems * NTH; item < nitems; item += NTH)      // wider images: the rest in place
-            process(*(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16),
-                    *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16), a.idx[prow * CPP + item], item);
+        for (int item = tid + kLinItems * NTH; item < nitems; item += NTH) {    // wider images: the rest in place
+            const u32x4 dar = *(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16);
+            if constexpr (NOSEL) process(dar, dar, a.idx3[prow * CPP + item], item);
+            else process(dar, *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16), a.idx[prow * CPP + item], item);
+        }
         if (kLinItems && pr + (int)gridDim.x < prs) prefetch(pr + gridDim.x);
         __syncthreads();   // LDS-DMA drained (vmcnt(0)) and the dz images complete
 #pragma unroll
@@ -613,6 +628,46 @@ __global__ __launch_bounds__(256) void conv1_lin_reduce_kernel(const float* part
         for (int u = 0; u < 4; ++u) v4[u] += part[(size_t)(b + u) * kLinAcc + i];
     for (; b < b1; ++b) v4[0] += part[(size_t)b * kLinAcc + i];
     mid[(size_t)blockIdx.y * kLinAcc + i] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+}
+
+// NOSEL form: S2 = sum_p dz y of the first layer from the reduced X(dz) (rows r = kh*16 + kw*4 + c, the 16 slice sums of
+// conv1_lin_reduce_kernel): y = Wq^T patch + b per pixel with Wq the filter as the forward pass reads it (rounded to T),
+// so sum_p dz[co] y[co] = sum_r Wq[r][co] X(dz)[r][co] + b[co] sum_p dz[co].  Written as record P (S1 = 0) behind the P
+// block records of conv1_wgrad_lin_kernel: bn_bwd_finalize adds it like any other.  One block, 32 channels x 32 slices.
+template <typename T>
+__global__ __launch_bounds__(1024) void conv1_lin_s2_kernel(const float* mid, const float* W, const float* bias, float* psum,
+                                                            int P) {
+    __shared__ double red[32][33], red1[32][33];
+    const int co = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    {                                                // S1 of the block records: slice sl takes records sl, sl + 32, ...
+        double s1 = 0.0;
+        for (int p = sl; p < P; p += 32) s1 += (double)psum[((size_t)p * 2 + 0) * 32 + co];
+        red1[sl][co] = s1;
+    }
+    __syncthreads();
+    double t = 0.0;
+    if (sl < 27) {                                   // slice = tap-channel tc = (kh*3 + kw)*3 + c
+        const int c = sl % 3, kw = (sl / 3) % 3, kh = sl / 9;
+        const int r = kh * 16 + kw * 4 + c;
+        float xdz = 0.f;
+#pragma unroll
+        for (int k = 0; k < kLinMid; ++k) xdz += mid[(size_t)k * kLinAcc + r * 32 + co];
+        t = (double)Elem<T>::to_f32(Elem<T>::from_f32(W[sl * 32 + co])) * (double)xdz;
+    } else if (sl == 27) {                           // b * S1
+        double s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s1 += red1[k][co];
+        t = (double)bias[co] * s1;
+    }
+    red[sl][co] = t;
+    __syncthreads();
+    if (sl == 0) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 28; ++k) v += red[k][co];
+        psum[((size_t)P * 2 + 0) * 32 + co] = 0.f;
+        psum[((size_t)P * 2 + 1) * 32 + co] = (float)v;
+    }
 }
 
 // dW[t][c][co] = inv_gs * (scale X(dz) - ka X(1) - kb (G W + b X(1)))   (rows r = kh*16 + kw*4 + c)
@@ -883,7 +938,10 @@ static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
     if (red < red2) red = red2;
     if (lds < red) lds = red;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    auto kern = a.gram ? conv1_wgrad_lin_kernel<T, false> : conv1_wgrad_lin_kernel<T, true>;
+    const bool nosel = a.idx3 != nullptr;
+    if (nosel && !(a.Wf && a.bias)) return hipErrorInvalidValue;
+    auto kern = nosel ? (a.gram ? conv1_wgrad_lin_kernel<T, false, true> : conv1_wgrad_lin_kernel<T, true, true>)
+                      : (a.gram ? conv1_wgrad_lin_kernel<T, false, false> : conv1_wgrad_lin_kernel<T, true, false>);
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int prs = a.N * (a.H / 2);
@@ -893,6 +951,10 @@ static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
     const int count = a.gram ? 48 * 32 : kLinAcc;
     hipLaunchKernelGGL(kern, dim3(nb), dim3(kLinThreads), lds, s, a, part);
     hipLaunchKernelGGL(conv1_lin_reduce_kernel, dim3((count + 255) / 256, kLinMid), dim3(256), 0, s, part, nb, a.acc, 0, count);
+    if (nosel) {
+        hipLaunchKernelGGL(conv1_lin_s2_kernel<T>, dim3(1), dim3(1024), 0, s, a.acc, a.Wf, a.bias, a.psum, nb);
+        if (a.nblocks_out) *a.nblocks_out = nb + 1;
+    }
     return hipGetLastError();
 }
 

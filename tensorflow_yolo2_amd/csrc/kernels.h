@@ -120,6 +120,12 @@ struct Conv1PoolArgs {
     // positions it was (idx [Mout][chunks] u16: 2 bits per channel of a 16-byte chunk)
     void* ysel = nullptr;
     unsigned short* idx = nullptr;
+    // round 4, 16-bit types: NO conv output at all is kept.  idx3 [Mout][chunks] u32 holds 3 bits per channel of a chunk:
+    // the window position (2) and whether the activation there took the leaky branch (1: 0.1 * z >= z).  That is all the
+    // backward pass needs per element (g = dA * slope, scattered to that position); its sum of g * y follows from the
+    // linearity of y in the filter: sum_p dz y = sum_k W[k] X(dz)[k] + b sum dz, with X(dz) the matrix the weight
+    // gradient forms anyway (conv1_wgrad.hip conv1_lin_s2_kernel).  Set instead of ysel / idx.
+    unsigned* idx3 = nullptr;
 };
 // backward reduce pass of the same layer with the conv output recomputed (x4 + dA in, psum out)
 struct Conv1BnBwdArgs {
@@ -169,6 +175,11 @@ struct Conv1WgradLinArgs {
     const unsigned short* idx;  // [Mout][chunks]
     const float *scale, *shift;
     const float* gram = nullptr; // [48][48] totals of the forward pass's Gram matrix (launch_conv1_gram_stats): G is not rebuilt here
+    // Conv1PoolArgs::idx3 form (ysel / idx null): Wf (fp32 HWIO [3][3][3][32]) and bias for sum g * y = W . X(dz) + b sum dz,
+    // written as one more psum record (S1 = 0) behind the blocks' records
+    const unsigned* idx3 = nullptr;
+    const float* Wf = nullptr;
+    const float* bias = nullptr;
     float* acc;                 // 16 slice sums of [48*32 + 48*48], followed by the per-block partials (conv1_wgrad_lin_scratch_floats)
     float* psum;                // out: BN-backward partial sums [blocks][2][32] (S1, S2) -- the reduce pass rides here
     int* nblocks_out;           // host: number of partial records written

@@ -110,6 +110,7 @@ struct y2_ctx {
     // pooled 3-channel first layer, training: the linear form of its backward pass (conv1_wgrad.hip) -- its conv
     // output is never stored
     bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
+    bool nosel1() const { return lin1() && L[0].ysel == 0; }     // ... and not even the arg-max outputs (Conv1PoolArgs::idx3)
     size_t o_infertab = 0;      // BnInferLayer per layer (one prepare launch for all inference-mode layers)
     size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0, o_slab = 0;
     size_t o_ks = 0, ks_floats = 0;   // K-split partial tiles of small convolution launches (ConvArgs::ks_scratch)
@@ -240,8 +241,12 @@ static void plan(y2_ctx* c) {
         Layer& y = c->L[l];
         const bool lin1 = y.first3 && c->L.size() > 1 && conv1_pool_ok(y.H, y.W, y.pool, y.cout) &&
                           conv1_wgrad_lin_ok(y.H, y.W, y.pool, y.ldy, (int)sz);
-        y.ysel = (y.pool && (!y.first3 || lin1)) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
-        y.idx0 = lin1 ? take((size_t)c->N * y.Ho * y.Wo * (y.ldy * sz / 16) * sizeof(unsigned short) + 256) : 0;
+        // round 4, 16-bit types: the linear form keeps NO conv output of the first layer, only 3 index bits per element
+        // (kernels.h Conv1PoolArgs::idx3); Y2_CONV1_YSEL=1 (and the f32 parity mode) keep ysel + 2 index bits
+        static const bool keep_ysel = getenv("Y2_CONV1_YSEL") != nullptr;
+        const bool nosel = lin1 && c->dtype != 0 && !keep_ysel;
+        y.ysel = (y.pool && (!y.first3 || (lin1 && !nosel))) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
+        y.idx0 = lin1 ? take((size_t)c->N * y.Ho * y.Wo * (y.ldy * sz / 16) * (nosel ? sizeof(unsigned) : sizeof(unsigned short)) + 256) : 0;
         if (lin1) c->o_lin = take(conv1_wgrad_lin_scratch_floats() * sizeof(float));
         if (lin1 && conv1_gram_ok(y.H, y.W, (int)sz)) c->o_gram = take(conv1_gram_scratch_floats() * sizeof(float));
     }
@@ -760,7 +765,8 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             const int tiles = c->N * (y.H / 2) * ((y.W + 31) / 32);
             q.nblocks = (tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4;
             q.store_y = (c->bound_training && !c->lin1()) ? 1 : 0;
-            if (c->lin1()) { q.ysel = c->ws + y.ysel; q.idx = (unsigned short*)(c->ws + y.idx0); }
+            if (c->nosel1()) q.idx3 = (unsigned*)(c->ws + y.idx0);
+            else if (c->lin1()) { q.ysel = c->ws + y.ysel; q.idx = (unsigned short*)(c->ws + y.idx0); }
             HIPCHK(launch_conv1_pool(c->dtype, q, s));
             continue;
         }
@@ -889,8 +895,13 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             if (lin1) {
                 // linear form: the reduce pass rides in the weight-gradient kernel, which does not need its result
                 Conv1WgradLinArgs g{};
-                g.x4 = c->ws + y.xin + c->in_geom(l).base_off(sz); g.dA = b.dA; g.ysel = c->ws + y.ysel;
-                g.idx = (const unsigned short*)(c->ws + y.idx0);
+                g.x4 = c->ws + y.xin + c->in_geom(l).base_off(sz); g.dA = b.dA;
+                if (c->nosel1()) {
+                    g.idx3 = (const unsigned*)(c->ws + y.idx0); g.Wf = c->params + y.pW; g.bias = c->params + y.pb;
+                } else {
+                    g.ysel = c->ws + y.ysel;
+                    g.idx = (const unsigned short*)(c->ws + y.idx0);
+                }
                 g.scale = b.scale; g.shift = b.shift; g.acc = (float*)(c->ws + c->o_lin); g.psum = psum;
                 if (c->gram_valid) g.gram = (const float*)(c->ws + c->o_gram);
                 int nbl = 0;
