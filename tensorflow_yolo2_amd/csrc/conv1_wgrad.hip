@@ -482,19 +482,42 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
         const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho;
         const char* xrow = (const char*)a.x4 + (bpix(n, h0, 0, a.H, a.W) - (size_t)(a.W + 2)) * XP;
         const size_t xpitch = (size_t)(a.W + 1) * XP;
+        const size_t prow = ((size_t)n * Ho + ho) * Wo;
+        // this row pair's first kBatch items per thread: every load issued before the first one is used (left to the
+        // compiler the loop below loads, waits and processes item by item: three to four exposed latencies per row pair)
+        constexpr int kBatch = kLinItems ? 0 : 4;
+        u32x4 bda[kBatch ? kBatch : 1], bys[kBatch ? kBatch : 1];
+        unsigned bix[kBatch ? kBatch : 1];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const int item = tid + k * NTH;
+            if (item < nitems) {
+                bda[k] = *(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16);
+                if constexpr (NOSEL) {
+                    bix[k] = a.idx3[prow * CPP + item];
+                } else {
+                    bys[k] = *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16);
+                    bix[k] = a.idx[prow * CPP + item];
+                }
+            }
+        }
         __syncthreads();   // previous row pair fully consumed
         for (int kh = 0; kh < 4; ++kh)
             for (int i0 = w * 64; i0 < x_chunks; i0 += NTH) {
                 const int i = i0 + lane;
                 if (i < x_chunks) glds16(xrow + kh * xpitch + (size_t)i * 16, x_l + kh * x_bytes + i0 * 16);
             }
-        const size_t prow = ((size_t)n * Ho + ho) * Wo;
 #pragma unroll
         for (int k = 0; k < kLinItems; ++k) {
             const int item = tid + k * NTH;
             if (item < nitems) process(pda[k], pys[k], pix_[k], item);
         }
-        for (int item = tid + kLinItems * NTH; item < nitems; item += NTH) {    // wider images: the rest in place
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+            const int item = tid + k * NTH;
+            if (item < nitems) process(bda[k], NOSEL ? bda[k] : bys[k], bix[k], item);
+        }
+        for (int item = tid + (kLinItems + kBatch) * NTH; item < nitems; item += NTH) {    // wider images: the rest in place
             const u32x4 dar = *(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16);
             if constexpr (NOSEL) process(dar, dar, a.idx3[prow * CPP + item], item);
             else process(dar, *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16), a.idx[prow * CPP + item], item);
