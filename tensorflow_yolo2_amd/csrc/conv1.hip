@@ -398,10 +398,13 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float zm = fmaxf(fmaxf(fmaxf(m[e], z[0][e]), z[1][e]), fmaxf(z[2][e], z[3][e]));   // NaN: skipped
-                    const unsigned d = z[0][e] == zm ? 0u : (z[1][e] == zm ? 1u : (z[2][e] == zm ? 2u : 3u));
+                    unsigned d = z[2][e] == zm ? 2u : 3u;      // three selects (a nested conditional became branches)
+                    d = z[1][e] == zm ? 1u : d;
+                    d = z[0][e] == zm ? 0u : d;
                     m[e] = leaky01(zm);
                     // leaky01_slope(z) = 0.1 exactly where 0.1 * z >= z, i.e. where max(0.1 z, z) <= 0
-                    arg |= (d | (m[e] <= 0.f ? 4u : 0u)) << (3 * e);
+                    const unsigned neg = m[e] <= 0.f ? 4u : 0u;
+                    arg |= (d | neg) << (3 * e);
                 }
             } else {
 #pragma unroll
