@@ -193,6 +193,49 @@ hipError_t launch_bn_infer_prepare_all(const BnInferLayer* tab, int nlayers, int
 
 // ---------------------------------------------------------------------------
 // forward: out = maxpool2x2?( leaky( y*scale + shift ) )
+// One 2x2 window of a pooled layer's apply pass: r = the activation's maximum, ys = the conv output at its first
+// arg-max in row-major window order.  Whole windows (every even-sized map): the four loads are issued before the first
+// is used, the maximum is taken on z = y * scale + shift (the activation max(slope z, z), slope in [0, 1], is
+// non-decreasing: leaky(max z) = max leaky(z) bit for bit) and the position found by equality -- 6 vector operations
+// per element for the search instead of 5 per position in a load-compare-select chain.
+template <typename T>
+Y2_DEV void pool_window(const BnActArgs& a, int n, int ho, int wo, int c0, const float* sc, const float* sh, float* r,
+                        Chunk<T>& ys) {
+    constexpr int EPC = 16 / sizeof(T);
+    const int hi0 = 2 * ho, wi0 = 2 * wo;
+    if (hi0 + 1 < a.H && wi0 + 1 < a.W) {
+        const char* p = (const char*)a.y + (((size_t)(n * a.H + hi0) * a.W + wi0) * a.ldy + c0) * sizeof(T);
+        const size_t pxB = (size_t)a.ldy * sizeof(T), rowB = (size_t)a.W * pxB;
+        const Chunk<T> v0 = ld_chunk<T>(p), v1 = ld_chunk<T>(p + pxB), v2 = ld_chunk<T>(p + rowB), v3 = ld_chunk<T>(p + rowB + pxB);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float z0 = Elem<T>::to_f32(v0.v[e]) * sc[e] + sh[e], z1 = Elem<T>::to_f32(v1.v[e]) * sc[e] + sh[e];
+            const float z2 = Elem<T>::to_f32(v2.v[e]) * sc[e] + sh[e], z3 = Elem<T>::to_f32(v3.v[e]) * sc[e] + sh[e];
+            const float zm = fmaxf(fmaxf(fmaxf(-INFINITY, z0), z1), fmaxf(z2, z3));     // NaN: skipped, as by `>`
+            T y = z2 == zm ? v2.v[e] : v3.v[e];
+            y = z1 == zm ? v1.v[e] : y;
+            y = z0 == zm ? v0.v[e] : y;
+            ys.v[e] = y;
+            r[e] = leaky_s(zm, a.slope);
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int hi = hi0 + (d >> 1), wi = wi0 + (d & 1);
+        if (hi < a.H && wi < a.W) {
+            Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float act = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
+                if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // block = (256 / cpr) pixel rows x cpr 16-byte channel chunks over a contiguous pixel range: the
 // channel chunk of a thread is fixed (scale/shift live in registers) and (n, ho, wo) advance
@@ -233,21 +276,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
         float r[EPC];
         if (POOL) {
             Chunk<T> ys;   // conv output at the first arg-max of the window (backward: BnActArgs::ysel)
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
-                if (hi < a.H && wi < a.W) {
-                    Chunk<T> v = ld_chunk<T>((const char*)a.y +
-                                             (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const float act = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
-                        if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
-                    }
-                }
-            }
+            pool_window<T>(a, n, ho, wo, c0, sc, sh, r, ys);
             if (a.ysel) st_chunk<T>((char*)a.ysel + ((size_t)po * a.ldy + c0) * sizeof(T), ys);
         } else {
             Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
@@ -374,20 +403,7 @@ __global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalize
         float r[EPC];
         if (POOL) {
             Chunk<T> ys;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) r[e] = -INFINITY;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
-                if (hi < a.H && wi < a.W) {
-                    Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)(n * a.H + hi) * a.W + wi) * a.ldy + c0) * sizeof(T));
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const float act = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
-                        if (act > r[e]) { r[e] = act; ys.v[e] = v.v[e]; }
-                    }
-                }
-            }
+            pool_window<T>(a, n, ho, wo, c0, sc, sh, r, ys);
             if (a.ysel) st_chunk<T>((char*)a.ysel + ((size_t)po * a.ldy + c0) * sizeof(T), ys);
         } else {
             Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
@@ -554,21 +570,42 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                     amax[e] = -INFINITY;
                     yb[e] = 0.f;
                 }
+                if (valid[3]) {
+                    // whole window (every even-sized map): the search of the forward pass (pool_window above) -- the
+                    // maximum on z first, then the first position that holds it, by equality
 #pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    if (valid[d]) {
+                    for (int e = 0; e < EPC; ++e) {
+                        const float y0 = Elem<T>::to_f32(yc[0].v[e]), y1 = Elem<T>::to_f32(yc[1].v[e]);
+                        const float y2 = Elem<T>::to_f32(yc[2].v[e]), y3 = Elem<T>::to_f32(yc[3].v[e]);
+                        const float z0 = y0 * sc[e] + sh[e], z1 = y1 * sc[e] + sh[e];
+                        const float z2 = y2 * sc[e] + sh[e], z3 = y3 * sc[e] + sh[e];
+                        const float zm = fmaxf(fmaxf(fmaxf(-INFINITY, z0), z1), fmaxf(z2, z3));
+                        int d = z2 == zm ? 2 : 3;
+                        float yv = z2 == zm ? y2 : y3;
+                        d = z1 == zm ? 1 : d;
+                        yv = z1 == zm ? y1 : yv;
+                        d = z0 == zm ? 0 : d;
+                        yv = z0 == zm ? y0 : yv;
+                        arg[e] = d;
+                        yb[e] = yv;
+                    }
+                } else {
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) {
-                            // the pooled quantity is leaky(z): compare what the forward pass compared
-                            const float yv = Elem<T>::to_f32(yc[d].v[e]);
-                            const float act = leaky_s(fmaf(yv, sc[e], sh[e]), a.slope);
-                            if (act > amax[e]) {
-                                amax[e] = act;
-                                yb[e] = yv;
-                                if (APPLY) arg[e] = d;
+                    for (int d = 0; d < 4; ++d)
+                        if (valid[d]) {
+#pragma unroll
+                            for (int e = 0; e < EPC; ++e) {
+                                // the pooled quantity is leaky(z): compare what the forward pass compared
+                                const float yv = Elem<T>::to_f32(yc[d].v[e]);
+                                const float act = leaky_s(fmaf(yv, sc[e], sh[e]), a.slope);
+                                if (act > amax[e]) {
+                                    amax[e] = act;
+                                    yb[e] = yv;
+                                    if (APPLY) arg[e] = d;
+                                }
                             }
                         }
-                    }
+                }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yb[e], sc[e], sh[e]), a.slope);
@@ -770,20 +807,39 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
                 amax[e] = -INFINITY;
                 yb[e] = 0.f;
             }
+            if (valid[3]) {      // whole window: the forward pass's search (pool_window; bn_bwd_kernel above)
 #pragma unroll
-            for (int d = 0; d < 4; ++d)
-                if (valid[d]) {
+                for (int e = 0; e < EPC; ++e) {
+                    const float y0 = Elem<T>::to_f32(yc[0].v[e]), y1 = Elem<T>::to_f32(yc[1].v[e]);
+                    const float y2 = Elem<T>::to_f32(yc[2].v[e]), y3 = Elem<T>::to_f32(yc[3].v[e]);
+                    const float z0 = y0 * sc[e] + sh[e], z1 = y1 * sc[e] + sh[e];
+                    const float z2 = y2 * sc[e] + sh[e], z3 = y3 * sc[e] + sh[e];
+                    const float zm = fmaxf(fmaxf(fmaxf(-INFINITY, z0), z1), fmaxf(z2, z3));
+                    int d = z2 == zm ? 2 : 3;
+                    float yv = z2 == zm ? y2 : y3;
+                    d = z1 == zm ? 1 : d;
+                    yv = z1 == zm ? y1 : yv;
+                    d = z0 == zm ? 0 : d;
+                    yv = z0 == zm ? y0 : yv;
+                    arg[e] = d;
+                    yb[e] = yv;
+                }
+            } else {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const float yv = Elem<T>::to_f32(yc[d].v[e]);
-                        const float act = leaky_s(fmaf(yv, sc[e], sh[e]), a.slope);
-                        if (act > amax[e]) {
-                            amax[e] = act;
-                            yb[e] = yv;
-                            arg[e] = d;
+                for (int d = 0; d < 4; ++d)
+                    if (valid[d]) {
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) {
+                            const float yv = Elem<T>::to_f32(yc[d].v[e]);
+                            const float act = leaky_s(fmaf(yv, sc[e], sh[e]), a.slope);
+                            if (act > amax[e]) {
+                                amax[e] = act;
+                                yb[e] = yv;
+                                arg[e] = d;
+                            }
                         }
                     }
-                }
+            }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yb[e], sc[e], sh[e]), a.slope);
 #pragma unroll
