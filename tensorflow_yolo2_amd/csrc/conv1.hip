@@ -282,12 +282,13 @@ hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
 // A wave tile is 2 image rows x 32 columns: two accumulators share the four input rows; the
 // wave-private LDS patch [64 px][32 co] feeds both the 1-KiB row stores of y and the 2x2 windows.
 // ---------------------------------------------------------------------------
-// TRACK: the window's arg-max and its conv output are kept for the backward pass (a.ysel / a.idx).  Without them
-// (inference, or a training binding that stores y) the window maximum is taken BEFORE the activation -- leaky is
-// non-decreasing, so leaky(max z) = max leaky(z) bit for bit -- and the per-element select chain (88 v_cndmask + 32
-// v_bfi + 31 compares of the ~400 vector instructions a tile costs; the kernel is bound by vector issue, not by HBM)
-// drops out.
-// TRACK 2 (Conv1PoolArgs::idx3): the arg-max position and the activation's branch only, no conv output kept
+// TRACK 1: the window's arg-max and its conv output are kept for the backward pass (a.ysel / a.idx; f32 parity mode and
+// Y2_CONV1_YSEL=1), found by a per-position compare / select chain on the activation.
+// TRACK 0 (inference, or a training binding that stores y): the window maximum is taken BEFORE the activation -- leaky is
+// non-decreasing, so leaky(max z) = max leaky(z) bit for bit -- and that chain (88 v_cndmask + 32 v_bfi + 31 compares of
+// the ~400 vector instructions a tile cost; the kernel is bound by vector issue, not by HBM) drops out.
+// TRACK 2 (Conv1PoolArgs::idx3; training, 16-bit types): the same maximum first, then the first position that holds it by
+// equality, and 3 bits per element (position, activation branch) instead of any conv output.
 template <typename T, bool STOREY, int TRACK>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
     typedef typename Elem<T>::frag frag_t;
