@@ -31,6 +31,14 @@ typedef struct y2_ctx y2_ctx;
 #define Y2_F32 0  /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32): parity mode        */
 #define Y2_F16 1  /* fp16 operands, fp32 accumulate                              */
 #define Y2_BF16 2 /* bf16 operands, fp32 accumulate                              */
+/* Round 5: the reference's precision on the FAST matrix pipe.  The reference is fp32 end to end
+ * (src/yolo2_nets/darknet.py:10-46, tf.float32 placeholders src/pascal/pascal_train_darknet.py:34-36).  Every MFMA
+ * operand (activation, filter, dY) is a pair of halves hi = f16(v), lo = f16(v - hi) in two planes of its channel row
+ * (4 bytes per element, as fp32); a product is hi*hi + lo*hi + hi*lo on v_mfma_f32_*_f16 with fp32 accumulation
+ * (~22 mantissa bits, a third of the f16 rate instead of the exact-f32 MFMA's sixteenth); conv outputs, gradients
+ * with respect to activations, statistics, batch norm, loss and optimizer are fp32 as in Y2_F32; the 3-channel image
+ * layer runs in exact fp32.  Gradients ride on the f16 loss scale (y2_set_options) with the f16 mode's overflow guard. */
+#define Y2_F16X2 3
 
 #define Y2_TAIL_NONE 0    /* output = last layer activation [N,Ho,Wo,Cout]       */
 #define Y2_TAIL_AVGPOOL 1 /* + average_pooling2d(k,k) + reshape -> [N,Cout]      */

@@ -16,11 +16,13 @@ if os.environ.get("Y2_DEV_LIB") == "1":
 if os.environ.get("Y2_LIB_PATH"):
     LIB_PATH = os.environ["Y2_LIB_PATH"]
 
-Y2_F32, Y2_F16, Y2_BF16 = 0, 1, 2
+Y2_F32, Y2_F16, Y2_BF16, Y2_F16X2 = 0, 1, 2, 3
 Y2_TAIL_NONE, Y2_TAIL_AVGPOOL = 0, 1
 DTYPES = {"f32": Y2_F32, "fp32": Y2_F32, "float32": Y2_F32,
           "f16": Y2_F16, "fp16": Y2_F16, "float16": Y2_F16,
-          "bf16": Y2_BF16, "bfloat16": Y2_BF16}
+          "bf16": Y2_BF16, "bfloat16": Y2_BF16,
+          # split-operand mode: (hi, lo) f16 pairs, three MFMAs per product, fp32-width storage (include/yolo2_hip.h)
+          "f16x2": Y2_F16X2}
 
 _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 _pi = C.POINTER(C.c_int)

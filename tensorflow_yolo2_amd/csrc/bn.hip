@@ -191,6 +191,22 @@ hipError_t launch_bn_infer_prepare_all(const BnInferLayer* tab, int nlayers, int
     return hipGetLastError();
 }
 
+// one 16-byte chunk of channels c0.. of cell `cell` of a bordered tensor with C channels per cell.  SPLIT (f16x2 mode,
+// T = float: four channels): the cell is [C halves hi][C halves lo] (common.h hsplit_t), 8 bytes go to each plane
+template <typename T, bool SPLIT>
+Y2_DEV void st_act(char* base, size_t cell, int C, int c0, const float* r) {
+    if constexpr (SPLIT) {
+        static_assert(sizeof(T) == 4, "the split store takes fp32 chunks");
+        st_split4(base + cell * (size_t)C * 4, C, c0, r);
+    } else {
+        constexpr int EPC = 16 / sizeof(T);
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(r[e]);
+        st_chunk<T>(base + (cell * (size_t)C + c0) * sizeof(T), o);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // forward: out = maxpool2x2?( leaky( y*scale + shift ) )
 // One 2x2 window of a pooled layer's apply pass: r = the activation's maximum, ys = the conv output at its first
@@ -240,7 +256,7 @@ Y2_DEV void pool_window(const BnActArgs& a, int n, int ho, int wo, int c0, const
 // block = (256 / cpr) pixel rows x cpr 16-byte channel chunks over a contiguous pixel range: the
 // channel chunk of a thread is fixed (scale/shift live in registers) and (n, ho, wo) advance
 // incrementally -- no per-element div/mod (64-bit ones cost more than the pass's arithmetic)
-template <typename T, bool POOL, bool OUTF32>
+template <typename T, bool POOL, bool OUTF32, bool SPLIT = false>
 __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
     constexpr int EPC = 16 / sizeof(T);
     const int cpr = a.ldy / EPC;           // <= 256 (checked by the launcher)
@@ -296,11 +312,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
                     if (c0 + e < a.C) o[c0 + e] = r[e];
             }
         } else {
-            Chunk<T> o;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(r[e]);
-            const size_t off = (bpix(n, ho, wo, Ho, Wo) * a.C + c0) * sizeof(T);
-            st_chunk<T>((char*)a.out + off, o);
+            st_act<T, SPLIT>((char*)a.out, bpix(n, ho, wo, Ho, Wo), a.C, c0, r);
         }
     }
 }
@@ -363,7 +375,7 @@ Y2_DEV void fin_slab_merge(const BnFinalizeArgs& f, int cbase, double (*red)[kSl
     __syncthreads();
 }
 
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalizeArgs f) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int CPB = kSlab / EPC;        // chunks per block row
@@ -410,11 +422,7 @@ __global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalize
 #pragma unroll
             for (int e = 0; e < EPC; ++e) r[e] = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
         }
-        Chunk<T> o;
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(r[e]);
-        const size_t off = (bpix(n, ho, wo, Ho, Wo) * a.C + c0) * sizeof(T);
-        st_chunk<T>((char*)a.out + off, o);
+        st_act<T, SPLIT>((char*)a.out, bpix(n, ho, wo, Ho, Wo), a.C, c0, r);
     }
 }
 
@@ -422,7 +430,7 @@ bool bn_fin_act_ok(const BnActArgs& a, const BnFinalizeArgs& f) {
     static const int pmax = getenv("Y2DEV_FIN_PMAX") ? atoi(getenv("Y2DEV_FIN_PMAX")) : 128;
     return f.P > 0 && f.P <= pmax && !a.out_f32 && a.ldy % kSlab == 0 && a.C == a.ldy && f.ldp == a.ldy;
 }
-template <typename T>
+template <typename T, bool SPLIT = false>
 static hipError_t bn_fin_act_T(const BnActArgs& a, const BnFinalizeArgs& f, hipStream_t s) {
     constexpr int EPC = 16 / sizeof(T);
     const int Ho = a.pool ? (a.H + 1) / 2 : a.H, Wo = a.pool ? (a.W + 1) / 2 : a.W;
@@ -435,8 +443,8 @@ static hipError_t bn_fin_act_T(const BnActArgs& a, const BnFinalizeArgs& f, hipS
     if (nx > cap) nx = cap;
     if (nx == 0) nx = 1;
     dim3 g((unsigned)nx, (unsigned)ny), b(256);
-    if (a.pool) hipLaunchKernelGGL((bn_fin_act_kernel<T, true>), g, b, 0, s, a, f);
-    else hipLaunchKernelGGL((bn_fin_act_kernel<T, false>), g, b, 0, s, a, f);
+    if (a.pool) hipLaunchKernelGGL((bn_fin_act_kernel<T, true, SPLIT>), g, b, 0, s, a, f);
+    else hipLaunchKernelGGL((bn_fin_act_kernel<T, false, SPLIT>), g, b, 0, s, a, f);
     return hipGetLastError();
 }
 hipError_t launch_bn_fin_act(int dtype, const BnActArgs& a, const BnFinalizeArgs& f, hipStream_t s) {
@@ -445,11 +453,12 @@ hipError_t launch_bn_fin_act(int dtype, const BnActArgs& a, const BnFinalizeArgs
         case 0: return bn_fin_act_T<float>(a, f, s);
         case 1: return bn_fin_act_T<half_t>(a, f, s);
         case 2: return bn_fin_act_T<bf16_t>(a, f, s);
+        case 3: return bn_fin_act_T<float, true>(a, f, s);
     }
     return hipErrorInvalidValue;
 }
 
-template <typename T>
+template <typename T, bool SPLIT = false>
 static hipError_t bn_act_T(const BnActArgs& a, hipStream_t s) {
     constexpr int EPC = 16 / sizeof(T);
     const int Ho = a.pool ? (a.H + 1) / 2 : a.H, Wo = a.pool ? (a.W + 1) / 2 : a.W;
@@ -464,10 +473,10 @@ static hipError_t bn_act_T(const BnActArgs& a, hipStream_t s) {
     dim3 g((unsigned)nb), b(256);
     if (a.pool) {
         if (a.out_f32) hipLaunchKernelGGL((bn_act_kernel<T, true, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((bn_act_kernel<T, true, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((bn_act_kernel<T, true, false, SPLIT>), g, b, 0, s, a);
     } else {
         if (a.out_f32) hipLaunchKernelGGL((bn_act_kernel<T, false, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((bn_act_kernel<T, false, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((bn_act_kernel<T, false, false, SPLIT>), g, b, 0, s, a);
     }
     return hipGetLastError();
 }
@@ -476,6 +485,7 @@ hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t s) {
         case 0: return bn_act_T<float>(a, s);
         case 1: return bn_act_T<half_t>(a, s);
         case 2: return bn_act_T<bf16_t>(a, s);
+        case 3: return bn_act_T<float, true>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -510,7 +520,7 @@ __host__ __device__ inline BwdGeom bwd_geom(const BnBwdArgs& a) {
     return g;
 }
 
-template <typename T, bool POOL, bool APPLY>
+template <typename T, bool POOL, bool APPLY, bool SPLIT = false>
 __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
     constexpr int EPC = 16 / sizeof(T);
     __shared__ float red[APPLY ? 1 : (256 * 8 + 8)];  // [rows][CT][EPC] (EPC<=8, CT*rows<=256)
@@ -619,34 +629,30 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                     for (int d = 0; d < 4; ++d) {
                         if (!valid[d]) continue;
                         const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
-                        Chunk<T> o;
+                        float o[EPC];
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) {
                             const float t = fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
-                            o.v[e] = Elem<T>::from_f32((arg[e] == d) ? fmaf(sc[e], gz[e], t) : t);
+                            o[e] = (arg[e] == d) ? fmaf(sc[e], gz[e], t) : t;
                         }
-                        const size_t off = (bpix(n, hi, wi, a.H, a.W) * a.ldy + c0) * sizeof(T);
-                        st_chunk<T>((char*)a.dyp + off, o);
+                        st_act<T, SPLIT>((char*)a.dyp, bpix(n, hi, wi, a.H, a.W), a.ldy, c0, o);
                     }
                 }
             } else {
                 Chunk<T> v = ld_chunk<T>((const char*)a.y + ((size_t)po * a.ldy + c0) * sizeof(T));
-                Chunk<T> o;
+                float o[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float yv = Elem<T>::to_f32(v.v[e]);
                     const float gz = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yv, sc[e], sh[e]), a.slope);
                     if (APPLY) {
-                        o.v[e] = Elem<T>::from_f32(fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e])));
+                        o[e] = fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e]));
                     } else {
                         s1[e] += gz;
                         s2[e] = fmaf(gz, yv, s2[e]);
                     }
                 }
-                if (APPLY) {
-                    const size_t off = (bpix(n, ho, wo, a.H, a.W) * a.ldy + c0) * sizeof(T);
-                    st_chunk<T>((char*)a.dyp + off, o);
-                }
+                if (APPLY) st_act<T, SPLIT>((char*)a.dyp, bpix(n, ho, wo, a.H, a.W), a.ldy, c0, o);
             }
         }
     }
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(SLN * kFinCh) void bn_bwd_finalize_kernel(BnBwdArgs
 // its channels in double (4 slices, fixed order), forms ka / kb, and the blocks with blockIdx.x == 0 write dbeta,
 // dgamma, dbias and coef.
 // ---------------------------------------------------------------------------
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool SPLIT = false>
 __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int CPB = kSlab / EPC;
@@ -846,26 +852,24 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
             for (int d = 0; d < 4; ++d) {
                 if (!valid[d]) continue;
                 const int hi = 2 * ho + (d >> 1), wi = 2 * wo + (d & 1);
-                Chunk<T> o;
+                float o[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const float t = fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
-                    o.v[e] = Elem<T>::from_f32((arg[e] == d) ? fmaf(sc[e], gz[e], t) : t);
+                    o[e] = (arg[e] == d) ? fmaf(sc[e], gz[e], t) : t;
                 }
-                const size_t off = (bpix(n, hi, wi, a.H, a.W) * a.ldy + c0) * sizeof(T);
-                st_chunk<T>((char*)a.dyp + off, o);
+                st_act<T, SPLIT>((char*)a.dyp, bpix(n, hi, wi, a.H, a.W), a.ldy, c0, o);
             }
         } else {
             Chunk<T> v = ld_chunk<T>((const char*)a.y + ((size_t)po * a.ldy + c0) * sizeof(T));
-            Chunk<T> o;
+            float o[EPC];
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const float yv = Elem<T>::to_f32(v.v[e]);
                 const float gz = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yv, sc[e], sh[e]), a.slope);
-                o.v[e] = Elem<T>::from_f32(fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e])));
+                o[e] = fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e]));
             }
-            const size_t off = (bpix(n, ho, wo, a.H, a.W) * a.ldy + c0) * sizeof(T);
-            st_chunk<T>((char*)a.dyp + off, o);
+            st_act<T, SPLIT>((char*)a.dyp, bpix(n, ho, wo, a.H, a.W), a.ldy, c0, o);
         }
     }
 }
@@ -873,7 +877,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
 bool bn_bwd_fin_apply_ok(const BnBwdArgs& a) {
     static const int pmax = getenv("Y2DEV_FIN_PMAX") ? atoi(getenv("Y2DEV_FIN_PMAX")) : 128;
     return a.P > 0 && a.P <= pmax && a.ldy % kSlab == 0 && a.C == a.ldy; }
-template <typename T>
+template <typename T, bool SPLIT = false>
 static hipError_t bn_bwd_fin_apply_T(const BnBwdArgs& a, hipStream_t s) {
     constexpr int EPC = 16 / sizeof(T);
     const int Ho = a.pool ? (a.H + 1) / 2 : a.H, Wo = a.pool ? (a.W + 1) / 2 : a.W;
@@ -885,8 +889,8 @@ static hipError_t bn_bwd_fin_apply_T(const BnBwdArgs& a, hipStream_t s) {
     if (nx > cap) nx = cap;
     if (nx == 0) nx = 1;
     dim3 g((unsigned)nx, (unsigned)ny), b(256);
-    if (a.pool) hipLaunchKernelGGL((bn_bwd_fin_apply_kernel<T, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((bn_bwd_fin_apply_kernel<T, false>), g, b, 0, s, a);
+    if (a.pool) hipLaunchKernelGGL((bn_bwd_fin_apply_kernel<T, true, SPLIT>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((bn_bwd_fin_apply_kernel<T, false, SPLIT>), g, b, 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_bn_bwd_fin_apply(int dtype, const BnBwdArgs& a, hipStream_t s) {
@@ -895,6 +899,7 @@ hipError_t launch_bn_bwd_fin_apply(int dtype, const BnBwdArgs& a, hipStream_t s)
         case 0: return bn_bwd_fin_apply_T<float>(a, s);
         case 1: return bn_bwd_fin_apply_T<half_t>(a, s);
         case 2: return bn_bwd_fin_apply_T<bf16_t>(a, s);
+        case 3: return bn_bwd_fin_apply_T<float, true>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -913,11 +918,11 @@ static int bwd_blocks(const BnBwdArgs& a) {
 }
 int bn_bwd_partials(const BnBwdArgs& a) { return 2048; }
 
-template <typename T, bool APPLY>
+template <typename T, bool APPLY, bool SPLIT = false>
 static hipError_t bn_bwd_T(const BnBwdArgs& a, hipStream_t s) {
     dim3 g(APPLY ? bwd_blocks<T>(a) : a.P), b(256);
-    if (a.pool) hipLaunchKernelGGL((bn_bwd_kernel<T, true, APPLY>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((bn_bwd_kernel<T, false, APPLY>), g, b, 0, s, a);
+    if (a.pool) hipLaunchKernelGGL((bn_bwd_kernel<T, true, APPLY, SPLIT>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((bn_bwd_kernel<T, false, APPLY, SPLIT>), g, b, 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s) {
@@ -925,6 +930,7 @@ hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s) {
         case 0: a.P = bwd_blocks<float>(a); return bn_bwd_T<float, false>(a, s);
         case 1: a.P = bwd_blocks<half_t>(a); return bn_bwd_T<half_t, false>(a, s);
         case 2: a.P = bwd_blocks<bf16_t>(a); return bn_bwd_T<bf16_t, false>(a, s);
+        case 3: a.P = bwd_blocks<float>(a); return bn_bwd_T<float, false>(a, s);     // f16x2: every input of the pass is fp32
     }
     return hipErrorInvalidValue;
 }
@@ -937,6 +943,7 @@ hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s) {
         case 0: return bn_bwd_T<float, true>(a, s);
         case 1: return bn_bwd_T<half_t, true>(a, s);
         case 2: return bn_bwd_T<bf16_t, true>(a, s);
+        case 3: return bn_bwd_T<float, true, true>(a, s);
     }
     return hipErrorInvalidValue;
 }

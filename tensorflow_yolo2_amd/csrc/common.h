@@ -55,6 +55,53 @@ template <> struct Elem<bf16_t> {
     static Y2_DEV bf16_t from_f32(float v) { return (bf16_t)v; }
 };
 
+// ---------------------------------------------------------------------------
+// Split-operand element ("f16x2", dtype 3 -- round 5): one fp32-width value kept as TWO halves, hi = f16(v) and
+// lo = f16(v - hi), in two PLANES of a channel row: a pixel (or filter row) of C elements is C*4 bytes,
+// [C halves hi][C halves lo].  A product a*b is formed on the f16 matrix pipe as hi*hi + lo*hi + hi*lo (fp32
+// accumulate; the lo*lo term is 2^-22 of the product and dropped): ~22 mantissa bits at a third of the f16 MFMA rate
+// instead of the exact-f32 MFMA's sixteenth.  sizeof(hsplit_t) = 4 on purpose: every byte count of the executor
+// (row pitch, tensor size) is that of the f32 mode; what differs is the operand type the kernels read (op_t) and the
+// K loop (three plane passes).  Conv outputs, dgrad outputs and everything the batch-norm passes read are plain fp32.
+// Range: f16 keeps subnormals on this hardware (MFMA A/B inputs un-flushed, scripts/probes/mfma_denorm.hip), so the
+// lo plane degrades gracefully: |v| >= 2^-3 keeps all 22 bits, below that the absolute error floor is 2^-25.
+// Filters are pre-scaled by kSplitWScale (a power of two: exact) so that typical weights (|w| ~ 0.01 .. 0.1) sit in
+// the full-precision range; the conv epilogues multiply the accumulators by its reciprocal.
+// ---------------------------------------------------------------------------
+struct hsplit_t { uint32_t bits; };
+template <> struct Elem<hsplit_t> {
+    typedef f16x8 frag;
+    static constexpr int kPerFrag = 8;
+    static constexpr int kId = 3;
+};
+constexpr float kSplitWScale = 64.0f, kSplitWScaleInv = 1.0f / 64.0f;
+// operand type of the MFMA kernels / type of what their epilogues store
+template <typename T> struct Types { typedef T op_t; typedef T out_t; static constexpr bool kSplit = false; };
+template <> struct Types<hsplit_t> { typedef half_t op_t; typedef float out_t; static constexpr bool kSplit = true; };
+// K chunk c of a launch whose K range is [hi plane | lo plane | hi plane again] x [filter hi | filter hi | filter lo]:
+// n = chunks per plane.  Activation chunk: c mod 2n; filter chunk: c < n ? c : c - n (hi, hi, lo).
+template <bool SPLIT> Y2_DEV int split_act_chunk(int c, int n) { return SPLIT ? (c >= 2 * n ? c - 2 * n : c) : c; }
+template <bool SPLIT> Y2_DEV int split_flt_chunk(int c, int n) { return SPLIT ? (c >= n ? c - n : c) : c; }
+Y2_DEV void split_f16(float v, half_t& hi, half_t& lo) {
+    hi = (half_t)v;
+    lo = (half_t)(v - (float)hi);
+}
+// four consecutive channels c0.. of one cell of a split tensor with C elements per cell: 8 bytes into each plane
+Y2_DEV void st_split4(char* cell, int C, int c0, const float* r) {
+    half_t h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_f16(r[e], h[e], l[e]);
+    *(u32x2*)(cell + (size_t)c0 * 2) = *(const u32x2*)h;
+    *(u32x2*)(cell + (size_t)(C + c0) * 2) = *(const u32x2*)l;
+}
+Y2_DEV void ld_split4(const char* cell, int C, int c0, float* r) {
+    half_t h[4], l[4];
+    *(u32x2*)h = *(const u32x2*)(cell + (size_t)c0 * 2);
+    *(u32x2*)l = *(const u32x2*)(cell + (size_t)(C + c0) * 2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (float)h[e] + (float)l[e];
+}
+
 // XCD-aware block index (8 XCDs, each with its own L2; the dispatcher deals consecutive workgroups round-robin over
 // them): workgroup b -> logical index such that each XCD works on ONE contiguous run of the logical grid, so the
 // tiles that share an operand panel meet in one L2.  Bijective for any grid size.  mode 0: identity.

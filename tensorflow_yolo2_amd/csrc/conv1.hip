@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(Conv1Args a) {
 }
 
 hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
+    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
     dim3 g(a.nblocks), b(256);
     if (a.stats_only) {
         switch (dtype) {
@@ -436,7 +437,13 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
                 Chunk<T> o;
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(m[e]);
-                st_chunk<T>((char*)a.out + (bpix(n, ho, wo, Ho, Wo) * 32 + ch * EPC) * SZ, o);
+                if constexpr (SZ == 4) {
+                    // f16x2 mode: the consumer's tensor is split, [32 halves hi][32 halves lo] per cell (common.h)
+                    if (a.out_split) st_split4((char*)a.out + bpix(n, ho, wo, Ho, Wo) * 128, 32, ch * EPC, m);
+                    else st_chunk<T>((char*)a.out + (bpix(n, ho, wo, Ho, Wo) * 32 + ch * EPC) * SZ, o);
+                } else {
+                    st_chunk<T>((char*)a.out + (bpix(n, ho, wo, Ho, Wo) * 32 + ch * EPC) * SZ, o);
+                }
                 if (TRACK == 1 && a.ysel) {
                     const size_t pix = ((size_t)n * Ho + ho) * Wo + wo;
                     st_chunk<T>((char*)a.ysel + (pix * 32 + ch * EPC) * SZ, ys);
@@ -490,6 +497,7 @@ static void conv1_pool_T(const Conv1PoolArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_conv1_pool(int dtype, const Conv1PoolArgs& a, hipStream_t s) {
+    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
     switch (dtype) {
         case 0: conv1_pool_T<float>(a, s); break;
         case 1: conv1_pool_T<half_t>(a, s); break;
@@ -647,6 +655,7 @@ __global__ __launch_bounds__(256) void conv1_bnbwd_reduce_kernel(Conv1BnBwdArgs 
 }
 
 hipError_t launch_conv1_bnbwd_reduce(int dtype, const Conv1BnBwdArgs& a, hipStream_t s) {
+    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
     dim3 g(a.nblocks), b(256);
     switch (dtype) {
         case 0: hipLaunchKernelGGL(conv1_bnbwd_reduce_kernel<float>, g, b, 0, s, a); break;

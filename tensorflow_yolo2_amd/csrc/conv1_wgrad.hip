@@ -126,6 +126,7 @@ static hipError_t c1wg_T(const Conv1WgradArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_conv1_wgrad(int dtype, const Conv1WgradArgs& a, hipStream_t s) {
+    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
     switch (dtype) {
         case 0: return c1wg_T<float>(a, s);
         case 1: return c1wg_T<half_t>(a, s);
@@ -360,6 +361,7 @@ bool conv1_wgrad_fused_ok(int H, int W, int pool, int ldy, int elem_size) {
 }
 
 hipError_t launch_conv1_wgrad_fused(int dtype, const Conv1WgradFusedArgs& a, hipStream_t s) {
+    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
     switch (dtype) {
         case 0: return c1wgf_T<float>(a, s);
         case 1: return c1wgf_T<half_t>(a, s);
@@ -944,6 +946,7 @@ static hipError_t c1gram_T(const Conv1GramStatsArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_conv1_gram_stats(int dtype, const Conv1GramStatsArgs& a, hipStream_t s) {
+    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
     switch (dtype) {
         case 1: return c1gram_T<half_t>(a, s);
         case 2: return c1gram_T<bf16_t>(a, s);
@@ -991,6 +994,7 @@ bool conv1_wgrad_lin_ok(int H, int W, int pool, int ldy, int elem_size) {
 size_t conv1_wgrad_lin_scratch_floats() { return (size_t)kLinAcc * (kLinMid + 512); }
 
 hipError_t launch_conv1_wgrad_lin(int dtype, const Conv1WgradLinArgs& a, hipStream_t s) {
+    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
     switch (dtype) {
         case 0: return c1lin_T<float>(a, s);
         case 1: return c1lin_T<half_t>(a, s);

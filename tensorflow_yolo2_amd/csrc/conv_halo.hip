@@ -384,8 +384,9 @@ int haloq_tile_choice(int W, int row_bytes, int Cout, int M, int elem_size) {
     return bc < 0.92 * lc ? best : legacy;
 }
 
-int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad, int elem_size) {
+int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad, int elem_size, int split) {
     if (taps == 1) {
+        if (split) return 0;
         // 1x1 on conv_haloq (one tap per K-chunk, compact image): 128-byte K chunks, more than 64 output channels, enough
         // pixels for 384-pixel tiles; 384 x 64 tiles on 32x32 MFMAs (layout 1) where 384 x 128 tiles would leave CUs
         // idle, else 384 x 128 on 16x16 MFMAs (layout 2).  Opt-in (Y2_HALOQ_1X1=1): measured no faster than conv_igemm
@@ -396,7 +397,9 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgra
         return narrow ? 1 : 2;
     }
     if (taps != 9) return 0;
-    if (conv_rf_config(taps, W, row_bytes, Cout, M) || conv_rfn_config(taps, W, row_bytes, Cout, M, dgrad)) return 0;    // register-resident filters: fetched from K-contiguous rows
+    // register-resident filters: fetched from K-contiguous rows (not in the split-operand mode: three filter planes per
+    // product do not fit the register file; those shapes run on conv_haloq there)
+    if (!split && (conv_rf_config(taps, W, row_bytes, Cout, M) || conv_rfn_config(taps, W, row_bytes, Cout, M, dgrad))) return 0;
     // Round 3: the 52-wide layers run on conv_haloq too (with the leaner tap step of this round it beats conv_halo's
     // LDS filter ring there: 128 -> 256 @52x52 forward 130.6 -> 126.2 us, dgrad 130.4 -> 114.0, same box;
     // Y2_NO_HALOQ_52=1 restores round 2's split for A/B)
@@ -412,6 +415,7 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgra
 bool conv_affine_ok(int dtype, const ConvArgs& a) {
     static const bool off = getenv("Y2_NO_INFER_FOLD") != nullptr;
     if (off || a.bw_psum || a.part_mean || a.is_dgrad) return false;
+    if (dtype_split(dtype)) return false;      // f16x2: the consumer's tensor is split (two planes); two-pass form
     const int rowb = a.C * (int)dtype_size(dtype);
     // conv_rf.hip: the 128-cout forward form stores wave-private row segments and folds too; the 208-wide
     // 32 <-> 64 forms (pooled layers in Darknet-19) keep the two-pass form
@@ -432,9 +436,10 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_
     a.xcd = xcd_mode;
     int bp = conv_block_pixels(a.Cout);
     hipError_t e;
-    const int rowb = a.C * (int)dtype_size(dtype);
-    const int esz = (int)dtype_size(dtype);
-    if (dtype != 0 && ((!a.bw_psum && conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M)) ||
+    const int rowb = a.C * dtype_kbytes(dtype);         // bytes of one operand plane per pixel: what the K chunks divide
+    const int esz = (int)dtype_size(dtype);             // stored element: sizes the epilogue patch
+    const bool split = dtype_split(dtype);
+    if ((dtype == 1 || dtype == 2) && ((!a.bw_psum && conv_rf_config(a.taps, a.W, rowb, a.Cout, a.M)) ||
                        conv_rfn_config(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad))) {
         int rec = 0;
         e = launch_conv_rf(dtype, a, s, &bp, &rec);
@@ -442,12 +447,12 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_
         if (records) *records = rec;
         return e;
     }
-    if (conv_filter_layout(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad, esz)) e = launch_conv_haloq(dtype, a, s, &bp);
+    if (conv_filter_layout(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad, esz, split)) e = launch_conv_haloq(dtype, a, s, &bp);
 #ifdef Y2_DEV
     else if (a.taps == 9 && dtype == 1 && dev_rule(a.W, a.Cout) >= 0)
         e = launch_conv_halo_variant(dev_rule(a.W, a.Cout), a, s, &bp);
 #endif
-    else if (a.taps == 9 && a.W <= 52) e = launch_conv_halo(dtype, a, s, &bp);
+    else if (a.taps == 9 && a.W <= 52 && !split) e = launch_conv_halo(dtype, a, s, &bp);
     else e = launch_conv_igemm(dtype, a, s);
     if (block_pixels) *block_pixels = bp;
     if (records) *records = (a.M + bp - 1) / bp;

@@ -78,6 +78,10 @@ template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CP
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int arows) {
     static_assert(TAPS == 9 || (TAPS == 1 && CPT), "1x1 filters run on the compact image (no halo, no border taps)");
     typedef typename Elem<T>::frag frag_t;
+    typedef typename Types<T>::op_t OT;      // f16x2 mode: the operands are half planes of fp32-width rows (common.h)
+    typedef typename Types<T>::out_t YT;
+    constexpr bool SPLIT = Types<T>::kSplit;
+    static_assert(!(SPLIT && KS), "the K split of small launches is not built for the split-operand mode");
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
     constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB, KG = BKB / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     const int npieces = (nrows + RPI - 1) / RPI;
     const int abytes = arows * BKB;
     const int rowbytes = a.C * SZ;
+    const int npl = a.C * (int)sizeof(OT) / BKB;     // K chunks per operand plane (f16x2: three plane passes, common.h)
     // compact image: [16 zero rows][image buffer(s): row lambda = pixel (m0 - W - 1 + lambda)][cell index per row]
     char* const img0 = smem + (CPT ? kZeroRows * BKB : 0);
     const uint32_t* const cell_tab = (const uint32_t*)(img0 + (ADB ? 2 : 1) * abytes);
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem
     const int lrow = lane / LPR, lslot = lane % LPR;
     auto issueA = [&](int c, int ab) {
-        const char* xs = xg + lo * (long)rowbytes + (long)c * BKB;
+        const char* xs = xg + lo * (long)rowbytes + (long)split_act_chunk<SPLIT>(c, npl) * BKB;
         char* dst = img0 + ab * abytes;
         if (CPT) {
             // eight table entries first, then their DMAs: an LDS-DMA is an LDS write to the compiler, so a table read
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         wbase[i] = (const char*)a.w + ((size_t)(n0 / 32 + wc * TC + i) * TAPS * kgrow * 64 + lane) * 16;
     static_assert(KG <= 4, "immediate offsets of the fragment loads");
     auto loadB = [&](int c, int t, u32x4 (&fb)[TC][KG]) {
-        const size_t off = (size_t)(t * kgrow + c * KG) * 1024;
+        const size_t off = (size_t)(t * kgrow + split_flt_chunk<SPLIT>(c, npl) * KG) * 1024;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const char* b = wbase[i] + off;
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    int c_begin = 0, nchunks = rowbytes / BKB;     // this workgroup's chunk range [c_begin, nchunks)
+    int c_begin = 0, nchunks = SPLIT ? 3 * npl : npl;     // this workgroup's chunk range [c_begin, nchunks)
     if constexpr (KS) {
         const int per = (nchunks + a.ks_splits - 1) / a.ks_splits;
         c_begin = split * per;
@@ -320,7 +325,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         return;
     } else {
         __syncthreads();
-        conv_epilogue<T, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
+        if constexpr (SPLIT) {      // the filters were packed times kSplitWScale (a power of two)
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) acc[i][j] *= kSplitWScaleInv;
+        }
+        conv_epilogue<YT, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
     }
 }
 
@@ -404,6 +415,9 @@ template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CP
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, int arows) {
     static_assert(TAPS == 9 || (TAPS == 1 && CPT), "1x1 filters run on the compact image (no halo, no border taps)");
     typedef typename Elem<T>::frag frag_t;
+    typedef typename Types<T>::op_t OT;      // f16x2 mode: the operands are half planes of fp32-width rows (common.h)
+    typedef typename Types<T>::out_t YT;
+    constexpr bool SPLIT = Types<T>::kSplit;
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
     constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB, KG = BKB / 64;   // k-groups of 64 bytes
     constexpr int TP16 = 2 * TP, TC16 = 2 * TC;
@@ -430,6 +444,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     const int npieces = (nrows + RPI - 1) / RPI;
     const int abytes = arows * BKB;
     const int rowbytes = a.C * SZ;
+    const int npl = a.C * (int)sizeof(OT) / BKB;     // K chunks per operand plane (f16x2: three plane passes, common.h)
     // compact image: [16 zero rows][image buffer(s): row lambda = pixel (m0 - W - 1 + lambda)][cell index per row]
     char* const img0 = smem + (CPT ? kZeroRows * BKB : 0);
     const uint32_t* const cell_tab = (const uint32_t*)(img0 + (ADB ? 2 : 1) * abytes);
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem
     const int lrow = lane / LPR, lslot = lane % LPR;
     auto issueA = [&](int c, int ab) {
-        const char* xs = xg + lo * (long)rowbytes + (long)c * BKB;
+        const char* xs = xg + lo * (long)rowbytes + (long)split_act_chunk<SPLIT>(c, npl) * BKB;
         char* dst = img0 + ab * abytes;
         if (CPT) {
             // eight table entries first, then their DMAs: an LDS-DMA is an LDS write to the compiler, so a table read
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         wbase[i] = (const char*)a.w + ((size_t)(n0 / 16 + wc * TC16 + i) * TAPS * kgrow * 64 + lane) * 16;
     static_assert(KG <= 4, "immediate offsets of the fragment loads");
     auto loadB = [&](int c, int t, u32x4 (&fb)[TC16][KG]) {
-        const size_t off = (size_t)(t * kgrow + c * KG) * 1024;
+        const size_t off = (size_t)(t * kgrow + split_flt_chunk<SPLIT>(c, npl) * KG) * 1024;
 #pragma unroll
         for (int i = 0; i < TC16; ++i) {
             const char* b = wbase[i] + off;
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
 #pragma unroll
         for (int j = 0; j < TP16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = rowbytes / BKB;
+    const int nchunks = SPLIT ? 3 * npl : npl;
     const int steps = nchunks * TAPS;
     u32x4 fbq[2][TC16][KG];
     int aoffq[2][TP16];                        // fragment-row addresses of the current / the next tap step
@@ -610,7 +625,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         if (s + 1 < steps) step(IntC<1>{}, s + 1);
     }
     __syncthreads();
-    conv_epilogue16<T, WP, WC, TP, TC, CPT>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int i = 0; i < TC16; ++i)
+#pragma unroll
+            for (int j = 0; j < TP16; ++j) acc[i][j] *= kSplitWScaleInv;
+    }
+    conv_epilogue16<YT, WP, WC, TP, TC, CPT>(a, acc, smem, w, lane, m0, n0, pt, ct);
 }
 
 // compact image: pixels [m0 - W - 1, m0 + BP + W], rounded up to whole 16-row groups
@@ -634,9 +655,9 @@ static size_t haloq_lds(int arows, bool adb, bool cpt) {
 }
 template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool M16, bool CPT, int TAPS = 9>
 static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
-    typedef EpiCfg<T, WP, WC, TP, TC> Epi;
+    typedef EpiCfg<typename Types<T>::out_t, WP, WC, TP, TC> Epi;
     constexpr int BP = WP * TP * 32, BC = WC * TC * 32, RPI = 64 / (BKB / 16);
-    if ((a.C * (int)sizeof(T)) % BKB != 0) return hipErrorInvalidValue;
+    if ((a.C * (int)sizeof(typename Types<T>::op_t)) % BKB != 0) return hipErrorInvalidValue;
     const int arows = CPT ? haloq_rows_compact(a.W, BP, TAPS) : haloq_rows(a.H, a.W, BP, RPI);
     if (CPT && arows > 0xFFFF) return hipErrorOutOfMemory;
     size_t lds = haloq_lds<BKB>(arows, ADB, CPT);
@@ -660,7 +681,7 @@ static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
 template <typename T, int WP, int WC, int TP, int TC, int BKB, bool M16 = false>
 static hipError_t haloq_pick(const ConvArgs& a, hipStream_t s) {
     constexpr int BP = WP * TP * 32, RPI = 64 / (BKB / 16);
-    const int nchunks = a.C * (int)sizeof(T) / BKB;
+    const int nchunks = a.C * (int)sizeof(typename Types<T>::op_t) / BKB * (Types<T>::kSplit ? 3 : 1);
     if (halo_compact()) {
         const int arows = haloq_rows_compact(a.W, BP);
         if (nchunks > 1 && haloq_lds<BKB>(arows, true, true) <= 150 * 1024)
@@ -758,7 +779,8 @@ static hipError_t haloq_ks(const ConvArgs& a0, hipStream_t s, int* bp) {
 
 template <typename T>
 static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
-    const int kb = a.C * (int)sizeof(T);
+    typedef typename Types<T>::out_t YT;        // the epilogue patch is sized by what is stored
+    const int kb = a.C * (int)sizeof(typename Types<T>::op_t);      // bytes of one operand plane per pixel
     const bool k128 = (kb % 128) == 0;
     if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
     if (a.W > 52) {
@@ -781,19 +803,19 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
     }
     if (a.Cout > 64) {
         hipError_t e = hipErrorOutOfMemory;
-        const int tile = haloq_tile_choice(a.W, kb, a.Cout, a.M, (int)sizeof(T));
+        const int tile = haloq_tile_choice(a.W, kb, a.Cout, a.M, (int)sizeof(YT));
         if (tile != HQ_NONE) {
             // the tile (and with it the filter pack: 16-row fragments for the _M16 kernels, 32-row ones otherwise) is
             // decided by ONE function for bind and launch time (conv_halo.hip haloq_tile_choice).  (Round 2 fell through
             // to a 32x32-tile kernel on the 16-row pack in the f32 mode -- wrong outputs from batch 24 up at 416x416.)
             switch (tile) {
                 case HQ_384x128_M16:
-                    if constexpr (sizeof(T) == 2) { *bp = 384; return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s); }
+                    if constexpr (sizeof(YT) == 2) { *bp = 384; return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s); }
                     return hipErrorInvalidValue;
                 case HQ_256x128_M16: *bp = 256; return haloq_pick<T, 4, 2, 2, 2, 128, true>(a, s);
                 case HQ_384x64: *bp = 384; return haloq_pick<T, 4, 2, 3, 1, 128>(a, s);
                 case HQ_512x128:
-                    if constexpr (sizeof(T) == 2) { *bp = 512; return haloq_pick<T, 4, 2, 4, 2, 128>(a, s); }
+                    if constexpr (sizeof(YT) == 2) { *bp = 512; return haloq_pick<T, 4, 2, 4, 2, 128>(a, s); }
                     return hipErrorInvalidValue;
                 case HQ_256x128: *bp = 256; return haloq_pick<T, 4, 2, 2, 2, 128>(a, s);
                 case HQ_512x64: *bp = 512; return haloq_pick<T, 4, 2, 4, 1, 128>(a, s);
@@ -807,8 +829,10 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
         // form of rounds 1-3 on the same fragment pack: 7x7 1024 -> 1024 at batch 24 148 -> 81 us, one image 147 -> 72
         // (profiles/r04_sweep_small_m.txt; 128 x 64, 256 x 32 and 256 x 64 tie -- what is left there is a K split)
         if (k128 && a.M < 384 * 8) {
-            const hipError_t e = haloq_ks<T>(a, s, bp);
-            if (e != hipErrorNotSupported) return e;
+            if constexpr (!Types<T>::kSplit) {
+                const hipError_t e = haloq_ks<T>(a, s, bp);
+                if (e != hipErrorNotSupported) return e;
+            }
             *bp = 256;
             return haloq_pick<T, 4, 2, 2, 1, 128>(a, s);
         }
@@ -847,6 +871,7 @@ hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* b
         case 0: return haloq_T<float>(a, s, bp);
         case 1: return haloq_T<half_t>(a, s, bp);
         case 2: return haloq_T<bf16_t>(a, s, bp);
+        case 3: return haloq_T<hsplit_t>(a, s, bp);
     }
     return hipErrorInvalidValue;
 }

@@ -65,6 +65,9 @@ template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL =
 __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     typedef ConvCfg<T, WP, WC, TP, TC, BKB, NS> Cfg;
     typedef typename Elem<T>::frag frag_t;
+    typedef typename Types<T>::op_t OT;      // operand type in LDS / the fragments (f16x2 mode: half planes)
+    typedef typename Types<T>::out_t YT;     // what the epilogue stores
+    constexpr bool SPLIT = Types<T>::kSplit;
     constexpr int NW = Cfg::NW, BP = Cfg::BP, BC = Cfg::BC, SZ = Cfg::SZ;
     constexpr int LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB, IPW = Cfg::IPW, KG = Cfg::KG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,7 +107,9 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
             voff[i] = (uint32_t)(n0 + r) * (uint32_t)(Ktot * SZ) + (uint32_t)((lslot ^ ((r / RPB) % LPR)) * 16);
         }
     }
-    const int cpt = (a.C * SZ) / BKB;  // k-chunks per tap
+    // k-chunks per tap; f16x2: three passes over the planes, [x hi | x lo | x hi] against [w hi | w hi | w lo]
+    const int npl = (a.C * (int)sizeof(OT)) / BKB;
+    const int cpt = SPLIT ? 3 * npl : npl;
     const int nK = a.taps * cpt;
     const int rowpitch = (a.W + 1) * a.C * SZ;
 
@@ -117,8 +122,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
         } else {
             tapoff = rowpitch + a.C * SZ;
         }
-        const char* xs = xg + tapoff + c * BKB;
-        const char* ws = wg + (size_t)(t * a.C * SZ + c * BKB);
+        const char* xs = xg + tapoff + split_act_chunk<SPLIT>(c, npl) * BKB;
+        const char* ws = wg + (size_t)(t * a.C * SZ + split_flt_chunk<SPLIT>(c, npl) * BKB);
         char* lbase = smem + buf * Cfg::STAGE;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
@@ -170,11 +175,11 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                 for (int i = 0; i < TC; ++i)
 #pragma unroll
-                    for (int e = 0; e < Elem<T>::kPerFrag; ++e) fc[i][e] = (T)(float)(kk + e);
+                    for (int e = 0; e < Elem<T>::kPerFrag; ++e) fc[i][e] = (OT)(float)(kk + e);
 #pragma unroll
                 for (int j = 0; j < TP; ++j)
 #pragma unroll
-                    for (int e = 0; e < Elem<T>::kPerFrag; ++e) fp[j][e] = (T)(float)(kk - e);
+                    for (int e = 0; e < Elem<T>::kPerFrag; ++e) fp[j][e] = (OT)(float)(kk - e);
             } else {
 #pragma unroll
                 for (int i = 0; i < TC; ++i) fc[i] = *(const frag_t*)(lb + cbase + i * 32 * BKB + foff[g]);
@@ -206,7 +211,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
         if (t == 123.456f) ((float*)a.y)[0] = t;
         return;
     }
-    conv_epilogue<T, WP, WC, TP, TC, (ABL >> 6)>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    if constexpr (SPLIT) {      // the filters were packed times kSplitWScale (a power of two)
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) acc[i][j] *= kSplitWScaleInv;
+    }
+    conv_epilogue<YT, WP, WC, TP, TC, (ABL >> 6)>(a, acc, smem, w, lane, m0, n0, pt, ct);
 }
 
 template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0>
@@ -229,7 +240,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 // tile choice by output-channel count; rows-per-partial (BP) is reported back
 template <typename T>
 static hipError_t launch_T(const ConvArgs& a, hipStream_t s) {
-    const int kb = a.C * (int)sizeof(T);  // bytes per tap per pixel
+    const int kb = a.C * (int)sizeof(typename Types<T>::op_t);  // bytes per tap per pixel (of one operand plane)
     const bool k128 = (kb % 128) == 0;
     if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
     // 2 LDS stages and two blocks per CU beat deeper rings here (global->LDS fill rate, not
@@ -251,6 +262,7 @@ hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
         case 0: return launch_T<float>(a, s);
         case 1: return launch_T<half_t>(a, s);
         case 2: return launch_T<bf16_t>(a, s);
+        case 3: return launch_T<hsplit_t>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -1,5 +1,7 @@
 // Internal launcher interface between the network executor (net.hip) and the
-// gfx950 kernels.  dtype: 0 = f32 (parity mode, exact-f32 MFMA), 1 = f16, 2 = bf16.
+// gfx950 kernels.  dtype: 0 = f32 (parity mode, exact-f32 MFMA), 1 = f16, 2 = bf16,
+// 3 = f16x2 (round 5: split-operand mode -- every MFMA operand is a (hi, lo) pair of halves in two planes of its
+// channel row, three f16 MFMAs per product, fp32-width storage everywhere: common.h hsplit_t).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -7,7 +9,11 @@
 
 namespace y2 {
 
-inline size_t dtype_size(int dtype) { return dtype == 0 ? 4 : 2; }
+inline size_t dtype_size(int dtype) { return (dtype == 0 || dtype == 3) ? 4 : 2; }   // bytes per stored element
+inline int dtype_kbytes(int dtype) { return dtype == 0 ? 4 : 2; }                  // bytes per element of ONE K plane (MFMA operand)
+inline bool dtype_split(int dtype) { return dtype == 3; }
+// dtype of the kernels whose arithmetic is elementwise fp32 in the split mode (first layer, casts): f32
+inline int dtype_plain(int dtype) { return dtype == 3 ? 0 : dtype; }
 
 struct ConvArgs {
     const void* x;      // zero-bordered NHWC [N][H+2][W+2][C]
@@ -74,7 +80,9 @@ bool conv_affine_ok(int dtype, const ConvArgs& a);
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
 hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels); // + filters via registers
-int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad = 0, int elem_size = 2);   // filter layout launch_conv expects (0/1/2)
+// filter layout launch_conv expects (0/1/2).  row_bytes = bytes of one operand plane per pixel (dtype_kbytes), elem_size
+// = dtype_size (sizes the epilogue patch), split = dtype_split
+int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad = 0, int elem_size = 2, int split = 0);
 // Pixel x cout tile of conv_haloq on the short-row 3x3 layers (W <= 52, more than 64 couts, 128-byte K chunks), chosen by
 // a cost model of the workgroup rounds on the 256 CUs (conv_halo.hip: haloq_tile_choice).  ONE function decides both the
 // kernel (launch time) and the filter pack it reads (bind time): HQ_384x128_M16 reads 16-row fragments (layout 2),
@@ -126,6 +134,7 @@ struct Conv1PoolArgs {
     // linearity of y in the filter: sum_p dz y = sum_k W[k] X(dz)[k] + b sum dz, with X(dz) the matrix the weight
     // gradient forms anyway (conv1_wgrad.hip conv1_lin_s2_kernel).  Set instead of ysel / idx.
     unsigned* idx3 = nullptr;
+    int out_split = 0;  // f16x2 mode (T = float kernels): `out` is a split tensor ([32 halves hi][32 halves lo] per cell)
 };
 // backward reduce pass of the same layer with the conv output recomputed (x4 + dA in, psum out)
 struct Conv1BnBwdArgs {
@@ -235,7 +244,33 @@ struct WgradArgs {
     // zero-fill of dW; without one they are added into a zeroed dW with float atomics (≈1.3 TB/s chip-wide)
     float* slab = nullptr;
     size_t slab_floats = 0;
+    // f16x2 mode: x / dy are split tensors.  The launchers run the 16-bit kernels once per operand-plane pair (hi hi,
+    // lo hi, hi lo -- `quads` = 3) with xpitch / ypitch = elements of the operand type per pixel (2 Cin / 2 Cdy) and
+    // every launch's partial tiles in its own range of the slab; ONE fixed-order sum over quads * splitk partials
+    int xpitch = 0, ypitch = 0;     // 0: Cin / Cdy
+    int quads = 1;
 };
+// f16x2: the split form of a (x, dy) pair for the 16-bit kernels (dtype 3 -> 1)
+inline int wgrad_split_args(int dtype, WgradArgs& a) {
+    if (!a.xpitch) a.xpitch = a.Cin;
+    if (!a.ypitch) a.ypitch = a.Cdy;
+    if (!dtype_split(dtype)) return dtype;
+    a.xpitch = 2 * a.Cin; a.ypitch = 2 * a.Cdy; a.quads = 3;
+    return 1;
+}
+// one launch per operand-plane pair (WgradArgs::quads): hi hi, x lo, dy lo -- each with its own slab range
+template <typename K, typename... Extra>
+inline hipError_t wgrad_launch_quads(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, const WgradArgs& a, Extra... extra) {
+    const size_t n = (size_t)a.taps * a.Cin * a.Cout;
+    for (int q = 0; q < a.quads; ++q) {
+        WgradArgs b = a;
+        if (q == 1) b.x = (const char*)a.x + (size_t)a.Cin * 2;
+        if (q == 2) b.dy = (const char*)a.dy + (size_t)a.Cdy * 2;
+        if (b.slab) b.slab = a.slab + (size_t)q * a.splitk * n;
+        hipLaunchKernelGGL(kern, grid, block, lds, s, b, extra...);
+    }
+    return hipGetLastError();
+}
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);       // one tap per block
 hipError_t launch_wgrad9(int dtype, const WgradArgs& a, hipStream_t s);      // 3x3: nine taps per block
 hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a, hipStream_t s);

@@ -227,7 +227,7 @@ static void plan(y2_ctx* c) {
     {   // K-split partial tiles of the small launches (conv_haloq.hip haloq_ks): forward and dgrad of every layer
         size_t ks = 0;
         for (auto& y : c->L) {
-            if (y.first3) continue;
+            if (y.first3 || dtype_split(c->dtype)) continue;     // (the K split is not built for the split-operand mode)
             ks = std::max(ks, conv_ks_scratch_floats(y.k * y.k, y.M, y.ldy, y.cin_s * (int)sz));
             ks = std::max(ks, conv_ks_scratch_floats(y.k * y.k, y.M, y.cin, y.ldy * (int)sz));
         }
@@ -244,7 +244,7 @@ static void plan(y2_ctx* c) {
         // round 4, 16-bit types: the linear form keeps NO conv output of the first layer, only 3 index bits per element
         // (kernels.h Conv1PoolArgs::idx3); Y2_CONV1_YSEL=1 (and the f32 parity mode) keep ysel + 2 index bits
         static const bool keep_ysel = getenv("Y2_CONV1_YSEL") != nullptr;
-        const bool nosel = lin1 && c->dtype != 0 && !keep_ysel;
+        const bool nosel = lin1 && dtype_plain(c->dtype) != 0 && !keep_ysel;
         y.ysel = (y.pool && (!y.first3 || (lin1 && !nosel))) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
         y.idx0 = lin1 ? take((size_t)c->N * y.Ho * y.Wo * (y.ldy * sz / 16) * (nosel ? sizeof(unsigned) : sizeof(unsigned short)) + 256) : 0;
         if (lin1) c->o_lin = take(conv1_wgrad_lin_scratch_floats() * sizeof(float));
@@ -260,7 +260,8 @@ static void plan(y2_ctx* c) {
     }
     c->o_psum = take(psum_floats * sizeof(float));
     // split-K partials of one weight-gradient launch: at most ~1,000 workgroups x one 64 x 32 x 9 (or 128 x 128) tile
-    c->slab_floats = (size_t)1024 * 18432;
+    // (f16x2: three operand-plane pairs per launch, each with its own partial tiles)
+    c->slab_floats = (size_t)1024 * 18432 * (dtype_split(c->dtype) ? 3 : 1);
     c->o_slab = take(c->slab_floats * sizeof(float));
     c->o_dA0 = take(max_dA * sz + 256);
     c->o_dA1 = take(max_dA * sz + 256);
@@ -300,7 +301,7 @@ int y2_darknet19_spec(int kind, int output_filter, int* spec, int max_layers) {
 int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers, int tail, int tail_k, int batch,
                   int height, int width, int dtype) {
     if (!out || !spec || num_layers <= 0) return fail(Y2_ERR_ARG, "bad arguments");
-    if (dtype < 0 || dtype > 2) return fail(Y2_ERR_ARG, "dtype must be 0 (f32), 1 (f16) or 2 (bf16)");
+    if (dtype < 0 || dtype > 3) return fail(Y2_ERR_ARG, "dtype must be 0 (f32), 1 (f16), 2 (bf16) or 3 (f16x2)");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(Y2_ERR_ARG, "bad input shape");
     y2_ctx* c = new y2_ctx();
     c->N = batch; c->H = height; c->W = width; c->dtype = dtype;
@@ -318,10 +319,10 @@ int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers
             delete c;
             return fail(Y2_ERR_ARG, "layer %d: in_chl %d does not match previous out_chl %d", l, y.cin, cprev);
         }
-        if (y.cout > (dtype == 0 ? 1024 : 2048)) {
+        if (y.cout > (dtype_size(dtype) == 4 ? 1024 : 2048)) {
             delete c;
             return fail(Y2_ERR_ARG, "layer %d: out_chl %d exceeds the batch-norm kernels' row width (%d)", l, y.cout,
-                        dtype == 0 ? 1024 : 2048);
+                        dtype_size(dtype) == 4 ? 1024 : 2048);
         }
         y.first3 = (l == 0 && y.cin == 3);
         if (y.first3 && !(y.k == 3 && y.cout == 32)) {
@@ -501,9 +502,10 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
         p.wd = training ? (void*)(c->ws + y.wd) : nullptr;   // layer 0 too: y2_backward_input wants its dgrad
         p.taps = y.k * y.k; p.Cin = y.cin; p.Cout = y.cout; p.Cout_pad = y.cout_pad; p.Kc = y.cin_s;
         p.Cin_pad = y.cin_pad; p.Cdy = y.ldy;
-        p.wf_frag = conv_filter_layout(p.taps, y.W, y.cin_s * (int)c->sz(), y.cout, y.M, 0, (int)c->sz());   // forward launch
-        p.wd_frag = conv_filter_layout(p.taps, y.W, y.ldy * (int)c->sz(), y.cin, y.M, 1, (int)c->sz());   // dgrad launch: Cout = cin
-        pack_layer_plan(p, nb, (int)c->sz());
+        const int kb = dtype_kbytes(c->dtype), split = dtype_split(c->dtype) ? 1 : 0;
+        p.wf_frag = conv_filter_layout(p.taps, y.W, y.cin_s * kb, y.cout, y.M, 0, (int)c->sz(), split);   // forward launch
+        p.wd_frag = conv_filter_layout(p.taps, y.W, y.ldy * kb, y.cin, y.M, 1, (int)c->sz(), split);   // dgrad launch: Cout = cin
+        pack_layer_plan(p, nb, split ? 2 : (int)c->sz());     // (f16x2: the pack kernels run their 16-bit form on two planes)
         nb += p.wf_blocks + p.wd_blocks;
         p.opt_first = ntile;
         ntile += p.wf_blocks;
@@ -700,7 +702,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             // convolution pass (moments of the exact fp32 outputs, double merge): a randomly initialised 20-layer
             // stack amplifies a 1e-6 perturbation of the first scale / shift to 1e-3 at the top, enough to flip
             // leaky / arg-max decisions the f32 tests compare element-wise with the oracle.
-            gram1 = pool1 && training && c->lin1() && c->o_gram != 0 && !no_gram && c->dtype != 0;
+            gram1 = pool1 && training && c->lin1() && c->o_gram != 0 && !no_gram && dtype_plain(c->dtype) != 0;
             if ((!pool1 || training) && !gram1) { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
             c->gram_valid = gram1;
         } else {
@@ -765,6 +767,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             const int tiles = c->N * (y.H / 2) * ((y.W + 31) / 32);
             q.nblocks = (tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4;
             q.store_y = (c->bound_training && !c->lin1()) ? 1 : 0;
+            q.out_split = dtype_split(c->dtype) ? 1 : 0;
             if (c->nosel1()) q.idx3 = (unsigned*)(c->ws + y.idx0);
             else if (c->lin1()) { q.ysel = c->ws + y.ysel; q.idx = (unsigned short*)(c->ws + y.idx0); }
             HIPCHK(launch_conv1_pool(c->dtype, q, s));
@@ -881,6 +884,8 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         const bool rec1 = y.first3 && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
                           conv1_pool_ok(y.H, y.W, y.pool, y.cout);
         const bool lin1 = y.first3 && c->lin1();
+        // f16x2: the 3-channel layer's own dy (un-pooled / odd-sized fallbacks) is consumed by fp32 kernels
+        const int bn_dtype = y.first3 ? dtype_plain(c->dtype) : c->dtype;
         if (lin1 && c->fopt.on && forked && l == 0) {
             // Every gradient above this layer is complete once the side stream has passed the dgrad that was just
             // queued: check and update those layers there, beside this layer's (compute-bound) gradient kernel.
@@ -921,16 +926,16 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             } else if (fused_P > 0) {
                 b.P = fused_P;
             } else {
-                HIPCHK(launch_bn_bwd_reduce(c->dtype, b, s));
+                HIPCHK(launch_bn_bwd_reduce(bn_dtype, b, s));
             }
             fused_P = 0;
             // short partial lists: the finalize rides in the apply pass (bn.hip bn_bwd_fin_apply_kernel)
             static const bool no_fin_fuse = getenv("Y2_NO_BN_FIN_FUSE") != nullptr;
             if (!fused1 && !lin1 && !no_fin_fuse && bn_bwd_fin_apply_ok(b)) {
-                HIPCHK(launch_bn_bwd_fin_apply(c->dtype, b, s));
+                HIPCHK(launch_bn_bwd_fin_apply(bn_dtype, b, s));
             } else {
                 HIPCHK(launch_bn_bwd_finalize(b, s));
-                if (!fused1 && !lin1) HIPCHK(launch_bn_bwd_apply(c->dtype, b, s));
+                if (!fused1 && !lin1) HIPCHK(launch_bn_bwd_apply(bn_dtype, b, s));
             }
         }
         char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
@@ -988,7 +993,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 // keeps its own recomputing reduce
                 // (a launch of a few hundred pixels splits its K range over workgroups instead -- conv_haloq.hip haloq_ks --
                 //  and leaves the reduce to the standalone kernel: 7x7 1024 -> 512 at batch 24: 81 us fused and un-split)
-                const bool ks = c->ks_floats && conv_ks_depth(a.taps, a.M, a.Cout, a.C * (int)sz) >= 2;
+                const bool ks = c->ks_floats && conv_ks_depth(a.taps, a.M, a.Cout, a.C * dtype_kbytes(c->dtype)) >= 2;
                 const bool fuse = !no_fuse && !ks && l > 0 && l - 1 >= layer_lo && !z.first3 && z.ldy == y.cin;
                 if (l == 1 && z.first3 && c->fopt.on && c->fopt.ctrl && c->lin1() && forked)
                     a.nonfinite = (unsigned*)(c->ws + c->o_nfflag);   // this launch stores dA_0: the early guard's view of layer 0
@@ -1071,7 +1076,7 @@ int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
     const size_t sz = c->sz();
     if (what == 0) {
         const int C = y.first3 ? 3 : y.cin;
-        HIPCHK(launch_unpack_act(c->dtype, c->ws + y.xin + c->in_geom(l).base_off(sz), dst, c->N, y.H, y.W, C,
+        HIPCHK(launch_unpack_act(y.first3 ? dtype_plain(c->dtype) : c->dtype, c->ws + y.xin + c->in_geom(l).base_off(sz), dst, c->N, y.H, y.W, C,
                                  y.cin_s, s));
     } else if (what == 1) {
         if (c->fwd_folded[l])
@@ -1097,7 +1102,7 @@ int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
         if (!c->bound_training) return fail(Y2_ERR_STATE, "no gradients in inference binding");
         if (y.first3 && (c->lin1() || conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz())))
             return fail(Y2_ERR_STATE, "the first layer's dy is fused into its weight gradient and never stored");
-        HIPCHK(launch_unpack_act(c->dtype, c->ws + y.dyp + c->dy_geom(l).base_off(sz), dst, c->N, y.H, y.W, y.cout,
+        HIPCHK(launch_unpack_act(y.first3 ? dtype_plain(c->dtype) : c->dtype, c->ws + y.dyp + c->dy_geom(l).base_off(sz), dst, c->N, y.H, y.W, y.cout,
                                  y.ldy, s));
     } else {
         return fail(Y2_ERR_ARG, "unknown selector");
@@ -1286,7 +1291,8 @@ struct OpPlan {
 // split-K partial tiles of the op-level weight gradient (WgradArgs::slab): at most ~1,000 workgroups x one 64 x 32 x 9
 // (or 128 x 128) tile, as in the network plan -- the op-level gradients are then summed in a fixed order too
 // (no float atomics: bit-reproducible run to run, like the network's)
-constexpr size_t kOpSlabFloats = (size_t)1024 * 18432;
+constexpr size_t kOpSlabFloats1 = (size_t)1024 * 18432;
+static size_t op_slab_floats(int dtype) { return kOpSlabFloats1 * (dtype_split(dtype) ? 3 : 1); }
 static OpPlan op_plan(int N, int H, int W, int Cin, int Cout, int k, int dtype) {
     OpPlan p{};
     const size_t sz = dtype_size(dtype);
@@ -1304,9 +1310,9 @@ static OpPlan op_plan(int N, int H, int W, int Cin, int Cout, int k, int dtype) 
     p.dyp = take(PadGeom{N, H, W, p.Cdy}.bytes(sz));
     p.dx = take((size_t)N * H * W * p.Cin_p * sz + 256);
     p.dw = take((size_t)k * k * p.Cin_p * Cout * sizeof(float));
-    p.slab = take(kOpSlabFloats * sizeof(float));
-    p.ks_floats = std::max(conv_ks_scratch_floats(k * k, N * H * W, p.ldy, p.Cin_p * (int)sz),
-                           conv_ks_scratch_floats(k * k, N * H * W, p.Cin_p, p.Cdy * (int)sz));
+    p.slab = take(op_slab_floats(dtype) * sizeof(float));
+    p.ks_floats = dtype_split(dtype) ? 0 : std::max(conv_ks_scratch_floats(k * k, N * H * W, p.ldy, p.Cin_p * (int)sz),
+                                                     conv_ks_scratch_floats(k * k, N * H * W, p.Cin_p, p.Cdy * (int)sz));
     p.ks = take(p.ks_floats * sizeof(float));
     p.total = off;
     return p;
@@ -1330,7 +1336,7 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
               int k, int dtype, void* workspace, void* stream) {
     if (!x || !w || !y || !workspace) return fail(Y2_ERR_ARG, "null tensor");
     if (k != 1 && k != 3) return fail(Y2_ERR_ARG, "filter size must be 1 or 3");
-    if (dtype < 0 || dtype > 2) return fail(Y2_ERR_ARG, "bad dtype");
+    if (dtype < 0 || dtype > 3) return fail(Y2_ERR_ARG, "bad dtype");
     hipStream_t s = (hipStream_t)stream;
     const size_t sz = dtype_size(dtype);
     OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
@@ -1339,7 +1345,7 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
     char* xp = ws + p.xp + g.base_off(sz);
     HIPCHK(op_pack_bordered(dtype, x, ws + p.xp, p.wf - p.xp, g, Cin, s));
     HIPCHK(launch_pack_weights(dtype, w, ws + p.wf, nullptr, k * k, Cin, Cout, p.Cout_pad, p.Cin_p, 0, 0,
-                               conv_filter_layout(k * k, W, p.Cin_p * (int)sz, Cout, N * H * W, 0, (int)sz), s));
+                               conv_filter_layout(k * k, W, p.Cin_p * dtype_kbytes(dtype), Cout, N * H * W, 0, (int)sz, dtype_split(dtype)), s));
     ConvArgs a{};
     a.x = xp; a.w = ws + p.wf; a.y = ws + p.y; a.bias = bias;
     a.N = N; a.H = H; a.W = W; a.C = p.Cin_p; a.M = N * H * W; a.Cout = Cout; a.ldy = p.ldy; a.taps = k * k;
@@ -1352,7 +1358,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
                        int Cin, int Cout, int k, int dtype, void* workspace, void* stream) {
     if (!x || !w || !dy || !workspace) return fail(Y2_ERR_ARG, "null tensor");
     if (k != 1 && k != 3) return fail(Y2_ERR_ARG, "filter size must be 1 or 3");
-    if (dtype < 0 || dtype > 2) return fail(Y2_ERR_ARG, "bad dtype");
+    if (dtype < 0 || dtype > 3) return fail(Y2_ERR_ARG, "bad dtype");
     hipStream_t s = (hipStream_t)stream;
     const size_t sz = dtype_size(dtype);
     OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
@@ -1364,7 +1370,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
     HIPCHK(op_pack_bordered(dtype, dy, ws + p.dyp, p.dx - p.dyp, gy, Cout, s));
     if (dx) {
         HIPCHK(launch_pack_weights(dtype, w, nullptr, ws + p.wd, k * k, Cin, Cout, 0, 0, p.Cin_pad, p.Cdy,
-                                   conv_filter_layout(k * k, W, p.Cdy * (int)sz, p.Cin_p, N * H * W, 1, (int)sz), s));
+                                   conv_filter_layout(k * k, W, p.Cdy * dtype_kbytes(dtype), p.Cin_p, N * H * W, 1, (int)sz, dtype_split(dtype)), s));
         ConvArgs a{};
         a.x = dyp; a.w = ws + p.wd; a.y = ws + p.dx;
         a.N = N; a.H = H; a.W = W; a.C = p.Cdy; a.M = N * H * W; a.Cout = p.Cin_p; a.ldy = p.Cin_p; a.taps = k * k;
@@ -1379,7 +1385,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
         g.x = xp; g.dy = dyp; g.dW = direct ? dw : (float*)(ws + p.dw);
         g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = p.Cin_p; g.Cdy = p.Cdy; g.Cout = Cout;
         g.taps = k * k; g.splitk = 0; g.scale = 1.f;
-        g.slab = (float*)(ws + p.slab); g.slab_floats = kOpSlabFloats;
+        g.slab = (float*)(ws + p.slab); g.slab_floats = op_slab_floats(dtype);
         HIPCHK(launch_wgrad_auto(dtype, g, s));
         for (int t = 0; t < k * k && !direct; ++t)
             HIPCHK(hipMemcpyAsync(dw + (size_t)t * Cin * Cout, (float*)(ws + p.dw) + (size_t)t * p.Cin_p * Cout,

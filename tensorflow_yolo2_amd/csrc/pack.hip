@@ -93,6 +93,7 @@ hipError_t launch_pack_input_u8(int dtype, const uint8_t* img, void* x4, int N, 
         case 0: return pack_input_u8_T<float>(img, x4, N, H, W, s);
         case 1: return pack_input_u8_T<half_t>(img, x4, N, H, W, s);
         case 2: return pack_input_u8_T<bf16_t>(img, x4, N, H, W, s);
+        case 3: return pack_input_u8_T<float>(img, x4, N, H, W, s);     // f16x2: the 3-channel layer runs in exact fp32
     }
     return hipErrorInvalidValue;
 }
@@ -102,6 +103,7 @@ hipError_t launch_pack_input(int dtype, const float* img, void* x4, int N, int H
         case 0: return pack_input_T<float>(img, x4, N, H, W, s);
         case 1: return pack_input_T<half_t>(img, x4, N, H, W, s);
         case 2: return pack_input_T<bf16_t>(img, x4, N, H, W, s);
+        case 3: return pack_input_T<float>(img, x4, N, H, W, s);
     }
     return hipErrorInvalidValue;
 }
@@ -161,6 +163,39 @@ __global__ void act_pack8_kernel(const float* __restrict__ in, T* __restrict__ x
         }
     }
 }
+// f16x2 mode: the bordered tensor is split (cell = [Cs halves hi][Cs halves lo], common.h hsplit_t).  Op-level entries
+// and debug reads only (the network's own tensors are written split by the batch-norm passes): one element per thread
+template <bool PACK>
+__global__ void act_pack_split_kernel(const float* in, char* xp, float* out, int N, int H, int W, int C, int Cs) {
+    const int Ci = PACK ? Cs : C;
+    const size_t total = (size_t)N * H * W * Ci;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Ci);
+        const size_t p = i / Ci;
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        const int n = (int)(p / ((size_t)W * H));
+        half_t* cell = (half_t*)(xp + bpix(n, h, w, H, W) * (size_t)Cs * 4);
+        if (PACK) {
+            half_t hi, lo;
+            split_f16(c < C ? in[p * C + c] : 0.f, hi, lo);
+            cell[c] = hi;
+            cell[Cs + c] = lo;
+        } else {
+            out[i] = (float)cell[c] + (float)cell[Cs + c];
+        }
+    }
+}
+template <bool PACK>
+static hipError_t act_pack_split(const float* in, void* xp, float* out, int N, int H, int W, int C, int Cs, hipStream_t s) {
+    size_t total = (size_t)N * H * W * (PACK ? Cs : C);
+    size_t nb = (total + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL((act_pack_split_kernel<PACK>), dim3((unsigned)nb), dim3(256), 0, s, in, (char*)xp, out, N, H, W, C, Cs);
+    return hipGetLastError();
+}
+
 template <typename T, bool PACK>
 static hipError_t act_pack_T(const float* in, void* xp, float* out, int N, int H, int W, int C, int Cs,
                              hipStream_t s) {
@@ -187,6 +222,7 @@ hipError_t launch_pack_act(int dtype, const float* in, void* xp, int N, int H, i
         case 0: return act_pack_T<float, true>(in, xp, nullptr, N, H, W, C, Cs, s);
         case 1: return act_pack_T<half_t, true>(in, xp, nullptr, N, H, W, C, Cs, s);
         case 2: return act_pack_T<bf16_t, true>(in, xp, nullptr, N, H, W, C, Cs, s);
+        case 3: return act_pack_split<true>(in, xp, nullptr, N, H, W, C, Cs, s);
     }
     return hipErrorInvalidValue;
 }
@@ -227,6 +263,7 @@ __global__ void act_pack_region_kernel(const float* __restrict__ in, char* __res
 }
 hipError_t launch_pack_act_region(int dtype, const float* in, void* region, size_t region_bytes, size_t front_px, int N,
                                   int H, int W, int C, int Cs, hipStream_t s) {
+    if (dtype_split(dtype)) return hipErrorNotSupported;     // the caller zeroes the allocation and packs the body
     const int epc = dtype == 0 ? 4 : 8;
     if (C % epc || Cs % epc || region_bytes % 16 || (((uintptr_t)in | (uintptr_t)region) & 15)) return hipErrorNotSupported;
     const size_t chunks = region_bytes / 16;
@@ -247,6 +284,7 @@ hipError_t launch_unpack_act(int dtype, const void* xp, float* out, int N, int H
         case 0: return act_pack_T<float, false>(nullptr, (void*)xp, out, N, H, W, C, Cs, s);
         case 1: return act_pack_T<half_t, false>(nullptr, (void*)xp, out, N, H, W, C, Cs, s);
         case 2: return act_pack_T<bf16_t, false>(nullptr, (void*)xp, out, N, H, W, C, Cs, s);
+        case 3: return act_pack_split<false>(nullptr, (void*)xp, out, N, H, W, C, Cs, s);
     }
     return hipErrorInvalidValue;
 }
@@ -286,6 +324,7 @@ __global__ void cast_f32x8_kernel(const T* __restrict__ src, float* __restrict__
 }
 hipError_t launch_cast_to_f32(int dtype, const void* src, float* dst, size_t rows, int C, int lds, hipStream_t s,
                               float scale) {
+    dtype = dtype_plain(dtype);      // f16x2: conv outputs and gradients wrt activations are fp32
     if (C % 8 == 0 && lds % 8 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
         size_t nb8 = (rows * (C / 8) + 255) / 256;
         if (nb8 > 16384) nb8 = 16384;
@@ -325,6 +364,7 @@ __global__ void convert_grad_kernel(const float* src, T* dst, int M, int C, int 
 }
 hipError_t launch_convert_grad(int dtype, const float* src, void* dst, int M, int C, int ldd, float scale,
                                hipStream_t s) {
+    dtype = dtype_plain(dtype);
     size_t total = (size_t)M * ldd;
     size_t nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;
@@ -363,7 +403,8 @@ __host__ __device__ inline size_t frag_chunk_any(int layout, int row, int t, int
     return layout == 2 ? frag_chunk16(row, t, k, taps, krow, EPC) : frag_chunk(row, t, k, taps, krow, EPC);
 }
 
-template <typename T>
+// SPLIT (f16x2 mode, T = half_t): a packed row holds two planes per tap, [Kc halves hi][Kc halves lo] of W * kSplitWScale
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pack_wf_kernel(const float* __restrict__ W, T* __restrict__ wf, int taps,
                                                       int Cin, int Cout, int Cout_pad, int Kc, int frag) {
     constexpr int EPC = 16 / sizeof(T);
@@ -379,13 +420,25 @@ __global__ __launch_bounds__(256) void pack_wf_kernel(const float* __restrict__ 
     for (int r = ty; r < 32; r += 8) {
         const int co = co0 + r, ci = ci0 + tx;
         if (co < Cout_pad && ci < Kc) {
-            const size_t o = frag ? frag_chunk_any(frag, co, t, ci - ci % EPC, taps, Kc, EPC) * EPC + ci % EPC
-                                  : ((size_t)co * taps + t) * Kc + ci;
-            wf[o] = Elem<T>::from_f32(tile[tx][r]);
+            if constexpr (SPLIT) {
+                half_t hl[2];
+                split_f16(tile[tx][r] * kSplitWScale, hl[0], hl[1]);
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    const int k = pl * Kc + ci;
+                    const size_t o = frag ? frag_chunk_any(frag, co, t, k - k % EPC, taps, 2 * Kc, EPC) * EPC + k % EPC
+                                          : ((size_t)co * taps + t) * 2 * Kc + k;
+                    wf[o] = hl[pl];
+                }
+            } else {
+                const size_t o = frag ? frag_chunk_any(frag, co, t, ci - ci % EPC, taps, Kc, EPC) * EPC + ci % EPC
+                                      : ((size_t)co * taps + t) * Kc + ci;
+                wf[o] = Elem<T>::from_f32(tile[tx][r]);
+            }
         }
     }
 }
-template <typename T>
+template <typename T, bool SPLIT = false>
 __global__ void pack_wd_kernel(const float* __restrict__ W, T* __restrict__ wd, int taps, int Cin, int Cout,
                                int Cin_pad, int Cdy, int frag) {
     constexpr int EPC = 16 / sizeof(T);
@@ -396,22 +449,34 @@ __global__ void pack_wd_kernel(const float* __restrict__ W, T* __restrict__ wd, 
         const int ci = (int)(i / ((size_t)Cdy * taps));
         float v = 0.f;
         if (ci < Cin && co < Cout) v = W[((size_t)(taps - 1 - t) * Cin + ci) * Cout + co];
-        const size_t o = frag ? frag_chunk_any(frag, ci, t, co - co % EPC, taps, Cdy, EPC) * EPC + co % EPC : i;
-        wd[o] = Elem<T>::from_f32(v);
+        if constexpr (SPLIT) {
+            half_t hl[2];
+            split_f16(v * kSplitWScale, hl[0], hl[1]);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const int k = pl * Cdy + co;
+                const size_t o = frag ? frag_chunk_any(frag, ci, t, k - k % EPC, taps, 2 * Cdy, EPC) * EPC + k % EPC
+                                      : ((size_t)ci * taps + t) * 2 * Cdy + k;
+                wd[o] = hl[pl];
+            }
+        } else {
+            const size_t o = frag ? frag_chunk_any(frag, ci, t, co - co % EPC, taps, Cdy, EPC) * EPC + co % EPC : i;
+            wd[o] = Elem<T>::from_f32(v);
+        }
     }
 }
-template <typename T>
+template <typename T, bool SPLIT = false>
 static hipError_t pack_weights_T(const float* W, void* wf, void* wd, int taps, int Cin, int Cout, int Cout_pad,
                                  int Kc, int Cin_pad, int Cdy, int frag, hipStream_t s) {
     if (wf) {
         dim3 g((Cout_pad + 31) / 32, (Kc + 31) / 32, taps);
-        hipLaunchKernelGGL(pack_wf_kernel<T>, g, dim3(256), 0, s, W, (T*)wf, taps, Cin, Cout, Cout_pad, Kc, frag);
+        hipLaunchKernelGGL((pack_wf_kernel<T, SPLIT>), g, dim3(256), 0, s, W, (T*)wf, taps, Cin, Cout, Cout_pad, Kc, frag);
     }
     if (wd) {
         size_t total = (size_t)Cin_pad * taps * Cdy;
         size_t nb = (total + 255) / 256;
         if (nb > 16384) nb = 16384;
-        hipLaunchKernelGGL(pack_wd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, W, (T*)wd, taps, Cin, Cout, Cin_pad,
+        hipLaunchKernelGGL((pack_wd_kernel<T, SPLIT>), dim3((unsigned)nb), dim3(256), 0, s, W, (T*)wd, taps, Cin, Cout, Cin_pad,
                            Cdy, frag);
     }
     return hipGetLastError();
@@ -422,6 +487,7 @@ hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, in
         case 0: return pack_weights_T<float>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, frag, s);
         case 1: return pack_weights_T<half_t>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, frag, s);
         case 2: return pack_weights_T<bf16_t>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, frag, s);
+        case 3: return pack_weights_T<half_t, true>(W, wf, wd, taps, Cin, Cout, Cout_pad, Kc, Cin_pad, Cdy, frag, s);
     }
     return hipErrorInvalidValue;
 }
@@ -430,7 +496,36 @@ hipError_t launch_pack_weights(int dtype, const float* W, void* wf, void* wd, in
 // every layer's filters in ONE launch (the per-layer launches were latency-bound:
 // 2 x 21 kernels of ~8 us per step).  A block looks its layer up in a small table.
 // ---------------------------------------------------------------------------
-template <typename T>
+// one 16-byte chunk (EPC filter values v[], k = first K index of the chunk inside its tap) of packed row `row`, tap t, of
+// a pack whose rows hold krow K elements per tap.  layout: 0 K-contiguous rows, 1 / 2 fragment order.
+// SPLIT (f16x2 mode, T = half_t): two chunks -- the halves of v * kSplitWScale into the hi plane (k) and the lo plane
+// (krow + k) of a row that holds 2 * krow halves per tap
+template <typename T, bool SPLIT>
+Y2_DEV void st_filter_chunk(T* base, int layout, int row, int t, int k, int taps, int krow, const float* v) {
+    constexpr int EPC = 16 / sizeof(T);
+    if constexpr (SPLIT) {
+        Chunk<T> hi, lo;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) split_f16(v[e] * kSplitWScale, hi.v[e], lo.v[e]);
+        const int kr2 = 2 * krow;
+        if (layout) {
+            st_chunk<T>(base + frag_chunk_any(layout, row, t, k, taps, kr2, EPC) * EPC, hi);
+            st_chunk<T>(base + frag_chunk_any(layout, row, t, krow + k, taps, kr2, EPC) * EPC, lo);
+        } else {
+            T* q = base + ((size_t)row * taps + t) * kr2 + k;
+            st_chunk<T>(q, hi);
+            st_chunk<T>(q + krow, lo);
+        }
+    } else {
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.v[e] = Elem<T>::from_f32(v[e]);
+        if (layout) st_chunk<T>(base + frag_chunk_any(layout, row, t, k, taps, krow, EPC) * EPC, o);
+        else st_chunk<T>(base + ((size_t)row * taps + t) * krow + k, o);
+    }
+}
+
+template <typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restrict__ tab, int nlayers) {
     constexpr int EPC = 16 / sizeof(T);       // elements per 16-byte store
     constexpr int CPR = 64 / EPC;             // chunks per 64-element tile row
@@ -460,11 +555,10 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
             const int col = p * RPP + cr;
             const int co = co0 + col, ci = ci0 + cs * EPC;
             if (co < L.Cout_pad && ci < L.Kc) {
-                Chunk<T> o;
+                float o[EPC];
 #pragma unroll
-                for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[cs * EPC + k][col]);
-                if (L.wf_frag) st_chunk<T>(wf + frag_chunk_any(L.wf_frag, co, t, ci, L.taps, L.Kc, EPC) * EPC, o);
-                else st_chunk<T>(wf + ((size_t)co * L.taps + t) * L.Kc + ci, o);
+                for (int k = 0; k < EPC; ++k) o[k] = tile[cs * EPC + k][col];
+                st_filter_chunk<T, SPLIT>(wf, L.wf_frag, co, t, ci, L.taps, L.Kc, o);
             }
         }
     } else if (L.wd) {
@@ -482,22 +576,20 @@ __global__ __launch_bounds__(256) void pack_all_kernel(const PackLayer* __restri
                 const uint32_t q = i / (uint32_t)cpr;
                 const int tt = (int)(q % (uint32_t)L.taps), ci = (int)(q / (uint32_t)L.taps);
                 const int co = cc * EPC;
-                Chunk<T> o;
+                float o[EPC];
                 const float* src = W + ((size_t)(L.taps - 1 - tt) * L.Cin + ci) * L.Cout + co;
                 if (ci < L.Cin && vec && co + EPC <= L.Cout) {
 #pragma unroll
                     for (int e4 = 0; e4 < EPC; e4 += 4) {
                         const f32x4 v = *(const f32x4*)(src + e4);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o.v[e4 + j] = Elem<T>::from_f32(v[j]);
+                        for (int j = 0; j < 4; ++j) o[e4 + j] = v[j];
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < EPC; ++e)
-                        o.v[e] = Elem<T>::from_f32((ci < L.Cin && co + e < L.Cout) ? src[e] : 0.f);
+                    for (int e = 0; e < EPC; ++e) o[e] = (ci < L.Cin && co + e < L.Cout) ? src[e] : 0.f;
                 }
-                if (L.wd_frag) st_chunk<T>(wd + frag_chunk_any(L.wd_frag, ci, tt, co, L.taps, L.Cdy, EPC) * EPC, o);
-                else st_chunk<T>(wd + (size_t)i * EPC, o);
+                st_filter_chunk<T, SPLIT>(wd, L.wd_frag, ci, tt, co, L.taps, L.Cdy, o);
             }
         }
     }
@@ -518,7 +610,7 @@ Y2_DEV void opt_update(float& p, float& s0, float& s1, float g, float lr_t, floa
     else momentum_update(p, s0, g, lr_t, b1);
 }
 
-template <typename T, int KIND>
+template <typename T, int KIND, bool SPLIT = false>
 __global__ __launch_bounds__(256) void opt_pack_kernel(OptPackArgs a) {
     constexpr int EPC = 16 / sizeof(T);
     constexpr int CPR = 64 / EPC;
@@ -599,11 +691,10 @@ __global__ __launch_bounds__(256) void opt_pack_kernel(OptPackArgs a) {
             const int r = p * RPP + cr;
             const int ci = ci0 + r, co = co0 + cs * EPC;
             if (ci < L.Cin_pad && co < L.Cdy) {
-                Chunk<T> o;
+                float o[EPC];
 #pragma unroll
-                for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[r][cs * EPC + k]);
-                if (L.wd_frag) st_chunk<T>(wd + frag_chunk_any(L.wd_frag, ci, tt, co, L.taps, L.Cdy, EPC) * EPC, o);
-                else st_chunk<T>(wd + ((size_t)ci * L.taps + tt) * L.Cdy + co, o);
+                for (int k = 0; k < EPC; ++k) o[k] = tile[r][cs * EPC + k];
+                st_filter_chunk<T, SPLIT>(wd, L.wd_frag, ci, tt, co, L.taps, L.Cdy, o);
             }
         }
     }
@@ -616,11 +707,10 @@ __global__ __launch_bounds__(256) void opt_pack_kernel(OptPackArgs a) {
             const int col = p * RPP + cr;
             const int co = co0 + col, ci = ci0 + cs * EPC;
             if (co < L.Cout_pad && ci < L.Kc) {
-                Chunk<T> o;
+                float o[EPC];
 #pragma unroll
-                for (int k = 0; k < EPC; ++k) o.v[k] = Elem<T>::from_f32(tile[cs * EPC + k][col]);
-                if (L.wf_frag) st_chunk<T>(wf + frag_chunk_any(L.wf_frag, co, t, ci, L.taps, L.Kc, EPC) * EPC, o);
-                else st_chunk<T>(wf + ((size_t)co * L.taps + t) * L.Kc + ci, o);
+                for (int k = 0; k < EPC; ++k) o[k] = tile[cs * EPC + k][col];
+                st_filter_chunk<T, SPLIT>(wf, L.wf_frag, co, t, ci, L.taps, L.Kc, o);
             }
         }
     }
@@ -638,6 +728,8 @@ hipError_t launch_opt_pack(int dtype, const OptPackArgs& a, hipStream_t s) {
         case 3: Y2_OP(half_t, 1); break;
         case 4: Y2_OP(bf16_t, 0); break;
         case 5: Y2_OP(bf16_t, 1); break;
+        case 6: hipLaunchKernelGGL((opt_pack_kernel<half_t, 0, true>), g, b, 0, s, a); break;     // f16x2
+        case 7: hipLaunchKernelGGL((opt_pack_kernel<half_t, 1, true>), g, b, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
 #undef Y2_OP
@@ -659,6 +751,7 @@ hipError_t launch_pack_all(int dtype, const PackLayer* tab_dev, int nlayers, int
         case 0: hipLaunchKernelGGL(pack_all_kernel<float>, g, b, 0, s, tab_dev, nlayers); break;
         case 1: hipLaunchKernelGGL(pack_all_kernel<half_t>, g, b, 0, s, tab_dev, nlayers); break;
         case 2: hipLaunchKernelGGL(pack_all_kernel<bf16_t>, g, b, 0, s, tab_dev, nlayers); break;
+        case 3: hipLaunchKernelGGL((pack_all_kernel<half_t, true>), g, b, 0, s, tab_dev, nlayers); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -677,6 +770,7 @@ __global__ void pack_conv1_kernel(const float* W, T* wp) {
 }
 hipError_t launch_pack_conv1_weights(int dtype, const float* W, void* wp, hipStream_t s) {
     dim3 g(6), b(256);
+    dtype = dtype_plain(dtype);
     switch (dtype) {
         case 0: hipLaunchKernelGGL(pack_conv1_kernel<float>, g, b, 0, s, W, (float*)wp); break;
         case 1: hipLaunchKernelGGL(pack_conv1_kernel<half_t>, g, b, 0, s, W, (half_t*)wp); break;

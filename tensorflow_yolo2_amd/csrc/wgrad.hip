@@ -84,22 +84,22 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
         toff = 0;
     }
     const long kb = s_begin * BKP;
-    const char* xg = (const char*)a.x + ((kb + toff) * a.Cin + ci0) * SZ;
-    const char* yg = (const char*)a.dy + (kb * a.Cdy + co0) * SZ;
-    const long xstep = (long)BKP * a.Cin * SZ, ystep = (long)BKP * a.Cdy * SZ;
+    const char* xg = (const char*)a.x + ((kb + toff) * a.xpitch + ci0) * SZ;
+    const char* yg = (const char*)a.dy + (kb * a.ypitch + co0) * SZ;
+    const long xstep = (long)BKP * a.xpitch * SZ, ystep = (long)BKP * a.ypitch * SZ;
 
     uint32_t voffx[Cfg::IPWX], voffy[Cfg::IPWY];
 #pragma unroll
     for (int i = 0; i < Cfg::IPWX; ++i) {
         const int row = (i * NW + w) * Cfg::RPIX + lane / Cfg::LPRX;
         const int sl = (lane % Cfg::LPRX) ^ wg_swz<ROWX, SZ>(row);
-        voffx[i] = (uint32_t)row * (uint32_t)(a.Cin * SZ) + sl * 16;
+        voffx[i] = (uint32_t)row * (uint32_t)(a.xpitch * SZ) + sl * 16;
     }
 #pragma unroll
     for (int i = 0; i < Cfg::IPWY; ++i) {
         const int row = (i * NW + w) * Cfg::RPIY + lane / Cfg::LPRY;
         const int sl = (lane % Cfg::LPRY) ^ wg_swz<ROWY, SZ>(row);
-        voffy[i] = (uint32_t)row * (uint32_t)(a.Cdy * SZ) + sl * 16;
+        voffy[i] = (uint32_t)row * (uint32_t)(a.ypitch * SZ) + sl * 16;
     }
     auto stage = [&](int st, int buf) {
         const char* xs = xg + (long)st * xstep;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
                 const int ci = ci0 + (wi * TI + i) * 32 + acc_row(q, hh);
                 if (ci < a.Cin && co < a.Cout) {
                     const size_t o = ((size_t)tap * a.Cin + ci) * a.Cout + co;
-                    if (a.splitk == 1) a.dW[o] = acc[i][j][q] * a.scale;
+                    if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[i][j][q] * a.scale;
                     else if (a.slab) a.slab[(size_t)split * a.taps * a.Cin * a.Cout + o] = acc[i][j][q];
                     else atomicAdd(a.dW + o, acc[i][j][q] * a.scale);
                 }
@@ -226,8 +226,7 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     }
     hipError_t e = wgrad_split_prepare(a, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS, s, a);
-    e = hipGetLastError();
+    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS, s, a);
     return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 
@@ -284,29 +283,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 hipError_t wgrad_split_prepare(WgradArgs& a, hipStream_t s) {
-    if (a.splitk <= 1) return hipSuccess;
+    if (a.splitk * a.quads <= 1) return hipSuccess;
     const size_t n = (size_t)a.taps * a.Cin * a.Cout;
     static const bool no_slab = getenv("Y2_NO_WGRAD_SLAB") != nullptr;      // A/B switch: float atomics instead
-    if (!no_slab && a.slab && (n & 3) == 0 && (size_t)a.splitk * n <= a.slab_floats) return hipSuccess;
+    if (!no_slab && a.slab && (n & 3) == 0 && (size_t)a.splitk * a.quads * n <= a.slab_floats) return hipSuccess;
     a.slab = nullptr;      // atomics into a zeroed dW
     return hipMemsetAsync(a.dW, 0, n * sizeof(float), s);
 }
 hipError_t wgrad_split_finish(const WgradArgs& a, hipStream_t s) {
-    if (a.splitk <= 1 || !a.slab) return hipSuccess;
+    const int parts = a.splitk * a.quads;       // f16x2: the three operand-plane pairs are summed like splits
+    if (parts <= 1 || !a.slab) return hipSuccess;
     const size_t n4 = (size_t)a.taps * a.Cin * a.Cout / 4;
-    if (a.splitk <= 8) {
+    if (parts <= 8) {
         hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.slab, a.dW, n4,
-                           a.splitk, n4, a.scale);
+                           parts, n4, a.scale);
     } else {
         hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, s, a.slab, a.dW, n4,
-                           a.splitk, n4, a.scale);
+                           parts, n4, a.scale);
     }
     return hipGetLastError();
 }
 
 #ifdef Y2_DEV
 // development variants (f16, 128 x 128 tiles): stages x blocks target of the 1x1 form
-hipError_t launch_wgrad_variant(int variant, const WgradArgs& a, hipStream_t s) {
+hipError_t launch_wgrad_variant(int variant, const WgradArgs& a0, hipStream_t s) {
+    WgradArgs a = a0;
+    wgrad_split_args(1, a);
     typedef half_t T;
     switch (variant) {
         case 100: return wg_launch<T, 2, 2, 2, 2, 2>(a, s, 256);
@@ -322,8 +324,10 @@ hipError_t launch_wgrad_variant(int variant, const WgradArgs& a, hipStream_t s) 
 }
 #endif
 
-hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
+hipError_t launch_wgrad(int dtype, const WgradArgs& a0, hipStream_t s) {
+    WgradArgs a = a0;
     if (a.Cin % 32 != 0 || (a.Cin > 128 && a.Cin % 128 != 0)) return hipErrorInvalidValue;
+    dtype = wgrad_split_args(dtype, a);
     switch (dtype) {
         case 0: return wg_T<float>(a, s);
         case 1: return wg_T<half_t>(a, s);

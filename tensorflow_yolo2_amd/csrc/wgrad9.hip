@@ -80,9 +80,9 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
     const int xpieces = wrows / Cfg::RPIX;
     const long kb = s_begin * BKP;
     // window of step s starts at bordered position kb + s*BKP - pitch - 1 (top-left tap)
-    const char* xg = (const char*)a.x + ((kb - pitch - 1) * a.Cin + ci0) * SZ;
-    const char* yg = (const char*)a.dy + (kb * a.Cdy + co0) * SZ;
-    const long xstep = (long)BKP * a.Cin * SZ, ystep = (long)BKP * a.Cdy * SZ;
+    const char* xg = (const char*)a.x + ((kb - pitch - 1) * a.xpitch + ci0) * SZ;
+    const char* yg = (const char*)a.dy + (kb * a.ypitch + co0) * SZ;
+    const long xstep = (long)BKP * a.xpitch * SZ, ystep = (long)BKP * a.ypitch * SZ;
 
     const int lrx = lane / Cfg::LPRX, lsx = lane % Cfg::LPRX;
     uint32_t voffy[Cfg::IPWY];
@@ -90,7 +90,7 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
     for (int i = 0; i < Cfg::IPWY; ++i) {
         const int row = (i * NW + w) * Cfg::RPIY + lane / Cfg::LPRY;
         const int sl = (lane % Cfg::LPRY) ^ wg9_swz<ROWY, SZ>(row);
-        voffy[i] = (uint32_t)row * (uint32_t)(a.Cdy * SZ) + sl * 16;
+        voffy[i] = (uint32_t)row * (uint32_t)(a.ypitch * SZ) + sl * 16;
     }
     auto stage = [&](int st, int buf) {
         const char* xs = xg + (long)st * xstep;
@@ -98,7 +98,7 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
         char* lb = smem + buf * stage_bytes;
         for (int i = w; i < xpieces; i += NW) {
             const int row = i * Cfg::RPIX + lrx;
-            const uint32_t off = (uint32_t)row * (uint32_t)(a.Cin * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
+            const uint32_t off = (uint32_t)row * (uint32_t)(a.xpitch * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
             glds16(xs + off, lb + i * 1024);
         }
 #pragma unroll
@@ -215,7 +215,7 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
                 const int ci = ci0 + wi * 32 + acc_row(q, hh);
                 if (ci < a.Cin) {
                     const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
-                    if (a.splitk == 1) a.dW[o] = acc[t][j][q] * a.scale;
+                    if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[t][j][q] * a.scale;
                     else if (a.slab) a.slab[(size_t)split * 9 * a.Cin * a.Cout + o] = acc[t][j][q];
                     else atomicAdd(a.dW + o, acc[t][j][q] * a.scale);
                 }
@@ -289,9 +289,9 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
     const int nsteps = (int)(s_end > s_begin ? s_end - s_begin : 0);
 
     const long kb = s_begin * BKP;
-    const char* xg = (const char*)a.x + ((kb - pitch - 1) * a.Cin + ci0) * SZ;   // window row 0 of step 0
-    const char* yg = (const char*)a.dy + (kb * a.Cdy + co0) * SZ;
-    const long xstep = (long)BKP * a.Cin * SZ, ystep = (long)BKP * a.Cdy * SZ;
+    const char* xg = (const char*)a.x + ((kb - pitch - 1) * a.xpitch + ci0) * SZ;   // window row 0 of step 0
+    const char* yg = (const char*)a.dy + (kb * a.ypitch + co0) * SZ;
+    const long xstep = (long)BKP * a.xpitch * SZ, ystep = (long)BKP * a.ypitch * SZ;
     char* const ybase = smem + ringB;
 
     const int lrx = lane / Cfg::LPRX, lsx = lane % Cfg::LPRX;
@@ -300,14 +300,14 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
     for (int i = 0; i < Cfg::IPWY; ++i) {
         const int row = (i * NW + w) * Cfg::RPIY + lane / Cfg::LPRY;
         const int sl = (lane % Cfg::LPRY) ^ wg9_swz<ROWY, SZ>(row);
-        voffy[i] = (uint32_t)row * (uint32_t)(a.Cdy * SZ) + sl * 16;
+        voffy[i] = (uint32_t)row * (uint32_t)(a.ypitch * SZ) + sl * 16;
     }
     auto stage_x = [&](int g) {   // BKP rows: BKP / RPIX pieces of 1 KiB (aligned: a piece never wraps)
         const char* xs = xg + (long)g * xstep;
         char* dst = smem + (((uint32_t)g * (uint32_t)BKP * ROWX) & maskB);
         for (int i = w; i < BKP / Cfg::RPIX; i += NW) {
             const int row = i * Cfg::RPIX + lrx;   // row & 3 == LDS row & 3 (groups are 64-row aligned)
-            const uint32_t off = (uint32_t)row * (uint32_t)(a.Cin * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
+            const uint32_t off = (uint32_t)row * (uint32_t)(a.xpitch * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
             glds16(xs + off, dst + i * 1024);
         }
     };
@@ -392,7 +392,7 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
                 const int ci = ci0 + wi * 32 + acc_row(q, hh);
                 if (ci < a.Cin) {
                     const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
-                    if (a.splitk == 1) a.dW[o] = acc[t][q] * a.scale;
+                    if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[t][q] * a.scale;
                     else if (a.slab) a.slab[(size_t)split * 9 * a.Cin * a.Cout + o] = acc[t][q];
                     else atomicAdd(a.dW + o, acc[t][q] * a.scale);
                 }
@@ -451,8 +451,7 @@ static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0)
     }
     hipError_t e = wgrad_split_prepare(a, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), lds, s, a, lgR, G);
-    e = hipGetLastError();
+    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), lds, s, a, lgR, G);
     return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 
@@ -499,8 +498,7 @@ static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s, int blocks_target = 
     }
     hipError_t e = wgrad_split_prepare(a, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), lds, s, a, wrows);
-    e = hipGetLastError();
+    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), lds, s, a, wrows);
     return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 // deepest ring that fits (4 stages where the window is small)
@@ -566,8 +564,10 @@ static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
 }
 
 // 3x3 only; the window grows with the image row, so this form is for short rows
-hipError_t launch_wgrad9(int dtype, const WgradArgs& a, hipStream_t s) {
+hipError_t launch_wgrad9(int dtype, const WgradArgs& a0, hipStream_t s) {
+    WgradArgs a = a0;
     if (a.taps != 9 || a.Cin % 32 != 0) return hipErrorInvalidValue;
+    dtype = wgrad_split_args(dtype, a);
     switch (dtype) {
         case 0: return wg9_T<float>(a, s);
         case 1: return wg9_T<half_t>(a, s);
@@ -583,7 +583,9 @@ namespace y2 {
 // per-tap kernel on the large feature maps and for 1x1 filters
 #ifdef Y2_DEV
 // development variants (f16): explicit block shapes
-hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a, hipStream_t s) {
+hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a0, hipStream_t s) {
+    WgradArgs a = a0;
+    wgrad_split_args(1, a);
     switch (variant) {
         case 2: return wg9_launch<half_t, 2, 1>(a, s);
         case 3: return wg9_launch<half_t, 1, 2>(a, s);

@@ -123,7 +123,8 @@ class Network:
                                self.ws_bytes, int(training), _stream()))
         self.scale_owner = share_with.scale_owner if share_with is not None else self
         if grad_scale is None:
-            grad_scale = 1.0 if self.dtype != _lib.Y2_F16 else 1024.0
+            # f16 and the split-operand mode (f16 planes): gradients ride on a loss scale, dY's exponent range is f16's
+            grad_scale = 1024.0 if self.dtype in (_lib.Y2_F16, _lib.Y2_F16X2) else 1.0
         self.grad_scale = float(grad_scale)
         self._bessel = bool(bessel)
         check(self.lib.y2_set_options(h, self.grad_scale, int(bessel)))
@@ -337,7 +338,7 @@ class LossScaler:
         self._host = torch.zeros(8, dtype=torch.int32).pin_memory()
         self._event = None
         self.growth_interval, self.max_scale, self.min_scale = growth_interval, max_scale, min_scale
-        self.enabled = net.dtype == _lib.Y2_F16
+        self.enabled = net.dtype in (_lib.Y2_F16, _lib.Y2_F16X2)
         self._clean = 0
         self.overflows = 0
 
@@ -403,7 +404,7 @@ class AdamOptimizer:
         self.m = torch.zeros_like(net.params)
         self.v = torch.zeros_like(net.params)
         self.t = 0
-        self.guard = (net.dtype == _lib.Y2_F16) if guard is None else bool(guard)
+        self.guard = (net.dtype in (_lib.Y2_F16, _lib.Y2_F16X2)) if guard is None else bool(guard)
         self.scaler = LossScaler(net) if self.guard else None
 
     def step(self, grad_mult=1.0, full_check=False, joint=None):
@@ -477,7 +478,7 @@ class MomentumOptimizer:
         self.net, self.lr, self.mom = net, learning_rate, momentum
         self.fused_pack = bool(fused_pack)
         self.accum = torch.zeros_like(net.params)
-        self.guard = (net.dtype == _lib.Y2_F16) if guard is None else bool(guard)
+        self.guard = (net.dtype in (_lib.Y2_F16, _lib.Y2_F16X2)) if guard is None else bool(guard)
         self.scaler = LossScaler(net) if self.guard else None
 
     def step(self, grad_mult=1.0, full_check=False):

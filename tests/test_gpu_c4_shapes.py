@@ -69,7 +69,7 @@ def test_c4_first_layer_f16_vs_float64():
     check_first_layer(N, 416, backward=True, tag="C4")
 
 
-def _full_detector_step_f32_vs_torch_oracle(n):
+def _full_detector_step_f32_vs_torch_oracle(n, dtype="f32"):
     from oracle import torch_ref as T, loss_ref as L
     from tensorflow_yolo2_amd import engine as E, synthetic
     size, S = 416, 13
@@ -83,7 +83,7 @@ def _full_detector_step_f32_vs_torch_oracle(n):
     rloss, rious, rmask, _ = T.get_loss(rnet.reshape(n, S, S, 30), torch.tensor(labels), 20, n, size, S, 2,
                                         L.yolo_grid_offset(S, 2))
     rloss.backward()
-    net = E.Network(spec, n, size, size, dtype="f32", core_layers=18, training=True)
+    net = E.Network(spec, n, size, size, dtype=dtype, core_layers=18, training=True)
     net.load_params(params)
     grid = net.forward(torch.as_tensor(x).cuda(), True, True)
     e_grid = rel_to_max(grid.cpu().numpy(), rnet.detach().numpy().astype(np.float64))
@@ -99,13 +99,13 @@ def _full_detector_step_f32_vs_torch_oracle(n):
         a = g[l]["W"].ravel().astype(np.float64)
         b = tp[l]["W"].grad.numpy().ravel().astype(np.float64)
         cosines[l] = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
-    print("C4 f32 step bs%d: grid %.2e  loss %.2e  mask mismatches %d  last-layer grads %.2e  cos(dW) %s" %
-          (n, e_grid, e_loss, mism, e_last, cosines))
+    print("C4 %s step bs%d: grid %.2e  loss %.2e  mask mismatches %d  last-layer grads %.2e  cos(dW) %s" %
+          (dtype, n, e_grid, e_loss, mism, e_last, cosines))
     import _obs
-    _obs.gate("c4_f32_step_bs%d grid" % n, e_grid, TOL)
-    _obs.gate("c4_f32_step_bs%d loss" % n, e_loss, TOL)
-    _obs.gate("c4_f32_step_bs%d last-layer grads" % n, e_last, TOL)
-    _obs.gate("c4_f32_step_bs%d 1-min cos(dW)" % n, 1.0 - min(cosines.values()), 1e-3)
+    _obs.gate("c4_%s_step_bs%d grid" % (dtype, n), e_grid, TOL)
+    _obs.gate("c4_%s_step_bs%d loss" % (dtype, n), e_loss, TOL)
+    _obs.gate("c4_%s_step_bs%d last-layer grads" % (dtype, n), e_last, TOL)
+    _obs.gate("c4_%s_step_bs%d 1-min cos(dW)" % (dtype, n), 1.0 - min(cosines.values()), 1e-3)
     # object_mask is index work: it may only differ where two IoUs tie to within fp32 round-off of the two sides
     assert mism == 0 or rel_to_max(ious.cpu().numpy(), rious.detach().numpy().astype(np.float64)) < 3e-3
     assert all(c > 0.999 for c in cosines.values()), cosines
