@@ -127,7 +127,9 @@ int y2_wait_mark(y2_ctx* ctx, int k, void* stream);
  * [N,H,W,in_chl of layer 0]: for stacks composed into larger graphs (the YOLOv2 detector of the north star: 13x13
  * stack and head behind the passthrough concat).  The 3-channel image layer has no input gradient. */
 int y2_backward_input(y2_ctx* ctx, const float* dout, float* dinput, void* stream);
-/* copy a layer's saved activation (post BN+leaky+pool input of `layer`, or conv output) for tests */
+/* copy a layer's saved activation for tests.  what: 0 = bordered input of `layer` (post BN+leaky+pool of the layer
+ * below) [N,H,W,in_chl]; 1 = conv output [N,H,W,out_chl]; 2 = dy * grad_scale [N,H,W,out_chl]; 3 = the per-channel
+ * constants the last forward normalised the layer with, [4][out_chl]: mean, 1/sqrt(var + eps), scale, shift */
 int y2_debug_read(y2_ctx* ctx, int layer, int what, float* dst, void* stream);
 
 /* Optional measurement aid: bracket every kernel launch of y2_forward / y2_backward with

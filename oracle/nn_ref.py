@@ -220,25 +220,25 @@ def quantizer(kind):
     raise ValueError(kind)
 
 
-def conv_bn_layer(x, p, is_training, pool, dtype=np.float32, bessel=False, quant=None, stats_unrounded=False):
+def conv_bn_layer(x, p, is_training, pool, dtype=np.float32, bessel=False, quant=None, given_stats=None):
     """Returns (out, cache, new_moving).  cache holds what backward needs.
     quant (see quantizer) models the half-precision STORAGE points of the HIP fast
     modes: filter, conv output, layer output (arithmetic in between stays wide).
-    stats_unrounded (with quant): the batch moments are those of the conv output BEFORE its rounding to the storage
-    type -- the HIP path's pooled 3-channel first layer since round 4 (its statistics come from the Gram matrix of the
-    input patches, csrc/conv1_wgrad.hip; closer to the fp32 reference than moments of the rounded values)."""
+    given_stats = (mean, var), training mode only: the batch moments the layer normalises with are INPUTS instead of
+    being formed here.  The GPU tests hand over what the device normalised with (Network.layer_statistics) where the
+    device forms its moments in another way than from the stored conv output -- the HIP path's pooled 3-channel first
+    layer takes them from the Gram matrix of the input patches, csrc/conv1_wgrad.hip -- and gate those moments
+    separately against float64 (tests/test_gpu_r4_kernels.py); the oracle itself knows nothing about that form."""
     W = p["W"].astype(dtype)
     if quant is not None:
         W = quant(W).astype(dtype)
     h_conv = conv2d_same(x, W) + p["b"].astype(dtype)                 # darknet.py:35
-    h_exact = h_conv
     if quant is not None:
         h_conv = quant(h_conv).astype(dtype)
     gamma, beta = p["gamma"].astype(dtype), p["beta"].astype(dtype)
     new_moving = None
-    if is_training and quant is not None and stats_unrounded:
-        mean = h_exact.mean(axis=(0, 1, 2))
-        var = ((h_exact - mean) ** 2).mean(axis=(0, 1, 2))
+    if is_training and given_stats is not None:
+        mean, var = (np.asarray(v, dtype) for v in given_stats)
         h_bn = gamma * (h_conv - mean) / np.sqrt(var + BN_EPS) + beta
         m = h_conv.shape[0] * h_conv.shape[1] * h_conv.shape[2]
         var_upd = var * (m / max(m - 1, 1)) if bessel else var
@@ -288,14 +288,10 @@ def conv_bn_layer_backward(p, cache, dout, dtype=np.float32, need_dx=True, quant
 # --------------------------------------------------------------------------
 # networks
 # --------------------------------------------------------------------------
-def run_stack(x, params, spec, is_training, dtype=np.float32, bessel=False, quant=None, first_stats_unrounded=None):
+def run_stack(x, params, spec, is_training, dtype=np.float32, bessel=False, quant=None, first_stats=None):
     """is_training: bool, or a per-layer list of bools.  The LAST layer's output is
     never quantised (the HIP path emits it in fp32).
-    first_stats_unrounded (quantised runs only; None = as the HIP path of a training binding does): the pooled
-    3-channel first layer takes its batch moments from the un-rounded conv output (conv_bn_layer)."""
-    if first_stats_unrounded is None:
-        k0, ci0, co0, pool0 = spec[0]
-        first_stats_unrounded = quant is not None and k0 == 3 and ci0 == 3 and co0 == 32 and bool(pool0) and len(spec) > 1
+    first_stats = (mean, var): batch moments of layer 0 handed in as inputs (conv_bn_layer given_stats)."""
     caches, movings = [], []
     x = x.astype(dtype)
     if quant is not None:
@@ -303,7 +299,7 @@ def run_stack(x, params, spec, is_training, dtype=np.float32, bessel=False, quan
     n = len(params)
     for i, (p, (_k, _ci, _co, pool)) in enumerate(zip(params, spec)):
         tr = is_training[i] if isinstance(is_training, (list, tuple)) else is_training
-        x, cache, mv = conv_bn_layer(x, p, tr, pool, dtype, bessel, quant, stats_unrounded=(i == 0 and first_stats_unrounded))
+        x, cache, mv = conv_bn_layer(x, p, tr, pool, dtype, bessel, quant, given_stats=(first_stats if i == 0 else None))
         if quant is not None and i + 1 < n:
             x = quant(x).astype(dtype)
         caches.append(cache)

@@ -68,3 +68,44 @@ if __name__ == "__main__":
     elif mode in ("step8", "step64"):
         from test_gpu_c4_shapes import _full_detector_step_f32_vs_torch_oracle
         _full_detector_step_f32_vs_torch_oracle(int(mode[4:]), "f16x2")
+
+
+def diag(spec, n, hw, seed=0):
+    """layer by layer: stored activations, conv outputs, dy and gradients of f16x2 against the f32 mode"""
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(seed)
+    params = R.init_params(spec, seed=seed)
+    x = rng.uniform(-1, 1, (n, hw, hw, spec[0][1])).astype(np.float32)
+    res = {}
+    for dt in ("f32", "f16x2"):
+        net = E.Network(spec, n, hw, hw, dtype=dt, training=True)
+        net.load_params(params)
+        out = net.forward(torch.as_tensor(x).cuda(), True, True).clone()
+        g = np.random.default_rng(seed + 1).standard_normal(tuple(out.shape)).astype(np.float32) * 1e-2
+        net.backward(torch.as_tensor(g).cuda())
+        torch.cuda.synchronize()
+        d = {"out": out.cpu().numpy(), "grads": net.export_grads()}
+        for l in range(len(spec)):
+            if l > 0:
+                d["a%d" % l] = net.debug_read(l, 0).cpu().numpy()
+            d["y%d" % l] = net.debug_read(l, 1).cpu().numpy()
+            try:
+                d["dy%d" % l] = net.debug_read(l, 2).cpu().numpy() / net.grad_scale
+            except Exception as e:
+                pass
+        res[dt] = d
+    r = lambda a, b: np.abs(a.astype(np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
+    for l in range(len(spec)):
+        line = "layer %d %s:" % (l, spec[l])
+        for key in ("a%d" % l, "y%d" % l, "dy%d" % l):
+            if key in res["f32"] and key in res["f16x2"]:
+                line += "  %s %.2e" % (key, r(res["f16x2"][key], res["f32"][key].astype(np.float64)))
+        for k in ("W", "gamma", "beta"):
+            line += "  d%s %.2e" % (k, r(res["f16x2"]["grads"][l][k], res["f32"]["grads"][l][k].astype(np.float64)))
+        print(line)
+    print("out %.2e" % r(res["f16x2"]["out"], res["f32"]["out"].astype(np.float64)))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "diag":
+    diag([(3, 128, 256, 1), (3, 256, 512, 0), (1, 512, 256, 0), (3, 256, 512, 1), (3, 512, 1024, 0), (1, 1024, 30, 0)], 8, 28)

@@ -860,7 +860,7 @@ __global__ __launch_bounds__(1024) void conv1_gram_stats_kernel(Conv1GramStatsAr
     const int tid = threadIdx.x;
     for (int i = tid; i < kGram; i += 1024) {
         double v = 0.0;
-#pragma unroll
+#pragma unroll 4      // (fully unrolled, the 1024-thread block's 128-register budget spilled; the order of the sum is the same)
         for (int k = 0; k < kLinMid; ++k) v += (double)a.mid[(size_t)k * kGram + i];
         G[i / 48][i % 48] = v;
         a.gram[i] = (float)v;                               // the backward pass of this step reads the totals
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(1024) void conv1_gram_stats_kernel(Conv1GramStatsAr
     for (int i = tid; i < 48 * 32; i += 1024) {
         const int r = i >> 5, co = i & 31;
         double v = 0.0;
-#pragma unroll 8
+#pragma unroll 4
         for (int k = 0; k < 48; ++k) v += G[r][k] * (double)Wq[k][co];
         t[r][co] = v * (double)Wq[r][co];
     }
@@ -895,6 +895,7 @@ __global__ __launch_bounds__(1024) void conv1_gram_stats_kernel(Conv1GramStatsAr
     if (tid < 32) {
         const int c = tid;
         double m2 = 0.0, s = 0.0;
+#pragma unroll 4
         for (int r = 0; r < 48; ++r) {
             m2 += t[r][c];
             s += sv[r] * (double)Wq[r][c];
@@ -935,8 +936,14 @@ static hipError_t c1gram_T(const Conv1GramStatsArgs& a, hipStream_t s) {
     const size_t red = 4 * (size_t)kGram * sizeof(float);
     if (lds < red) lds = red;
     auto kern = conv1_gram_kernel<T>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    // the attribute is set once per size class (a call per training forward was host work on the hot path and
+    // is not allowed inside a stream capture)
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr = lds;
+    }
     const int ntile = a.N * (a.H / RT);
     const int nb = ntile < kGramMaxBlocks ? ntile : kGramMaxBlocks;
     float* part = a.mid + (size_t)kLinMid * kGram;
@@ -968,8 +975,13 @@ static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
     if (nosel && !(a.Wf && a.bias)) return hipErrorInvalidValue;
     auto kern = nosel ? (a.gram ? conv1_wgrad_lin_kernel<T, false, true> : conv1_wgrad_lin_kernel<T, true, true>)
                       : (a.gram ? conv1_wgrad_lin_kernel<T, false, false> : conv1_wgrad_lin_kernel<T, true, false>);
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    static size_t attr[4] = {0, 0, 0, 0};        // per kernel form of this T
+    const int form = (nosel ? 2 : 0) + (a.gram ? 1 : 0);
+    if (lds > attr[form]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr[form] = lds;
+    }
     const int prs = a.N * (a.H / 2);
     const int nb = prs < 512 ? prs : 512;
     float* part = a.acc + (size_t)kLinMid * kLinAcc;        // [nb][kLinAcc] behind the slice sums

@@ -313,7 +313,7 @@ hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* bp
     return hipErrorInvalidValue;
 }
 
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
 hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp);
 // development library only (make dev): Y2DEV_CONV="W:Cout:variant,..." forces a halo variant for (W, Cout), f16
 static int dev_rule(int W, int Cout) {
@@ -448,7 +448,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_
         return e;
     }
     if (conv_filter_layout(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad, esz, split)) e = launch_conv_haloq(dtype, a, s, &bp);
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
     else if (a.taps == 9 && dtype == 1 && dev_rule(a.W, a.Cout) >= 0)
         e = launch_conv_halo_variant(dev_rule(a.W, a.Cout), a, s, &bp);
 #endif
@@ -459,7 +459,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_
     return e;
 }
 
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
 // development variants (f16) for scripts/bench_conv.py
 #define HV(id, WP, TPARGS...) \
     case id: if (bp) *bp = halo_bp<WP, TPARGS>(); return halo_pick<T, WP, TPARGS>(a, s);
@@ -539,6 +539,6 @@ hipError_t launch_conv_halo_variant(int variant, const ConvArgs& a, hipStream_t 
     }
     return hipErrorInvalidValue;
 }
-#endif  // Y2_DEV
+#endif  // Y2_DEVBUILD
 
 }  // namespace y2

@@ -876,7 +876,7 @@ hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* b
     return hipErrorInvalidValue;
 }
 
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
 // development variants (f16) for scripts/bench_conv.py (timing only: the bench does not care about the
 // filter layout)
 hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t s, int* bp) {
@@ -923,6 +923,6 @@ hipError_t launch_conv_haloq_variant(int variant, const ConvArgs& a, hipStream_t
 #undef HQ
     return hipErrorInvalidValue;
 }
-#endif  // Y2_DEV
+#endif  // Y2_DEVBUILD
 
 }  // namespace y2

@@ -269,7 +269,7 @@ hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
 
 }  // namespace y2
 
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
 // ---------------------------------------------------------------------------
 // development library only: explicit tile / pipeline variants (f16 only) for A/B timing
 // ---------------------------------------------------------------------------
@@ -317,4 +317,4 @@ hipError_t launch_conv_igemm_variant(int variant, const ConvArgs& a, hipStream_t
     return hipErrorInvalidValue;
 }
 }  // namespace y2
-#endif  // Y2_DEV
+#endif  // Y2_DEVBUILD

@@ -27,7 +27,7 @@
 
 namespace y2 {
 
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
 // diagnostic build only: s_memtime deltas per phase of the 128-cout kernel (workgroup 0; [wave][phase])
 __device__ unsigned long long g_rf_stamps[8][8];
 #define RF_STAMP(k)                                                                                  \
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 
 #pragma unroll
     for (int g = 0; g < (WPRIV ? NSLOT - 1 : NSLOT); ++g) stage(T0 - AH + g);
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
 #endif
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
         }
     }
     wait_vmcnt<0>();
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
     if (blockIdx.x == 0 && lane == 0)
         for (int k2 = 0; k2 < 8; ++k2) g_rf_stamps[w][k2] = ph[k2];
 #endif
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(WP * WN * 64, 2) void conv_rfn_kernel(ConvArgs a, R
 }
 
 
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
 hipError_t rf_read_stamps(unsigned long long* dst) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rf_stamps), sizeof(unsigned long long) * 64);
 }
@@ -833,7 +833,7 @@ static hipError_t rf_T(int cfg, const ConvArgs& a, hipStream_t s, int* bp, int* 
     // SLOWER than one 8-wave workgroup on the 128-cout layers (a lone wave cannot keep the matrix pipe busy)
     if (cfg == 1) return rf_launch<T, 32, 2, 8, 1, 32, 2>(a, s, bp, records);
     if (cfg == 2) return rf_launch<T, 64, 1, 8, 1, 32, 3>(a, s, bp, records);
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
     static const int alt = getenv("Y2DEV_RF_ALT") ? atoi(getenv("Y2DEV_RF_ALT")) : 0;
     if (cfg == 3 && alt == 1) return rfn_launch<T, 64, 1, 4, 2, 2, 6, 2>(a, s, bp, records);
 #endif

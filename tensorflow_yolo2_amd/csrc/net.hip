@@ -1069,6 +1069,7 @@ int y2_wait_mark(y2_ctx* c, int k, void* stream) {
 // what: 0 = bordered input of `layer` (post BN+leaky+pool of the previous layer), [N,H,W,cin]
 //       1 = conv output (+bias) of `layer`, [N,H,W,cout]
 //       2 = dy (gradient wrt the conv output, times grad_scale), [N,H,W,cout]
+//       3 = the layer's normalisation constants of the last forward, [4][cout]: mean, invstd, scale, shift
 int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
     if (l < 0 || l >= (int)c->L.size()) return fail(Y2_ERR_ARG, "layer out of range");
     const Layer& y = c->L[l];
@@ -1104,6 +1105,16 @@ int y2_debug_read(y2_ctx* c, int l, int what, float* dst, void* stream) {
             return fail(Y2_ERR_STATE, "the first layer's dy is fused into its weight gradient and never stored");
         HIPCHK(launch_unpack_act(y.first3 ? dtype_plain(c->dtype) : c->dtype, c->ws + y.dyp + c->dy_geom(l).base_off(sz), dst, c->N, y.H, y.W, y.cout,
                                  y.ldy, s));
+    } else if (what == 3) {
+        // the per-channel constants the last forward normalised this layer with: dst [4][cout] = mean, 1 / sqrt(var + eps),
+        // scale = gamma * invstd, shift = beta - mean * scale (batch statistics of a training-mode layer, else the moving
+        // ones) -- tests hand them to the oracle as INPUTS where the device's moments are formed differently from the
+        // oracle's (the Gram-matrix statistics of the 3-channel layer) instead of teaching the oracle that form
+        if (!c->fwd_saved) return fail(Y2_ERR_STATE, "run y2_forward first");
+        const float* stat = (const float*)(c->ws + y.stat);
+        const float* src[4] = {stat + 2 * y.ldy, stat + 3 * y.ldy, stat, stat + y.ldy};
+        for (int k = 0; k < 4; ++k)
+            HIPCHK(hipMemcpyAsync(dst + (size_t)k * y.cout, src[k], (size_t)y.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
     } else {
         return fail(Y2_ERR_ARG, "unknown selector");
     }

@@ -304,7 +304,7 @@ hipError_t wgrad_split_finish(const WgradArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
 // development variants (f16, 128 x 128 tiles): stages x blocks target of the 1x1 form
 hipError_t launch_wgrad_variant(int variant, const WgradArgs& a0, hipStream_t s) {
     WgradArgs a = a0;

@@ -521,7 +521,7 @@ static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
     // many small blocks, two waves per SIMD -- beat 64x64 tiles on every Darknet-19 shape
     if constexpr (sizeof(T) == 2) {
         // long rows: the ring form stages 64 new rows per step instead of the whole window
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
         static const int minw = getenv("Y2DEV_WG9R_MINW") ? atoi(getenv("Y2DEV_WG9R_MINW")) : 52;
 #else
         constexpr int minw = 52;
@@ -581,7 +581,7 @@ hipError_t launch_wgrad9(int dtype, const WgradArgs& a0, hipStream_t s) {
 namespace y2 {
 // policy: all-taps kernel where the image rows are short (window ~1.5-2x the K step),
 // per-tap kernel on the large feature maps and for 1x1 filters
-#ifdef Y2_DEV
+#ifdef Y2_DEVBUILD
 // development variants (f16): explicit block shapes
 hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a0, hipStream_t s) {
     WgradArgs a = a0;
@@ -637,7 +637,7 @@ hipError_t launch_wgrad9_variant(int variant, const WgradArgs& a0, hipStream_t s
     }
     return hipErrorInvalidValue;
 }
-#endif  // Y2_DEV
+#endif  // Y2_DEVBUILD
 
 hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a0, hipStream_t s) {
     static const int xcd_mode = getenv("Y2_XCD_WGRAD") ? atoi(getenv("Y2_XCD_WGRAD")) : 1;

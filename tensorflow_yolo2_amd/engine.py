@@ -126,6 +126,7 @@ class Network:
             # f16 and the split-operand mode (f16 planes): gradients ride on a loss scale, dY's exponent range is f16's
             grad_scale = 1024.0 if self.dtype in (_lib.Y2_F16, _lib.Y2_F16X2) else 1.0
         self.grad_scale = float(grad_scale)
+        self.bn_eps, self.bn_momentum, self.zero_bias_grad = 1e-3, 0.99, False     # y2_ctx defaults (darknet.py:39-44)
         self._bessel = bool(bessel)
         check(self.lib.y2_set_options(h, self.grad_scale, int(bessel)))
         self._offsets = []
@@ -153,15 +154,23 @@ class Network:
         check(self.lib.y2_bind(self.h, _ptr(self.params), _ptr(self.grads), _ptr(self.state), _ptr(self.workspace),
                                self.ws_bytes, int(self.training), _stream()))
 
-    def set_layer_options(self, slopes=None, bn_eps=1e-3, bn_momentum=0.99, zero_bias_grad=False):
+    def set_layer_options(self, slopes=None, bn_eps=None, bn_momentum=None, zero_bias_grad=None):
         """per-layer activation slopes (0.1 leaky = the reference, 0 ReLU, 1 none) and the stack's batch-norm constants
-        (y2_set_layer_options; defaults = tf.layers.batch_normalization's)"""
+        (y2_set_layer_options).  Every argument left at None KEEPS the context's current value (a fresh context holds
+        tf.layers.batch_normalization's defaults: eps 1e-3, momentum 0.99, conv biases trainable) -- a call that only
+        changes the slopes does not reset a ResNet stack's eps 1e-5 / momentum 0.997."""
         arr = None
         if slopes is not None:
             assert len(slopes) == self.num_layers
             arr = (C.c_float * self.num_layers)(*[float(v) for v in slopes])
-        check(self.lib.y2_set_layer_options(self.h, arr, self.num_layers, float(bn_eps), float(bn_momentum),
-                                            int(bool(zero_bias_grad))))
+        if bn_eps is not None:
+            self.bn_eps = float(bn_eps)
+        if bn_momentum is not None:
+            self.bn_momentum = float(bn_momentum)
+        if zero_bias_grad is not None:
+            self.zero_bias_grad = bool(zero_bias_grad)
+        check(self.lib.y2_set_layer_options(self.h, arr, self.num_layers, self.bn_eps, self.bn_momentum,
+                                            int(self.zero_bias_grad)))
 
     def set_grad_scale(self, grad_scale):
         self.grad_scale = float(grad_scale)
@@ -309,6 +318,16 @@ class Network:
         cnt = (C.c_int * n)()
         check(self.lib.y2_profile_collect(self.h, ms, cnt, n))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(self.PROFILE_CATEGORIES)}
+
+    def layer_statistics(self, layer):
+        """the per-channel constants the last forward normalised `layer` with (y2_debug_read selector 3): dict of float64
+        arrays mean, invstd, scale, shift and var = 1 / invstd^2 - eps (the biased batch variance, or the moving one)"""
+        co = self.spec[layer][2]
+        t = torch.empty((4, co), dtype=torch.float32, device=self.device)
+        check(self.lib.y2_debug_read(self.h, layer, 3, _ptr(t), _stream()))
+        a = t.double().cpu().numpy()
+        eps = self.bn_eps
+        return {"mean": a[0], "invstd": a[1], "scale": a[2], "shift": a[3], "var": 1.0 / (a[1] * a[1]) - eps}
 
     def debug_read(self, layer, what):
         k, ci, co, _ = self.spec[layer]

@@ -106,8 +106,14 @@ def _full_detector_step_f32_vs_torch_oracle(n, dtype="f32"):
     _obs.gate("c4_%s_step_bs%d loss" % (dtype, n), e_loss, TOL)
     _obs.gate("c4_%s_step_bs%d last-layer grads" % (dtype, n), e_last, TOL)
     _obs.gate("c4_%s_step_bs%d 1-min cos(dW)" % (dtype, n), 1.0 - min(cosines.values()), 1e-3)
-    # object_mask is index work: it may only differ where two IoUs tie to within fp32 round-off of the two sides
-    assert mism == 0 or rel_to_max(ious.cpu().numpy(), rious.detach().numpy().astype(np.float64)) < 3e-3
+    # object_mask is index work: a cell's responsible box may only differ where ITS two IoUs tie to 1e-6 (fp32 round-off
+    # of the two sides) -- checked cell by cell (the whole-tensor bound would have passed a flipped box)
+    if mism:
+        dm, rm = mask.cpu().numpy(), rmask.numpy()
+        cells = np.argwhere((dm != rm).any(-1))
+        ri = rious.detach().numpy().astype(np.float64)
+        for c in cells:
+            assert abs(ri[tuple(c)][0] - ri[tuple(c)][1]) < 1e-6, ("responsible box differs away from an IoU tie", tuple(c), ri[tuple(c)])
     assert all(c > 0.999 for c in cosines.values()), cosines
 
 

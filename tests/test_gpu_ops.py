@@ -162,24 +162,34 @@ def test_stack_backward(first3, dtype):
     # leaky decisions (activations are STORED in half precision), so they are checked
     # against the oracle with the same storage points quantised (oracle quantizer()).
     q = R.quantizer(dtype)
-    ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q)
-    # Without the 3-channel layer the device and the oracle take their batch moments from the SAME rounded values: the
-    # half modes then agree to fp32 round-off (bf16 2.8e-7).  The pooled 3-channel first layer takes its moments from
-    # the Gram matrix of the input patches since round 4 (fp32 MFMA sums, ~1e-6 relative): scale / shift differ from the
-    # float64 ones in the 6th digit, which moves a fraction of the STORED half-precision activations by one ulp
-    # (2^-8 in bf16) -- amplified by the three batch-normed toy layers behind it (8 pixels per channel at the end).
-    tol_q = {"f32": 4e-6, "f16": 1e-3, "bf16": 1e-6}[dtype]      # observed 1.5e-6 / 7.3e-4 / 2.8e-7
-    if first3 and dtype != "f32":
-        tol_q = {"f16": 2e-3, "bf16": 8e-3}[dtype]                # observed 2.2e-3 in bf16 (one-ulp flips)
-    gate("stack forward vs quantised oracle %s first3=%d" % (dtype, first3), l2err(out.cpu().numpy(), ref), tol_q)
+    # The pooled 3-channel first layer of the half modes takes its batch moments from the Gram matrix of the input
+    # patches (moments of the UN-rounded conv output, fp32 MFMA sums).  The oracle is not taught that form: it is handed
+    # the moments the device normalised with as INPUTS of layer 0 (y2_debug_read selector 3), and those moments are
+    # gated on their own against float64 in test_first_layer_statistics_from_the_gram_matrix (1e-4).  With the same
+    # moments on both sides the stored half-precision activations agree again to the rounding of the arithmetic between
+    # the storage points (the round-4 gates bf16 8e-3 / f16 2e-3 are back at 1e-6 / 1e-3).
+    if q is None:
+        ref, caches, _ = R.run_stack(x, params, spec, True, np.float64)
+        gate("stack forward vs oracle f32 first3=%d" % first3, l2err(out.cpu().numpy(), ref), 4e-6)   # observed 1.5e-6
+    else:
+        # The oracle runs layer by layer on the device's stored inputs and the storage-rounding flips are gated as flips
+        # (few, a few ulps: tests/_shapes.py teacher_forced_stack); the fp32 network output, given the device's input of
+        # the last layer, is then held to fp32 round-off in BOTH half types (round 3's gates were 1e-3 / 1e-6 on the
+        # free-running stack, round 4's 2e-3 / 8e-3)
+        from _shapes import teacher_forced_stack
+        first_stats = None
+        if first3:
+            st = net.layer_statistics(0)
+            first_stats = (st["mean"], st["var"])
+        ref, caches, report = teacher_forced_stack(net, x, params, spec, dtype, first_stats)
+        print("stored activations that differ from the quantised oracle (layer, count, of, worst ulps):", report)
+        gate("stack forward vs quantised oracle %s first3=%d" % (dtype, first3), l2err(out.cpu().numpy(), ref), 5e-5)
     dout = rng.standard_normal(ref.shape).astype(np.float32)
     net.backward(dev(dout))
     _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,
                                      grad_scale=net.grad_scale)
     grads = net.export_grads()
     tol = {"f32": 5e-6, "f16": 4e-3, "bf16": 1e-2}[dtype]    # observed 1.7e-6 / 1.9e-3 / 4.3e-3
-    if first3 and dtype == "bf16":
-        tol = 3e-2                                            # the one-ulp flips above, through the backward pass
     for l in range(len(spec)):
         for k in ("W", "gamma", "beta"):
             gate("stack backward %s first3=%d" % (dtype, first3), l2err(grads[l][k], rgrads[l][k]), tol)
@@ -325,12 +335,22 @@ def test_first_layer_paths_odd_and_wide(shape, dtype):
     out = net.forward(dev(x), True, True)
     q = R.quantizer(dtype)
     # even sizes: the linear-form path, whose batch moments come from the Gram matrix (un-rounded conv output); odd sizes:
-    # conv1 + bn_act with the moments of the stored values -- the oracle is told which
+    # conv1 + bn_act with the moments of the stored values.  Either way the oracle gets the moments the device normalised
+    # layer 0 with as inputs (test_stack_backward above; the moments themselves are gated in test_gpu_r4_kernels.py)
     gram = shape[1] % 2 == 0 and shape[2] % 2 == 0
-    ref, caches, _ = R.run_stack(x, params, spec, True, np.float64, quant=q, first_stats_unrounded=gram and q is not None)
-    assert out.shape == ref.shape
-    gate("first layer forward %s gram=%d" % (dtype, gram), l2err(out.cpu().numpy(), ref),
-         {"f32": 3e-6, "f16": 1.5e-3 if gram else 4e-4}[dtype])   # 9.5e-7 / 1.6e-4 (one-ulp flips of stored f16 values with the Gram moments)
+    if q is None:
+        ref, caches, _ = R.run_stack(x, params, spec, True, np.float64)
+        assert out.shape == ref.shape
+        gate("first layer forward f32 gram=%d" % gram, l2err(out.cpu().numpy(), ref), 3e-6)      # 9.5e-7
+    else:
+        from _shapes import teacher_forced_stack
+        st = net.layer_statistics(0)
+        ref, caches, report = teacher_forced_stack(net, x, params, spec, dtype, (st["mean"], st["var"]))
+        assert out.shape == ref.shape
+        print("stored activations that differ from the quantised oracle (layer, count, of, worst ulps):", report)
+        # (the last layer's conv output is stored in the half type too: each of ITS rounding flips is one ulp over
+        #  sqrt(size) in l2 -- observed 1.3e-5 at 64 x 96)
+        gate("first layer forward %s gram=%d" % (dtype, gram), l2err(out.cpu().numpy(), ref), 5e-5)
     dout = rng.standard_normal(ref.shape).astype(np.float32)
     net.backward(dev(dout))
     _, rgrads = R.run_stack_backward(params, caches, dout.astype(np.float64), np.float64, quant=q,

@@ -369,14 +369,35 @@ def test_ab_switches_select_equivalent_paths(tmp_path):
     import subprocess, sys
     worker = os.path.join(ROOT, "tests", "switch_worker.py")
 
-    def run(env_extra, tag):
+    def run(env_extra, tag, labels=None):
         env = dict(os.environ)
         env.update(env_extra)
         out = str(tmp_path / (tag + ".npz"))
-        subprocess.run([sys.executable, worker, out], check=True, env=env, timeout=600)
+        subprocess.run([sys.executable, worker, out] + ([labels] if labels else []), check=True, env=env, timeout=600)
         return np.load(out)
 
-    base = run({}, "base")
+    # The loss jumps by O(1 / batch) where a perturbation of the output moves a cell's responsible-box choice (the
+    # arg-max of two IoUs, net_utils.py:300-305).  Round 4 widened the loss bound to 3e-2 to live with that; instead the
+    # object cells whose two IoUs lie within 20 % of each other in the default run are now DROPPED from the labels (a
+    # cell's IoUs depend on its own label only, and the forward pass on none): a switch then cannot flip a responsible box
+    # (the 1e-2 output perturbation moves an IoU by about as much), object_mask must come out IDENTICAL and the loss is
+    # held to 1e-3 again.
+    from tensorflow_yolo2_amd import synthetic
+    probe = run({}, "probe")
+    labels = synthetic.det_labels(16, 416, 13, 8)
+    obj = probe["response"] > 0
+    margin = np.abs(probe["ious"][..., 0] - probe["ious"][..., 1])
+    big = np.maximum(probe["ious"][..., 0], probe["ious"][..., 1])
+    # (a randomly initialised head predicts boxes that barely overlap their ground truth: the IoUs are a few percent, so the
+    #  margin is taken relative to the larger one -- the perturbation is relative too)
+    # ... and absolute as well: a box that barely touches its ground truth (IoU 0.005) loses the overlap altogether
+    tied = obj & ((margin < 0.2 * big) | (margin < 0.02))
+    labels[tied] = 0.0
+    print("object cells %d, dropped as near-tied %d" % (int(obj.sum()), int(tied.sum())))
+    assert int((labels[..., 0] > 0).sum()) >= 4
+    run_seed = str(tmp_path / "labels.npy")
+    np.save(run_seed, labels)
+    base = run({}, "base", run_seed)
     assert tuple(base["ctrl"]) == (0, 1, 0)
     switches = [{"Y2_NO_CONV_RF": "1"}, {"Y2_NO_WGRAD_SLAB": "1"}, {"Y2_XCD_CONV": "0", "Y2_XCD_WGRAD": "0"},
                 {"Y2_NO_BN_FIN_FUSE": "1"}, {"Y2_NO_FUSED_TRAIN_OP": "1"}, {"Y2_NO_BNBWD_FUSE": "1"},
@@ -384,19 +405,22 @@ def test_ab_switches_select_equivalent_paths(tmp_path):
                 {"Y2_NO_CONV1_GRAM": "1"}, {"Y2_LEGACY_TILES": "1"}, {"Y2_NO_KSPLIT": "1"},   # round 4: Gram-matrix statistics, tile cost model, K split of small launches
                 {"Y2_CONV1_YSEL": "1"}]     # first layer: arg-max conv outputs kept (ysel) instead of 3 index bits + the linear S2
     for sw in switches:
-        r = run(sw, "_".join(sw))
+        r = run(sw, "_".join(sw), run_seed)
         assert tuple(r["ctrl"]) == (0, 1, 0), sw
+        if not np.array_equal(r["mask"], base["mask"]):
+            for c in np.argwhere((r["mask"] != base["mask"]).any(-1)):
+                print("mask differs at", tuple(c), "ious base", base["ious"][tuple(c)], "switch", r["ious"][tuple(c)],
+                      "response", base["response"][tuple(c)])
+        assert np.array_equal(r["mask"], base["mask"]), sw        # index work: the same responsible boxes
         el = abs(float(r["loss"][4]) - float(base["loss"][4])) / abs(float(base["loss"][4]))
         eg, ep = l2err(r["grads"], base["grads"]), l2err(r["params"], base["params"])
         print("switch", sw, "loss %.2e grads %.2e params %.2e" % (el, eg, ep))
         # a different summation order moves f16 outputs by one ulp at layer 2; the randomly initialised 22-layer
         # network amplifies that ~1.4x per layer (scripts/diag_switch_forward.py: 5e-6 -> 1.3e-2 at the output), so
-        # the implementation switches are only held to the loss and to a loose gradient bound here -- their kernels are
-        # checked against the oracle one by one elsewhere; the scheduling switches below must give the same bits
-        # (the loss itself jumps by O(1 / batch) where the 1e-2 output perturbation moves a near-tied responsible-box
-        #  choice: observed 2.4e-4 ... 1.1e-2 over the rounds for the SAME switch, depending on what else changed the
-        #  last bits of the base run -- so the loss bound is loose too)
-        assert el < 3e-2 and eg < 0.5 and ep < 2e-2, (sw, el, eg, ep)
+        # the implementation switches are held to the loss (1e-3: the responsible boxes are fixed, above) and to a loose
+        # gradient bound here -- their kernels are checked against the oracle one by one elsewhere; the scheduling
+        # switches below must give the same bits
+        assert el < 1e-3 and eg < 0.5 and ep < 2e-2, (sw, el, eg, ep)
         # (Y2_HALO_COMPACT: the conflict-free LDS image of conv_haloq -- other addresses, the same products in the
         #  same order)
         if any(k in sw for k in ("Y2_NO_FUSED_TRAIN_OP", "Y2_XCD_CONV", "Y2_NO_WGRAD_OVERLAP", "Y2_NO_BN_FIN_FUSE")):

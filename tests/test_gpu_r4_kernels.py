@@ -167,32 +167,48 @@ def test_layer_options_relu_and_linear_stack_vs_torch(dtype, tol):
     dout = rng.standard_normal(tuple(out.shape)).astype(np.float32)
     dx = net.backward_input(torch.as_tensor(dout).cuda())
     g = net.export_grads()
-    # float64 reference
+    # float64 reference.  f16: the activations' DECISIONS are inputs of the reference -- the device's own ReLU masks, read
+    # from what it stored (the consumer's input is > 0 exactly where the ReLU passed) -- because the f16 run is the exact
+    # gradient of a function that differs from the float64 one where a y, STORED in half precision, sits within its
+    # rounding of the ReLU boundary and falls the other way.  Those decisions are counted and must (a) be few and (b) all
+    # sit at a near-zero z of the reference; with the same decisions on both sides every gradient is a smooth function of
+    # the stored values and is gated element-wise (this replaces the 0.15 l2 gate).
+    masks = None
+    if dtype != "f32":
+        masks = [net.debug_read(l + 1, 0).cpu().numpy() > 0 for l in range(2)]
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     tp = [{k: torch.tensor(p[k], dtype=torch.float64, requires_grad=True) for k in ("W", "gamma", "beta")} for p in params]
     h = xt.permute(0, 3, 1, 2)
     mv = []
-    for (k, _ci, _co, _p), p, s in zip(spec, tp, slopes):
+    flips = 0
+    for l, ((k, _ci, _co, _p), p, s) in enumerate(zip(spec, tp, slopes)):
         h = F.conv2d(h, p["W"].permute(3, 2, 0, 1), padding=k // 2)
         mean, var = h.mean((0, 2, 3)), h.var((0, 2, 3), unbiased=False)
         mv.append((0.003 * mean.detach().numpy(), 0.997 + 0.003 * var.detach().numpy()))
         z = (h - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5) * p["gamma"][None, :, None, None] \
             + p["beta"][None, :, None, None]
-        h = torch.maximum(s * z, z)
+        if masks is not None and l < 2:
+            m = torch.tensor(masks[l]).permute(0, 3, 1, 2)
+            other = m != (z.detach() > 0)
+            flips += int(other.sum())
+            # a decision may only differ where the reference's z is within the f16 rounding of the stored conv output
+            # (2^-11 of |y| times the scale: z is O(1), a few 1e-3 at most)
+            assert float(z.detach().abs()[other].max()) < 5e-3 if other.any() else True, "a ReLU decision differs away from z = 0"
+            h = torch.where(m, z, s * z)
+        else:
+            h = torch.maximum(s * z, z)
     ref = h.permute(0, 2, 3, 1)
     ref.backward(torch.tensor(dout, dtype=torch.float64))
-    # f32: element-wise gates.  f16: the forward pass is gated; its gradients are the exact gradients of a function that
-    # differs from the float64 one at ReLU decisions (y is STORED in half precision: a few of the 18,432 activations sit
-    # within its rounding of zero and fall the other way, each moving single gradient entries by O(1) -- the same stack
-    # with slopes 1, 1, 1 has no decisions and matches to 7e-4, scripts/diag_layer_options.py), so they are held in l2
-    l2 = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))
-    err = rel_to_max if dtype == "f32" else l2
-    gtol = tol if dtype == "f32" else 0.15
+    if masks is not None:
+        n_dec = sum(int(np.prod(mk.shape)) for mk in masks)
+        print("layer-options stack %s: %d of %d ReLU decisions differ from float64 (all at |z| < 5e-3)" % (dtype, flips, n_dec))
+        assert flips <= 0.01 * n_dec, (flips, n_dec)
+    gtol = tol if dtype == "f32" else 5e-3       # f16: dy, dA and the conv outputs are stored in half precision
     _obs.gate("layer-options stack forward %s" % dtype, rel_to_max(out.cpu().numpy(), ref.detach().numpy()), tol)
-    _obs.gate("layer-options stack input gradient %s" % dtype, err(dx.cpu().numpy(), xt.grad.numpy()), gtol)
+    _obs.gate("layer-options stack input gradient %s" % dtype, rel_to_max(dx.cpu().numpy(), xt.grad.numpy()), gtol)
     for l in range(3):
         for k in ("W", "gamma", "beta"):
-            _obs.gate("layer-options stack d%s %s" % (k, dtype), err(g[l][k], tp[l][k].grad.numpy()), gtol)
+            _obs.gate("layer-options stack d%s %s" % (k, dtype), rel_to_max(g[l][k], tp[l][k].grad.numpy()), gtol)
         assert float(np.abs(g[l]["b"]).max()) == 0.0                    # not a variable of this graph
     st = net.export_params()
     for l in range(3):
