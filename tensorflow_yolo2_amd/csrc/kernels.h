@@ -249,7 +249,27 @@ struct WgradArgs {
     // every launch's partial tiles in its own range of the slab; ONE fixed-order sum over quads * splitk partials
     int xpitch = 0, ypitch = 0;     // 0: Cin / Cdy
     int quads = 1;
+    // Round 5: the split-K sum INSIDE the weight-gradient kernel (wgrad_finish.h).  tile_cnt != null (>= cnt_ints zeroed
+    // ints, self-cleaning): every block adds 1 to its tile's counter after its partial tile is in the slab; the block
+    // that completes a group of <= 16 partials sums that group in index order (a fixed tree of groups: deterministic
+    // whoever arrives last, no spin-wait, so no co-residency requirement) and the one that completes the top group
+    // writes dW -- the separate wgrad_reduce launches (18 per detector step) disappear.
+    int* tile_cnt = nullptr;
+    size_t cnt_ints = 0;
+    int part0 = 0;          // slab slot of this launch's split 0 (quads: q * splitk); set by wgrad_launch_quads
+    int cnt_stride = 0;     // counters per tile (wgrad_cnt_per_tile); 0: the separate sum kernel runs after the launch
+    int fin_lds_off = 0;    // byte offset of the finish flag in the dynamic LDS (behind the staging buffers: the ring form
+                            // needs the buffers at an aligned LDS base, so no static __shared__ in these kernels)
 };
+constexpr int kWgFinG = 16;      // partials per group of the in-kernel sum
+// counters per tile for `parts` partials: one per group of every level of the tree
+inline int wgrad_cnt_per_tile(int parts) {
+    int c = 0;
+    for (int n = parts; ; n = (n + kWgFinG - 1) / kWgFinG) {
+        if (n <= kWgFinG) return c + 1;
+        c += (n + kWgFinG - 1) / kWgFinG;
+    }
+}
 // f16x2: the split form of a (x, dy) pair for the 16-bit kernels (dtype 3 -> 1)
 inline int wgrad_split_args(int dtype, WgradArgs& a) {
     if (!a.xpitch) a.xpitch = a.Cin;
@@ -261,12 +281,11 @@ inline int wgrad_split_args(int dtype, WgradArgs& a) {
 // one launch per operand-plane pair (WgradArgs::quads): hi hi, x lo, dy lo -- each with its own slab range
 template <typename K, typename... Extra>
 inline hipError_t wgrad_launch_quads(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t s, const WgradArgs& a, Extra... extra) {
-    const size_t n = (size_t)a.taps * a.Cin * a.Cout;
     for (int q = 0; q < a.quads; ++q) {
         WgradArgs b = a;
         if (q == 1) b.x = (const char*)a.x + (size_t)a.Cin * 2;
         if (q == 2) b.dy = (const char*)a.dy + (size_t)a.Cdy * 2;
-        if (b.slab) b.slab = a.slab + (size_t)q * a.splitk * n;
+        b.part0 = q * a.splitk;
         hipLaunchKernelGGL(kern, grid, block, lds, s, b, extra...);
     }
     return hipGetLastError();
@@ -451,5 +470,7 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 
 // per-(device, stream) scratch of the graph-level operators (split partial sums); grows on demand, never shrinks
 void* op_scratch(hipStream_t s, size_t bytes);
+int* op_counters(hipStream_t s, size_t ints);      // zeroed, self-cleaning tile counters (WgradArgs::tile_cnt)
+constexpr size_t kWgCntInts = 65536;
 
 }  // namespace y2

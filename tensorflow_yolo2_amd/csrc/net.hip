@@ -113,6 +113,7 @@ struct y2_ctx {
     bool nosel1() const { return lin1() && L[0].ysel == 0; }     // ... and not even the arg-max outputs (Conv1PoolArgs::idx3)
     size_t o_infertab = 0;      // BnInferLayer per layer (one prepare launch for all inference-mode layers)
     size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0, o_slab = 0;
+    size_t o_wgcnt = 0;         // tile counters of the in-kernel split-K sums (WgradArgs::tile_cnt; zero from y2_bind on)
     size_t o_ks = 0, ks_floats = 0;   // K-split partial tiles of small convolution launches (ConvArgs::ks_scratch)
     size_t o_gram = 0;          // first layer: Gram matrix of the input patches [48][48] + its slices / block partials
     bool gram_valid = false;    // the last forward computed it (training mode, pooled first layer): backward reuses it
@@ -263,6 +264,7 @@ static void plan(y2_ctx* c) {
     // (f16x2: three operand-plane pairs per launch, each with its own partial tiles)
     c->slab_floats = (size_t)1024 * 18432 * (dtype_split(c->dtype) ? 3 : 1);
     c->o_slab = take(c->slab_floats * sizeof(float));
+    c->o_wgcnt = take(kWgCntInts * sizeof(int));
     c->o_dA0 = take(max_dA * sz + 256);
     c->o_dA1 = take(max_dA * sz + 256);
     c->o_dh32 = take(c->tail == Y2_TAIL_AVGPOOL ? (size_t)c->L.back().M * c->L.back().cout * sizeof(float) : 0);
@@ -968,6 +970,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             g.N = c->N; g.H = y.H; g.W = y.W; g.M = y.M;
             g.Cin = y.cin_s; g.Cdy = y.ldy; g.Cout = y.cout; g.taps = y.k * y.k; g.splitk = 0; g.scale = inv_gs;
             g.slab = (float*)(c->ws + c->o_slab); g.slab_floats = c->slab_floats;
+            g.tile_cnt = (int*)(c->ws + c->o_wgcnt); g.cnt_ints = kWgCntInts;
             hipStream_t ws_ = s;
             if (c->overlap_wgrad && c->prof != 1) {
                 // fork: the filter gradient only reads x and dY; it fills the bubbles of the dgrad beside it.  The
@@ -1397,6 +1400,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
         g.N = N; g.H = H; g.W = W; g.M = N * H * W; g.Cin = p.Cin_p; g.Cdy = p.Cdy; g.Cout = Cout;
         g.taps = k * k; g.splitk = 0; g.scale = 1.f;
         g.slab = (float*)(ws + p.slab); g.slab_floats = op_slab_floats(dtype);
+        g.tile_cnt = op_counters(s, kWgCntInts); g.cnt_ints = g.tile_cnt ? kWgCntInts : 0;
         HIPCHK(launch_wgrad_auto(dtype, g, s));
         for (int t = 0; t < k * k && !direct; ++t)
             HIPCHK(hipMemcpyAsync(dw + (size_t)t * Cin * Cout, (float*)(ws + p.dw) + (size_t)t * p.Cin_p * Cout,

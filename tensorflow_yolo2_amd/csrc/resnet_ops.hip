@@ -81,6 +81,27 @@ void* op_scratch(hipStream_t s, size_t bytes) {
     }
     return e.first;
 }
+// per-(device, stream) counters of the in-kernel split-K sums of the op-level weight gradients (wgrad_finish.h): zeroed
+// once when they are allocated, self-cleaning afterwards (every launch leaves them at zero)
+int* op_counters(hipStream_t s, size_t ints) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<int*, size_t>> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = pool[std::make_pair(dev, s)];
+    if (e.second < ints) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+        if (cap != hipStreamCaptureStatusNone) return nullptr;      // the caller falls back to the separate sum kernel
+        int* p = nullptr;
+        if (hipMalloc((void**)&p, ints * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(p, 0, ints * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e.first = p;
+        e.second = ints;
+    }
+    return e.first;
+}
 }  // namespace y2
 
 // ---------------------------------------------------------------------------

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "conv_epilogue.h"
 #include "kernels.h"
+#include "wgrad_finish.h"
 
 namespace y2 {
 
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* const s_fin = (int*)(smem + Cfg::LDS);      // the finish flag sits behind the staging buffers (wgrad_finish.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = w / WO, wo = w % WO;
@@ -191,21 +193,43 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
                 if (ci < a.Cin && co < a.Cout) {
                     const size_t o = ((size_t)tap * a.Cin + ci) * a.Cout + co;
                     if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[i][j][q] * a.scale;
-                    else if (a.slab) a.slab[(size_t)split * a.taps * a.Cin * a.Cout + o] = acc[i][j][q];
+                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * a.taps * a.Cin * a.Cout + o; if (a.cnt_stride) slab_store(sp, acc[i][j][q]); else *sp = acc[i][j][q]; }
                     else atomicAdd(a.dW + o, acc[i][j][q] * a.scale);
                 }
             }
         }
+    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h)
+        const size_t nn = (size_t)a.taps * a.Cin * a.Cout;
+        splitk_finish(s_fin, a.tile_cnt + (size_t)((tap * nIT + it) * nOT + ot) * a.cnt_stride, a.part0 + split, a.splitk * a.quads,
+                      [&](int first, int stride, int count, bool final) __attribute__((always_inline)) {
+#pragma unroll 1
+            for (int i = 0; i < TI; ++i)
+#pragma unroll 1
+                for (int j = 0; j < TO; ++j) {
+                    const int co = co0 + (wo * TO + j) * 32 + r32;
+#pragma unroll 1
+                    for (int q = 0; q < 16; ++q) {
+                        const int ci = ci0 + (wi * TI + i) * 32 + acc_row(q, hh);
+                        if (ci < a.Cin && co < a.Cout) {
+                            const size_t o = ((size_t)tap * a.Cin + ci) * a.Cout + co;
+                            const float v = splitk_sum_slots(a.slab + (size_t)first * nn + o, (size_t)stride * nn, count);
+                            if (final) a.dW[o] = v * a.scale;
+                            else slab_store(a.slab + (size_t)first * nn + o, v);
+                        }
+                    }
+                }
+        });
+    }
 }
 
 template <typename T, int WI, int WO, int TI, int TO, int NS = 2>
 static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     typedef WgCfg<T, WI, WO, TI, TO, NS> Cfg;
-    static_assert(Cfg::LDS <= 160 * 1024, "LDS");
+    static_assert(Cfg::LDS + 16 <= 160 * 1024, "LDS");
     auto kern = wgrad_kernel<T, WI, WO, TI, TO, NS>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS + 16);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -226,7 +250,7 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     }
     hipError_t e = wgrad_split_prepare(a, s);
     if (e != hipSuccess) return e;
-    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS, s, a);
+    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS + 16, s, a);
     return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 
@@ -283,16 +307,32 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 hipError_t wgrad_split_prepare(WgradArgs& a, hipStream_t s) {
+    a.cnt_stride = 0;
     if (a.splitk * a.quads <= 1) return hipSuccess;
     const size_t n = (size_t)a.taps * a.Cin * a.Cout;
     static const bool no_slab = getenv("Y2_NO_WGRAD_SLAB") != nullptr;      // A/B switch: float atomics instead
-    if (!no_slab && a.slab && (n & 3) == 0 && (size_t)a.splitk * a.quads * n <= a.slab_floats) return hipSuccess;
+    // In-kernel sum (wgrad_finish.h): built and measured in round 5, NOT the default.  Y2_WGRAD_FINISH=<max parts> turns it on
+    // for launches of up to that many partials per tile.  Same box, configs[3] step: separate sum launches 8.78 ms; in-kernel
+    // with agent-scope fences 10.9 ms (every fence writes back / invalidates a whole L2 under the dgrad kernels); with
+    // sc1 atomics instead of fences 9.71 ms (the ONE block that completes a group of 16 partials of a 64-KB tile reads
+    // 1 MB through 4-byte sc1 loads, a few in flight per lane: a serial tail per tile where the separate kernel spreads
+    // the same reads over the whole chip in 6 us)
+    static const int finish_max = getenv("Y2_WGRAD_FINISH") ? atoi(getenv("Y2_WGRAD_FINISH")) : 0;
+    const bool sum_kernel = a.splitk * a.quads > finish_max;
+    if (!no_slab && a.slab && (n & 3) == 0 && (size_t)a.splitk * a.quads * n <= a.slab_floats) {
+        // in-kernel sum (wgrad_finish.h) where the caller lent counters: one set per dW tile.  The tile count is bounded by
+        // the smallest tiles any kernel form uses (32 x 32 per tap)
+        const int cps = wgrad_cnt_per_tile(a.splitk * a.quads);
+        const size_t tiles_max = (size_t)a.taps * ((a.Cin + 31) / 32) * ((a.Cout + 31) / 32);
+        if (a.tile_cnt && !sum_kernel && tiles_max * cps <= a.cnt_ints) a.cnt_stride = cps;
+        return hipSuccess;
+    }
     a.slab = nullptr;      // atomics into a zeroed dW
     return hipMemsetAsync(a.dW, 0, n * sizeof(float), s);
 }
 hipError_t wgrad_split_finish(const WgradArgs& a, hipStream_t s) {
     const int parts = a.splitk * a.quads;       // f16x2: the three operand-plane pairs are summed like splits
-    if (parts <= 1 || !a.slab) return hipSuccess;
+    if (parts <= 1 || !a.slab || a.cnt_stride) return hipSuccess;     // (cnt_stride: summed inside the launch)
     const size_t n4 = (size_t)a.taps * a.Cin * a.Cout / 4;
     if (parts <= 8) {
         hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.slab, a.dW, n4,

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "conv_epilogue.h"
 #include "kernels.h"
+#include "wgrad_finish.h"
 
 namespace y2 {
 
@@ -48,7 +49,7 @@ Y2_DEV int wg9_swz(int row) {
 // NS LDS stages; NS-1 K steps of LDS-DMA stay in flight across the raw barrier (counted vmcnt):
 // with one wave per SIMD (as many waves as the dW tiling yields) this is what hides HBM latency.
 template <typename T, int WI, int WO, int NS, int TG, int T0, int NTAP, int KS = 1, int CW = 1>
-Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
+Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
     typedef Wg9Cfg<T, WI, WO, TG, KS, CW> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
@@ -216,22 +217,46 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem) {
                 if (ci < a.Cin) {
                     const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
                     if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[t][j][q] * a.scale;
-                    else if (a.slab) a.slab[(size_t)split * 9 * a.Cin * a.Cout + o] = acc[t][j][q];
+                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * 9 * a.Cin * a.Cout + o; if (a.cnt_stride) slab_store(sp, acc[t][j][q]); else *sp = acc[t][j][q]; }
                     else atomicAdd(a.dW + o, acc[t][j][q] * a.scale);
                 }
             }
+    }
+    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h)
+        const size_t n9 = (size_t)9 * a.Cin * a.Cout;
+        splitk_finish(s_fin, a.tile_cnt + (size_t)(it * nOT + ot) * a.cnt_stride, a.part0 + split, a.splitk * a.quads,
+                      [&](int first, int stride, int count, bool final) __attribute__((always_inline)) {
+#pragma unroll 1
+            for (int j = 0; j < CW; ++j) {
+                const int co = co0 + (wo * CW + j) * 32 + r32;
+                if (co >= a.Cout) continue;
+#pragma unroll 1
+                for (int t = 0; t < NTAP; ++t)
+#pragma unroll 1
+                    for (int q = 0; q < 16; ++q) {
+                        const int ci = ci0 + wi * 32 + acc_row(q, hh);
+                        if (ci < a.Cin) {
+                            const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
+                            const float v = splitk_sum_slots(a.slab + (size_t)first * n9 + o, (size_t)stride * n9, count);
+                            if (final) a.dW[o] = v * a.scale;
+                            else slab_store(a.slab + (size_t)first * n9 + o, v);
+                        }
+                    }
+            }
+        });
     }
 }
 
 template <typename T, int WI, int WO, int NS, int TG, int KS = 1, int CW = 1>
 __global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9_kernel(WgradArgs a, int wrows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* const s_fin = (int*)(smem + a.fin_lds_off);
     if constexpr (TG == 1) {
-        wg9_body<T, WI, WO, NS, 1, 0, 9, KS, CW>(a, wrows, smem);
+        wg9_body<T, WI, WO, NS, 1, 0, 9, KS, CW>(a, wrows, smem, s_fin);
     } else {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (w < WI * WO) wg9_body<T, WI, WO, NS, 2, 0, 5, KS, CW>(a, wrows, smem);   // same barrier count in both arms
-        else wg9_body<T, WI, WO, NS, 2, 5, 4, KS, CW>(a, wrows, smem);
+        if (w < WI * WO) wg9_body<T, WI, WO, NS, 2, 0, 5, KS, CW>(a, wrows, smem, s_fin);   // same barrier count in both arms
+        else wg9_body<T, WI, WO, NS, 2, 5, 4, KS, CW>(a, wrows, smem, s_fin);
     }
 }
 
@@ -256,7 +281,7 @@ Y2_DEV typename Elem<T>::frag tr_frag_off(uint32_t o0, uint32_t o1) {
 }
 
 template <typename T, int WI, int WO, int TG, int T0, int NTAP, int KS = 1>
-Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
+Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin) {
     typedef Wg9Cfg<T, WI, WO, TG, KS> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
@@ -393,22 +418,42 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem) {
                 if (ci < a.Cin) {
                     const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
                     if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[t][q] * a.scale;
-                    else if (a.slab) a.slab[(size_t)split * 9 * a.Cin * a.Cout + o] = acc[t][q];
+                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * 9 * a.Cin * a.Cout + o; if (a.cnt_stride) slab_store(sp, acc[t][q]); else *sp = acc[t][q]; }
                     else atomicAdd(a.dW + o, acc[t][q] * a.scale);
                 }
             }
+    }
+    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h)
+        const size_t n9 = (size_t)9 * a.Cin * a.Cout;
+        splitk_finish(s_fin, a.tile_cnt + (size_t)(it * nOT + ot) * a.cnt_stride, a.part0 + split, a.splitk * a.quads,
+                      [&](int first, int stride, int count, bool final) __attribute__((always_inline)) {
+            if (co >= a.Cout) return;
+#pragma unroll 1
+            for (int t = 0; t < NTAP; ++t)
+#pragma unroll 1
+                for (int q = 0; q < 16; ++q) {
+                    const int ci = ci0 + wi * 32 + acc_row(q, hh);
+                    if (ci < a.Cin) {
+                        const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
+                        const float v = splitk_sum_slots(a.slab + (size_t)first * n9 + o, (size_t)stride * n9, count);
+                        if (final) a.dW[o] = v * a.scale;
+                        else slab_store(a.slab + (size_t)first * n9 + o, v);
+                    }
+                }
+        });
     }
 }
 
 template <typename T, int WI, int WO, int TG, int KS = 1>
 __global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9r_kernel(WgradArgs a, int lgR, int G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* const s_fin = (int*)(smem + a.fin_lds_off);
     if constexpr (TG == 1) {
-        wg9r_body<T, WI, WO, 1, 0, 9, KS>(a, lgR, G, smem);
+        wg9r_body<T, WI, WO, 1, 0, 9, KS>(a, lgR, G, smem, s_fin);
     } else {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (w < WI * WO) wg9r_body<T, WI, WO, 2, 0, 5, KS>(a, lgR, G, smem);
-        else wg9r_body<T, WI, WO, 2, 5, 4, KS>(a, lgR, G, smem);
+        if (w < WI * WO) wg9r_body<T, WI, WO, 2, 0, 5, KS>(a, lgR, G, smem, s_fin);
+        else wg9r_body<T, WI, WO, 2, 5, 4, KS>(a, lgR, G, smem, s_fin);
     }
 }
 
@@ -424,8 +469,9 @@ static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0)
     const int G = (wrows + Cfg::BKP - 1) / Cfg::BKP;
     int lgR = 7;
     while ((1 << lgR) < Cfg::BKP * (G + 1)) ++lgR;
-    const size_t lds = ((size_t)Cfg::ROWX << lgR) + 2 * (size_t)Cfg::YS;
+    const size_t lds = ((size_t)Cfg::ROWX << lgR) + 2 * (size_t)Cfg::YS + 16;     // + the finish flag (wgrad_finish.h)
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
+    a.fin_lds_off = (int)lds - 16;
     auto kern = wgrad9r_kernel<T, WI, WO, TG, KS>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
@@ -465,8 +511,9 @@ static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s, int blocks_target = 
     // stages drain to zero and take whole pieces only
     const int gran = NS > 2 ? Cfg::RPIX * Cfg::NW : Cfg::RPIX;
     wrows = (wrows + gran - 1) / gran * gran;
-    size_t lds = NS * ((size_t)wrows * Cfg::ROWX + Cfg::YS);
+    size_t lds = NS * ((size_t)wrows * Cfg::ROWX + Cfg::YS) + 16;     // + the finish flag (wgrad_finish.h)
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
+    a.fin_lds_off = (int)lds - 16;
     auto kern = wgrad9_kernel<T, WI, WO, NS, TG, KS, CW>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
