@@ -187,6 +187,25 @@ int y2_accumulate(float* dst, const float* src, size_t n, void* stream);
  * as the two branch gradients of the unit above, never summed in memory); fp32 tensors of n elements, 16-byte aligned. */
 int y2_add_relu(const float* a, const float* b, float* out, size_t n, void* stream);
 int y2_add_relu_backward(const float* dout, const float* dout2, const float* out, float* g, size_t n, void* stream);
+/* Round 5.  LINKED stacks: the stride-1 bottleneck units of the ResNet swap (src/slim_dir/nets/resnet_v1.py:99-112;
+ * src/pascal/pascal_train_resnet.py:37-50) hand activations and gradients to each other in the arithmetic type instead of
+ * through fp32 NHWC tensors (round 4: a cast, a pack and a convert pass on both sides of every join).
+ *   y2_bordered_bytes: size of a zero-bordered tensor [N][H+1][W+1][C] of `dtype` with its guard bands, and the byte
+ *     offset of cell 0 inside it; the caller allocates it ZEROED once (borders and guards are never written).
+ *   y2_link: tensors of the NEXT y2_forward / y2_backward calls of this context (all nullable; pointers address cell 0):
+ *     x_bordered   layer 0's input is this tensor (y2_forward's `images` may then be NULL; no pack pass)
+ *     out_bordered the last layer's activation is written here (the consumer's input; y2_forward's `out` may be NULL)
+ *     join_bordered / join_self   the stored value is relu(join + stack(x)) with the join read from a bordered tensor of
+ *                  the output's geometry, or from the stack's own layer-0 input (identity shortcut); either output form
+ *     dout_t       [M][out_chl] of T: d loss / d (pre-join output) * grad_scale (y2_backward's `dout` may be NULL)
+ *     dx_t         [M][in_chl] of T: receives d loss / d input * grad_scale (beside, or instead of, y2_backward_input's fp32)
+ *   y2_join_backward: g = (d1 + d2) * [out > 0], all of T except d2 when d2_f32 (the g of a run's top unit, fp32);
+ *     out bordered (the unit's output as its consumer holds it), d1 / d2 / g [M][C]. */
+size_t y2_bordered_bytes(int N, int H, int W, int C, int dtype, size_t* cell0_offset);
+int y2_link(y2_ctx* ctx, void* x_bordered, void* out_bordered, const void* join_bordered, int join_self, const void* dout_t,
+            void* dx_t);
+int y2_join_backward(int dtype, const void* out_bordered, const void* d1, const void* d2, int d2_f32, void* g, int N, int H,
+                     int W, int C, void* stream);
 /* scores [rows][classes] -> best score and class index per row (the class choice in front of the NMS of the YOLOv2
  * detector; ties: smallest index, as np.argmax in net_utils.py:418) */
 int y2_class_argmax(const float* scores, float* best, int* cls, int rows, int classes, void* stream);

@@ -74,6 +74,9 @@ SIGNATURES = {
     "y2_accumulate": (_i, [_vp, _vp, _sz, _vp]),
     "y2_add_relu": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "y2_add_relu_backward": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "y2_bordered_bytes": (_sz, [_i, _i, _i, _i, _i, _psz]),
+    "y2_link": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "y2_join_backward": (_i, [_i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "y2_scale": (_i, [_vp, _sz, _f, _vp]),
     "y2_class_argmax": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "y2_decode_anchors": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -299,6 +299,13 @@ __global__ __launch_bounds__(256) void bn_act_kernel(BnActArgs a) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) r[e] = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
         }
+        if (a.join_t) {     // join from a bordered tensor of T (whole chunks: the launcher checks C % EPC == 0)
+            if (c0 < a.C) {
+                const Chunk<T> jv = ld_chunk<T>((const char*)a.join_t + (bpix(n, ho, wo, Ho, Wo) * a.C + c0) * sizeof(T));
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) r[e] = fmaxf(r[e] + Elem<T>::to_f32(jv.v[e]), 0.f);
+            }
+        }
         if (OUTF32) {
             float* o = (float*)a.out + (size_t)po * a.C;
             if (a.join) {
@@ -421,6 +428,11 @@ __global__ __launch_bounds__(256) void bn_fin_act_kernel(BnActArgs a, BnFinalize
             Chunk<T> v = ld_chunk<T>((const char*)a.y + (((size_t)po * a.ldy) + c0) * sizeof(T));
 #pragma unroll
             for (int e = 0; e < EPC; ++e) r[e] = leaky_s(Elem<T>::to_f32(v.v[e]) * sc[e] + sh[e], a.slope);
+        }
+        if (a.join_t) {
+            const Chunk<T> jv = ld_chunk<T>((const char*)a.join_t + (bpix(n, ho, wo, Ho, Wo) * a.C + c0) * sizeof(T));
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) r[e] = fmaxf(r[e] + Elem<T>::to_f32(jv.v[e]), 0.f);
         }
         st_act<T, SPLIT>((char*)a.out, bpix(n, ho, wo, Ho, Wo), a.C, c0, r);
     }

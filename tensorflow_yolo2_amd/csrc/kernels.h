@@ -391,6 +391,8 @@ struct BnActArgs {
                           // what the BN-backward reduce needs of y (fused into the dgrad epilogue above this layer)
     const float* join = nullptr;   // out_f32 only, [M][C] like out: the stored value is max(act + join, 0) -- the join of a
                                    // ResNet bottleneck unit (y2_forward_join)
+    const void* join_t = nullptr;  // the same join read from a BORDERED tensor of T with the output's geometry (round 5,
+                                   // y2_link: bottleneck units chained without an fp32 hand-over); either output form
 };
 hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t s);
 // merge of a short partial list (P <= 128) + apply in one launch (64-channel slabs); bn_fin_act_ok says whether it applies

@@ -147,6 +147,14 @@ struct y2_ctx {
     int n_marks = 0;
     const int* cur_marks = nullptr;
     float* dinput = nullptr;        // y2_backward_input: gradient wrt the stack's input, fp32 [N,H,W,cin]
+    // y2_link (round 5): tensors of the arithmetic type handed from / to the neighbouring stacks of a composed graph --
+    // no fp32 round trip between the bottleneck units of the ResNet swap.  Bordered pointers address cell 0.
+    void* ext_xin = nullptr;        // layer 0's bordered input (else: the fp32 images are packed into the workspace)
+    void* ext_out = nullptr;        // the last layer's output, bordered [N][Ho+1][Wo+1][cout] (else: fp32 `out`)
+    const void* ext_join = nullptr; // added before a final ReLU: bordered, the output's geometry
+    int ext_join_self = 0;          // ... or the stack's own layer-0 input (identity shortcut)
+    const void* ext_dout = nullptr; // gradient wrt the (pre-join) output, [M][ldy] of T, already times grad_scale
+    void* ext_dx = nullptr;         // gradient wrt the stack's input, [M][cin] of T, times grad_scale
     std::vector<ProfRec> prof_recs;
     size_t prof_used = 0;
     size_t sz() const { return dtype_size(dtype); }
@@ -631,7 +639,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
                         int update_moving, float* out, void* stream, const float* join = nullptr);
 int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, int update_moving, float* out,
                void* stream) {
-    if (!images) return fail(Y2_ERR_ARG, "null tensor");
+    if (!images && !c->ext_xin) return fail(Y2_ERR_ARG, "null tensor");
     return forward_impl(c, images, nullptr, train_core, train_head, update_moving, out, stream);
 }
 // The stack as the residual branch of a ResNet bottleneck unit: out = relu(join + stack(images)) written by the last
@@ -654,7 +662,7 @@ int y2_forward_u8(y2_ctx* c, const uint8_t* images_u8, int train_core, int train
 static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8, int train_core, int train_head,
                         int update_moving, float* out, void* stream, const float* join) {
     if (!c->ws) return fail(Y2_ERR_STATE, "bind buffers first");
-    if (!out) return fail(Y2_ERR_ARG, "null tensor");
+    if (!out && !c->ext_out) return fail(Y2_ERR_ARG, "null tensor");
     hipStream_t s = (hipStream_t)stream;
     const size_t sz = c->sz();
     if (c->weights_dirty) {
@@ -676,7 +684,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
         const Layer& y = c->L[l];
         const int training = (l < c->core_layers) ? train_core : train_head;
         c->fwd_training[l] = training;
-        char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
+        char* xin = (l == 0 && c->ext_xin) ? (char*)c->ext_xin : c->ws + y.xin + c->in_geom(l).base_off(sz);
         float* stat = (float*)(c->ws + y.stat);
         float *scale = stat, *shift = stat + y.ldy, *mean = stat + 2 * y.ldy, *invstd = stat + 3 * y.ldy;
         int P = 0;
@@ -708,7 +716,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             if ((!pool1 || training) && !gram1) { PROF(CAT_CONV1_FWD); HIPCHK(launch_conv1_fwd(c->dtype, a, s)); }
             c->gram_valid = gram1;
         } else {
-            if (l == 0) HIPCHK(launch_pack_act(c->dtype, images, xin, c->N, y.H, y.W, y.cin, y.cin_s, s));
+            if (l == 0 && !c->ext_xin) HIPCHK(launch_pack_act(c->dtype, images, xin, c->N, y.H, y.W, y.cin, y.cin_s, s));
             ConvArgs a{};
             a.x = xin; a.w = c->ws + y.wf; a.y = c->ws + y.y; a.bias = c->params + y.pb;
             if (training) { a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2; }
@@ -745,7 +753,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
         // short partial lists: the merge rides in the apply pass (bn.hip bn_fin_act_kernel)
         static const bool no_fin_fuse = getenv("Y2_NO_BN_FIN_FUSE") != nullptr;
         bool fin_fused = false;
-        if (training && !pool1 && !no_fin_fuse && l + 1 < nl) {
+        if (training && !pool1 && !no_fin_fuse && (l + 1 < nl || c->ext_out)) {
             BnActArgs t{};
             t.C = y.cout; t.ldy = y.ldy; t.out_f32 = 0;
             fin_fused = bn_fin_act_ok(t, f);
@@ -782,10 +790,17 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
         if (l + 1 < nl) {
             b.out = c->ws + c->L[l + 1].xin + c->in_geom(l + 1).base_off(sz);
             b.out_f32 = 0;
+        } else if (c->ext_out) {      // linked: the consumer stack's bordered input, in the arithmetic type
+            b.out = c->ext_out;
+            b.out_f32 = 0;
+            b.join_t = c->ext_join_self ? (const void*)(c->ext_xin ? (char*)c->ext_xin : c->ws + c->L[0].xin + c->in_geom(0).base_off(sz))
+                                        : c->ext_join;
         } else {
             b.out = (c->tail == Y2_TAIL_AVGPOOL) ? (void*)(c->ws + c->o_h32) : (void*)out;
             b.out_f32 = 1;
             b.join = join;
+            if (!join) b.join_t = c->ext_join_self ? (const void*)(c->ext_xin ? (char*)c->ext_xin : c->ws + c->L[0].xin + c->in_geom(0).base_off(sz))
+                                                   : c->ext_join;
         }
         if (y.pool && c->bound_training && y.ysel) b.ysel = c->ws + y.ysel;
         if (fin_fused) HIPCHK(launch_bn_fin_act(c->dtype, b, f, s));
@@ -831,7 +846,11 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
     const size_t sz = c->sz();
     const float inv_gs = 1.0f / c->grad_scale;
     char* dA[2] = {c->ws + c->o_dA0, c->ws + c->o_dA1};
-    if (layer_hi == nl) {
+    const bool ext_top = layer_hi == nl && c->ext_dout != nullptr;
+    if (ext_top) {
+        c->dA_cur = 0;
+        if (layer_lo > 0 && c->grads) HIPCHK(hipMemsetAsync(c->grads, 0, c->L[layer_lo].pW * sizeof(float), s));
+    } else if (layer_hi == nl) {
         if (!dout) return fail(Y2_ERR_ARG, "null output gradient");
         const Layer& y = c->L.back();
         const float* src = dout;
@@ -871,7 +890,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         float* stat = (float*)(c->ws + y.stat);
         char* dyp = c->ws + y.dyp + c->dy_geom(l).base_off(sz);
         BnBwdArgs b{};
-        b.dA = dA[c->dA_cur]; b.y = c->ws + y.y;
+        b.dA = (ext_top && l == nl - 1) ? c->ext_dout : (const void*)dA[c->dA_cur]; b.y = c->ws + y.y;
         b.scale = stat; b.shift = stat + y.ldy; b.mean = stat + 2 * y.ldy; b.invstd = stat + 3 * y.ldy;
         b.coef = stat + 4 * y.ldy;
         b.psum = psum;
@@ -940,7 +959,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 if (!fused1 && !lin1) HIPCHK(launch_bn_bwd_apply(bn_dtype, b, s));
             }
         }
-        char* xin = c->ws + y.xin + c->in_geom(l).base_off(sz);
+        char* xin = (l == 0 && c->ext_xin) ? (char*)c->ext_xin : c->ws + y.xin + c->in_geom(l).base_off(sz);
         if (lin1) {
             // no conv output of this layer exists: dW = scale X(dz) - ka X(1) - kb (G W + b X(1))  (conv1_wgrad.hip)
             Conv1DwFinalizeArgs f{};
@@ -982,9 +1001,9 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 forked = true;
             }
             { ProfScope _p(c, ws_, CAT_WGRAD); HIPCHK(launch_wgrad_auto(c->dtype, g, ws_)); }
-            if (l > 0 || c->dinput) {
+            if (l > 0 || c->dinput || c->ext_dx) {
                 ConvArgs a{};
-                a.x = dyp; a.w = c->ws + y.wd; a.y = dA[c->dA_cur ^ 1];
+                a.x = dyp; a.w = c->ws + y.wd; a.y = (l == 0 && c->ext_dx) ? (char*)c->ext_dx : dA[c->dA_cur ^ 1];
                 a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.ldy; a.M = y.M; a.Cout = y.cin; a.ldy = y.cin;
                 a.taps = y.k * y.k;
                 a.is_dgrad = 1;
@@ -1010,8 +1029,9 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }
                 if (fuse) fused_P = rec;
                 c->dA_cur ^= 1;
-                if (l == 0)   // the stack's input gradient leaves in fp32 NHWC, loss scale divided out
-                    HIPCHK(launch_cast_to_f32(c->dtype, dA[c->dA_cur], c->dinput, (size_t)y.M, y.cin, y.cin, s, inv_gs));
+                if (l == 0 && c->dinput)   // the stack's input gradient leaves in fp32 NHWC, loss scale divided out
+                    HIPCHK(launch_cast_to_f32(c->dtype, c->ext_dx ? (const void*)c->ext_dx : (const void*)dA[c->dA_cur], c->dinput,
+                                              (size_t)y.M, y.cin, y.cin, s, inv_gs));
             }
         }
         for (int k = 0; k < c->n_marks; ++k)
@@ -1062,6 +1082,33 @@ int y2_backward_input(y2_ctx* c, const float* dout, float* dinput, void* stream)
     c->dinput = nullptr;
     return rc;
 }
+// ---------------------------------------------------------------------------
+// Linked stacks (round 5): the bottleneck units of the ResNet swap (src/slim_dir/nets/resnet_v1.py:99-112) hand their
+// activations and gradients to each other in the arithmetic type -- bordered tensors forward, [M][C] tensors backward --
+// instead of through fp32 NHWC tensors (cast / pack / convert passes on both sides of every join).
+// ---------------------------------------------------------------------------
+size_t y2_bordered_bytes(int N, int H, int W, int C, int dtype, size_t* cell0_offset) {
+    const PadGeom g{N, H, W, C};
+    if (cell0_offset) *cell0_offset = g.base_off(dtype_size(dtype));
+    return g.bytes(dtype_size(dtype));
+}
+int y2_link(y2_ctx* c, void* x_bordered, void* out_bordered, const void* join_bordered, int join_self, const void* dout_t,
+            void* dx_t) {
+    if (dtype_split(c->dtype) && (x_bordered || out_bordered || join_bordered || join_self || dout_t || dx_t))
+        return fail(Y2_ERR_ARG, "y2_link: not built for the split-operand mode");
+    const Layer& first = c->L.front();
+    const Layer& last = c->L.back();
+    if ((x_bordered || dx_t) && first.first3) return fail(Y2_ERR_ARG, "y2_link: the 3-channel image layer takes fp32 / uint8 images");
+    if ((out_bordered || join_bordered || join_self) && (c->tail == Y2_TAIL_AVGPOOL || last.cout != last.ldy || (last.cout % 8) != 0))
+        return fail(Y2_ERR_ARG, "y2_link: the linked output needs out_chl in multiples of 32 and no average-pool tail");
+    if (join_self && (first.cin != last.cout || first.H != last.Ho || first.W != last.Wo))
+        return fail(Y2_ERR_ARG, "y2_link: an identity shortcut needs input and output of one shape");
+    if (join_self && join_bordered) return fail(Y2_ERR_ARG, "y2_link: one join");
+    c->ext_xin = x_bordered; c->ext_out = out_bordered; c->ext_join = join_bordered; c->ext_join_self = join_self ? 1 : 0;
+    c->ext_dout = dout_t; c->ext_dx = dx_t;
+    return Y2_OK;
+}
+
 int y2_wait_mark(y2_ctx* c, int k, void* stream) {
     if (k < 0 || k >= (int)c->mark_main.size()) return fail(Y2_ERR_ARG, "no such mark");
     HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->mark_main[k], 0));

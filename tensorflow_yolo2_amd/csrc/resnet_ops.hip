@@ -658,6 +658,38 @@ static void rn_bn_apply(const float* x, const float* res, float* y, size_t total
                            gamma, beta, eps, relu);
 }
 
+// The join's backward between LINKED stacks (y2_link, round 5): g = (d1 + d2) * [out > 0] in the arithmetic type T.
+// out: the unit's output as the consumer stack holds it (bordered [N][H+1][W+1][C], cell 0); d1 [M][C] of T: the input
+// gradient of the main branch of the unit above; d2 [M][C]: the other addend -- of T (that unit's shortcut branch or its
+// own g) or fp32 (d2_f32: the g of a run's top unit, which still arrives through the fp32 operators); g [M][C] of T.
+// Eight channels per thread.
+template <typename T>
+__global__ void rn_join_bwd_t_kernel(const T* __restrict__ outb, const T* __restrict__ d1, const void* __restrict__ d2,
+                                     int d2_f32, T* __restrict__ g, int N, int H, int W, int C) {
+    const int cg = C / 8;
+    const size_t total = (size_t)N * H * W * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cg) * 8;
+        const size_t m = i / cg;
+        const int w = (int)(m % W), h = (int)((m / W) % H), n = (int)(m / ((size_t)W * H));
+        const y2::Chunk<T> o = y2::ld_chunk<T>(outb + y2::bpix(n, h, w, H, W) * C + c);
+        const y2::Chunk<T> a = y2::ld_chunk<T>(d1 + m * C + c);
+        float b[8];
+        if (d2_f32) {
+            const float4 b0 = *(const float4*)((const float*)d2 + m * C + c), b1 = *(const float4*)((const float*)d2 + m * C + c + 4);
+            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+        } else {
+            const y2::Chunk<T> bt = y2::ld_chunk<T>((const T*)d2 + m * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = y2::Elem<T>::to_f32(bt.v[e]);
+        }
+        y2::Chunk<T> r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            r.v[e] = y2::Elem<T>::from_f32(y2::Elem<T>::to_f32(o.v[e]) > 0.f ? y2::Elem<T>::to_f32(a.v[e]) + b[e] : 0.f);
+        y2::st_chunk<T>(g + m * C + c, r);
+    }
+}
 extern "C" {
 
 int y2_batch_norm_forward(const float* x, const float* residual, float* y, size_t rows, int channels, const float* gamma,
@@ -749,6 +781,23 @@ int y2_add_relu_backward(const float* dout, const float* dout2, const float* out
     const size_t n4 = n / 4;
     hipLaunchKernelGGL(rn_add_relu_bwd_kernel, dim3(grid_for(n4)), dim3(256), 0, (hipStream_t)stream, (const float4*)dout,
                        (const float4*)dout2, (const float4*)out, (float4*)g, n4, dout, dout2, out, g, n4 * 4, n);
+    RCHK(hipGetLastError());
+    return Y2_OK;
+}
+
+int y2_join_backward(int dtype, const void* out_bordered, const void* d1, const void* d2, int d2_f32, void* g, int N, int H,
+                     int W, int C, void* stream) {
+    if (!out_bordered || !d1 || !d2 || !g) return rfail(Y2_ERR_ARG, "null tensor");
+    if (dtype != 1 && dtype != 2) return rfail(Y2_ERR_ARG, "y2_join_backward: 16-bit arithmetic types (linked stacks)");
+    if (C % 8 != 0) return rfail(Y2_ERR_ARG, "y2_join_backward: channels in multiples of 8");
+    const size_t total = (size_t)N * H * W * (C / 8);
+    const dim3 grid(grid_for(total)), block(256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(rn_join_bwd_t_kernel<y2::half_t>, grid, block, 0, (hipStream_t)stream, (const y2::half_t*)out_bordered,
+                           (const y2::half_t*)d1, d2, d2_f32, (y2::half_t*)g, N, H, W, C);
+    else
+        hipLaunchKernelGGL(rn_join_bwd_t_kernel<y2::bf16_t>, grid, block, 0, (hipStream_t)stream, (const y2::bf16_t*)out_bordered,
+                           (const y2::bf16_t*)d1, d2, d2_f32, (y2::bf16_t*)g, N, H, W, C);
     RCHK(hipGetLastError());
     return Y2_OK;
 }

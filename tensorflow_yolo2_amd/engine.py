@@ -275,6 +275,31 @@ class Network:
             assert dout.is_cuda and dout.dtype == torch.float32 and dout.is_contiguous()
         check(self.lib.y2_backward(self.h, _ptr(dout), layer_lo, layer_hi, _stream()))
 
+    # ---- linked stacks (y2_link: bottleneck units chained in the arithmetic type) -----------------------------
+    def link(self, x=None, out=None, join=None, join_self=False, dout=None, dx=None):
+        """tensors of the next forward / backward calls of this context: x / out / join are Bordered tensors, dout / dx
+        [M][C] tensors of the arithmetic type (include/yolo2_hip.h y2_link); all None restores the fp32 interface"""
+        cell = lambda b: None if b is None else C.c_void_p(b.cell0)
+        raw = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._linked = (x, out, join, dout, dx)           # keep the tensors alive
+        check(self.lib.y2_link(self.h, cell(x), cell(out), cell(join), int(bool(join_self)), raw(dout), raw(dx)))
+
+    def forward_linked(self, is_training=True, update_moving=False, out=None, images=None):
+        """forward with the linked tensors: `images` only when layer 0 is not linked, `out` (fp32) only when the output
+        is not"""
+        check(self.lib.y2_forward(self.h, _ptr(images) if images is not None else None, int(bool(is_training)),
+                                  int(bool(is_training)), int(bool(update_moving)),
+                                  _ptr(out) if out is not None else None, _stream()))
+        return out
+
+    def backward_linked(self, dout=None, dinput=None):
+        """backward; dout (fp32) only when no typed output gradient is linked; dinput: fp32 [N,H,W,cin] to receive the
+        input gradient as well (y2_backward_input)"""
+        if dinput is not None:
+            check(self.lib.y2_backward_input(self.h, _ptr(dout) if dout is not None else None, _ptr(dinput), _stream()))
+        else:
+            check(self.lib.y2_backward(self.h, _ptr(dout) if dout is not None else None, 0, self.num_layers, _stream()))
+
     def backward_input(self, dout):
         """full backward; also returns d loss / d input of the stack, fp32 [N,H,W,cin] (composed graphs)"""
         assert dout.is_cuda and dout.dtype == torch.float32 and dout.is_contiguous()
@@ -337,6 +362,47 @@ class Network:
         t = torch.empty((self.batch, info[4], info[5], c), dtype=torch.float32, device=self.device)
         check(self.lib.y2_debug_read(self.h, layer, what, _ptr(t), _stream()))
         return t
+
+
+class Bordered:
+    """a zero-bordered activation tensor [N][H+1][W+1][C] of the arithmetic type with its guard bands (csrc/common.h
+    bpix), allocated zeroed once: what two linked stacks share (Network.link)"""
+
+    def __init__(self, n, h, w, c, dtype, device):
+        lib = _lib.load()
+        dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        off = C.c_size_t(0)
+        nbytes = lib.y2_bordered_bytes(n, h, w, c, dt, C.byref(off))
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.cell0 = self.buf.data_ptr() + off.value
+        self.shape = (n, h, w, c)
+        self._off, self._tdtype = off.value, {_lib.Y2_F32: torch.float32, _lib.Y2_F16: torch.float16, _lib.Y2_BF16: torch.bfloat16}[dt]
+
+    def _interior(self):
+        """view of the image cells [N, H, W, C] in the tensor's own type: cell (n, h, w) sits at row n (H + 1) + h + 1,
+        column w + 1 of a (W + 1)-wide pixel grid that starts at cell 0"""
+        n, h, w, c = self.shape
+        esz = torch.empty(0, dtype=self._tdtype).element_size()
+        rows = n * (h + 1)
+        body = self.buf[self._off:self._off + rows * (w + 1) * c * esz].view(self._tdtype).view(n, h + 1, w + 1, c)
+        return body[:, 1:, 1:, :]
+
+    def write(self, x):
+        """tests: fill the image cells from an fp32 NHWC tensor (borders stay zero)"""
+        self._interior().copy_(x.to(self._tdtype))
+
+    def read(self):
+        return self._interior().float()
+
+
+def join_backward(dtype, out_bordered, d1, d2, g):
+    """g = (d1 + d2) * [out > 0] between linked stacks (y2_join_backward); d2 fp32 or of the arithmetic type"""
+    lib = _lib.load()
+    dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    n, h, w, c = out_bordered.shape
+    check(lib.y2_join_backward(dt, C.c_void_p(out_bordered.cell0), C.c_void_p(d1.data_ptr()), C.c_void_p(d2.data_ptr()),
+                               int(d2.dtype == torch.float32), C.c_void_p(g.data_ptr()), n, h, w, c, _stream()))
+    return g
 
 
 # ---------------------------------------------------------------------------

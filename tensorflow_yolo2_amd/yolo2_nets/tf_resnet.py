@@ -57,6 +57,7 @@ def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, 
 
 
 _TWO_CALL_JOIN = bool(os.environ.get("Y2_RESNET_TWO_CALL_JOIN"))
+_NO_LINK = bool(os.environ.get("Y2_RESNET_NO_LINK"))       # A/B: round 4's fp32 hand-over between the fused units
 
 
 class ResNet50Yolo:
@@ -64,7 +65,7 @@ class ResNet50Yolo:
 
     def __init__(self, batch, image_size=224, B=2, num_class=20, dtype="f32", blocks=None, root_depth=64,
                  fc_hidden=4096, seed=0, device="cuda:0", learning_rate=0.0005, keep_prob=0.5, loss_scale=None,
-                 graph=False, graph_check_every=16, fused=None):
+                 graph=False, graph_check_every=16, fused=None, link=None):
         """dtype: arithmetic of the convolution / FC contractions.  "f32" (default: the reference's precision).  With
         "f16" the gradient of the loss is multiplied by a dynamic loss scale before the backward pass (activation
         gradients 50 layers deep at batch 4 fall below f16's normal range otherwise), the scale is divided out inside
@@ -84,6 +85,9 @@ class ResNet50Yolo:
         if fused is None:
             fused = dtype != "f32" and self._stacks_fit(self.blocks, root_depth)
         self.fused = bool(fused)
+        # link (round 5; default on, Y2_RESNET_NO_LINK=1 / link=False: round 4's fp32 hand-over): runs of fused units
+        # exchange activations and gradients in the arithmetic type (_linked_units)
+        self.link = (not _NO_LINK) if link is None else bool(link)
         self.vars = variable_list(self.blocks, root_depth, fc_hidden, self.S * self.S * self.out_c, self.S)
         self.layout = variable_list(self.blocks, root_depth, fc_hidden, self.S * self.S * self.out_c, self.S,
                                     hidden_bias=self.fused)
@@ -108,6 +112,7 @@ class ResNet50Yolo:
                 self.p[name] = self.state[os_:os_ + n].view(shape)
                 os_ += n
         self._stacks = {}                                 # unit scope -> (main stack, projection stack or None)
+        self._stacks_meta = {}
         self.m = torch.zeros_like(self.params)
         self.v = torch.zeros_like(self.params)
         self.t = 0
@@ -161,6 +166,71 @@ class ResNet50Yolo:
             proj = make("shortcut", "shortcut", [(1, cin, depth, 0)], [1.0]) if depth != cin else None
             self._stacks[key] = (main, proj)
         return self._stacks[key]
+
+    def _linked_units(self, hw0, cin0):
+        """Round 5: runs of consecutive stride-1 units exchange their activations and gradients in the arithmetic type
+        (engine.Network.link; include/yolo2_hip.h y2_link) -- bordered half-precision tensors forward, [M][C] tensors
+        backward -- instead of fp32 NHWC tensors with a cast / pack / convert pass on both sides of every join.  A run
+        is entered from and left to the fp32 graph-level operators (root, stride-2 units, head); its first unit must have a
+        projection shortcut (its input gradient leaves as two fp32 addends), which every first unit of a block has.
+        Returns {unit scope: descriptor}; built once per input size."""
+        key = ("units", hw0)
+        if key in self._stacks_meta:
+            return self._stacks_meta[key]
+        units, run = {}, []
+        hw, cin = hw0, cin0
+
+        def close(run):
+            for i, u in enumerate(run):
+                u["bottom"], u["top"] = i == 0, i == len(run) - 1
+                u["below"], u["above"] = (run[i - 1] if i > 0 else None), (run[i + 1] if i + 1 < len(run) else None)
+        for bname, blk in self.blocks:
+            for i, (depth, db, stride) in enumerate(blk):
+                sc = "%s/unit_%d/bottleneck_v1/" % (bname, i + 1)
+                if self.fused and stride == 1:
+                    u = {"scope": sc, "hw": hw, "cin": cin, "depth": depth, "db": db, "proj": depth != cin}
+                    if not run and not u["proj"]:
+                        close([u])                      # an identity unit cannot open a run: it stays on the fp32 interface
+                    else:
+                        run.append(u)
+                    units[sc] = u
+                else:
+                    close(run)
+                    run = []
+                hw, cin = (hw + stride - 1) // stride, depth
+        close(run)
+        if not self.link or self.dtype not in ("f16", "bf16"):       # (the typed hand-over exists for the 16-bit types)
+            for u in units.values():
+                u["bottom"] = u["top"] = True
+                u["below"] = u["above"] = None
+        dev, dt, n = str(self.device), self.dtype, self.batch
+        tdt = torch.float16 if dt == "f16" else torch.bfloat16
+        for u in units.values():
+            main, proj = self._stack_for(u["scope"], u["hw"], u["cin"], u["depth"], u["db"])
+            u["main"], u["pstack"] = main, proj
+            m = n * u["hw"] * u["hw"]
+            if not u["top"]:      # my output is the next unit's bordered input
+                u["out_b"] = E.Bordered(n, u["hw"], u["hw"], u["depth"], dt, dev)
+                u["g"] = torch.zeros((m, u["depth"]), dtype=tdt, device=dev)        # my join's gradient (T), made by join_backward
+            if u["proj"] and not (u["bottom"] and u["top"]):
+                u["short_b"] = E.Bordered(n, u["hw"], u["hw"], u["depth"], dt, dev)  # the projection's output, joined in T
+            if not u["bottom"]:
+                u["dxm"] = torch.zeros((m, u["cin"]), dtype=tdt, device=dev)
+                if u["proj"]:
+                    u["dxp"] = torch.zeros((m, u["cin"]), dtype=tdt, device=dev)
+        for u in units.values():
+            if u["bottom"] and u["top"]:
+                continue                                  # unlinked: round 4's calls
+            xin = u["below"]["out_b"] if not u["bottom"] else None
+            out_b = u.get("out_b")
+            g_in = u.get("g")                               # None at the top: fp32 dout through the convert pass
+            if u["proj"]:
+                u["pstack"].link(x=xin, out=u["short_b"], dout=g_in, dx=u.get("dxp"))
+                u["main"].link(x=xin, out=out_b, join=u["short_b"], dout=g_in, dx=u.get("dxm"))
+            else:
+                u["main"].link(x=xin, out=out_b, join_self=True, dout=g_in, dx=u.get("dxm"))
+        self._stacks_meta[key] = units
+        return units
 
     def params_changed(self):
         """the flat parameter buffer moved (optimizer step, load, restore): the stacks re-pack their filters"""
@@ -258,9 +328,23 @@ class ResNet50Yolo:
         tape.append(("conv7", images))
         x, r = self._bn(x, "conv1", True); tape.append(r)
         pooled = E.max_pool_3x3_s2(x); tape.append(("pool", x)); x = pooled                # resnet_v1.py:198
-        for bname, units in self.blocks:
-            for i, (depth, db, stride) in enumerate(units):                                  # resnet_v1.py:99-112
+        units = self._linked_units(int(x.shape[1]), int(x.shape[3])) if self.fused else {}
+        for bname, blk in self.blocks:
+            for i, (depth, db, stride) in enumerate(blk):                                    # resnet_v1.py:99-112
                 sc = "%s/unit_%d/bottleneck_v1/" % (bname, i + 1)
+                if self.fused and stride == 1 and not (units[sc]["bottom"] and units[sc]["top"]):
+                    # linked run: typed tensors between the units, fp32 only where the run meets the graph-level operators
+                    u = units[sc]
+                    xin = x.contiguous() if u["bottom"] else None
+                    out = None
+                    if u["top"]:
+                        out = torch.empty((self.batch, u["hw"], u["hw"], u["depth"]), dtype=torch.float32, device=self.device)
+                    if u["proj"]:
+                        u["pstack"].forward_linked(is_training, update_moving, images=xin)
+                    u["main"].forward_linked(is_training, update_moving, out=out, images=xin)
+                    tape.append(("linked", u, out))
+                    x = out
+                    continue
                 if self.fused and stride == 1:
                     main, proj = self._stack_for(sc, int(x.shape[1]), int(x.shape[3]), depth, db)
                     xin = x.contiguous()
@@ -320,10 +404,38 @@ class ResNet50Yolo:
         dx = dflat.reshape(feat.shape).contiguous()
         dx2 = None          # a fused unit leaves its input gradient as two addends (main branch, shortcut): the unit below
         for rec in reversed(self.tape[:-1]):    # folds their sum into its own join's backward, anything else adds them first
-            if rec[0] != "fused" and dx2 is not None:
+            if rec[0] not in ("fused", "linked") and dx2 is not None:
                 dx = E.accumulate(dx, dx2)
                 dx2 = None
-            if rec[0] == "fused":
+            if rec[0] == "linked":
+                _k, u, out = rec
+                main, proj = u["main"], u["pstack"]
+                if u["top"]:
+                    # the run's top: the incoming gradient is fp32; g = d(relu(r + s)) to both branches, fp32
+                    g32 = E.add_relu_backward(dx.contiguous(), out, dx2)
+                    dx2 = None
+                    main.backward_linked(dout=g32)                        # input gradient -> u["dxm"] (T)
+                    if proj is not None:
+                        proj.backward_linked(dout=g32)                    # -> u["dxp"] (T)
+                    u["_short_grad"] = g32 if proj is None else u["dxp"]
+                else:
+                    a = u["above"]
+                    # g = (main branch of the unit above + its shortcut branch) * [my output > 0], all in T
+                    E.join_backward(self.dtype, u["out_b"], a["dxm"], a["_short_grad"], u["g"])
+                    if u["bottom"]:
+                        # the run's bottom: the input gradient leaves as two fp32 addends (main branch, projection)
+                        dx = torch.empty((self.batch, u["hw"], u["hw"], u["cin"]), dtype=torch.float32, device=self.device)
+                        dx2 = torch.empty_like(dx)
+                        main.backward_linked(dinput=dx)
+                        proj.backward_linked(dinput=dx2)
+                    else:
+                        main.backward_linked()
+                        if proj is not None:
+                            proj.backward_linked()
+                        u["_short_grad"] = u["g"] if proj is None else u["dxp"]
+                if u["top"] and u["bottom"]:
+                    raise AssertionError("unlinked units take the fused path")
+            elif rec[0] == "fused":
                 _k, main, proj, out = rec
                 g = E.add_relu_backward(dx.contiguous(), out, dx2)     # d(relu(r + s)) = dout * [out > 0], to both branches
                 dx = main.backward_input(g)
