@@ -264,6 +264,16 @@ int y2_fully_connected(const float* x, const float* w, const float* bias, float*
                        int out_features, int relu, int dtype, void* stream);
 int y2_fully_connected_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int rows,
                                 int in_features, int out_features, int dtype, void* stream);
+/* Round 5: the weight gradient of a fully connected layer fused with the guarded Adam update of that weight -- dW is
+ * never stored (tf.train.AdamOptimizer(0.0005).minimize over yolo_fc1, src/pascal/pascal_train_resnet.py:41-50: 1.64 GB of
+ * weights; writing, scanning and re-reading its gradient were 3 of the 10 passes over that size per step).  x [rows,in],
+ * dz [rows,out] (gradient at the pre-activation, times the loss scale), w / m / v [in,out]; ctrl: the control block of
+ * y2_adam_step_guarded AFTER that call advanced it for this step (found_inf: nothing moves; lr_t applies).  The caller's
+ * overflow scan covers every OTHER gradient (the bias gradient of the same layer is the column sum of dz: a non-finite
+ * dz is seen there). */
+int y2_fc_adam_apply_guarded(const float* x, const float* dz, float* w, float* m, float* v, int rows, int in_features,
+                             int out_features, int dtype, const void* ctrl, float beta1, float beta2, float eps,
+                             float grad_mult, void* stream);
 /* slim.fully_connected tail (pascal_train_resnet.py:41-46): y <- act(y + bias) in place; backward dz = dy [y > 0],
  * dbias = column sums; tf.nn.dropout(x, keep_prob) with a mask that is a function of (seed, index) */
 int y2_bias_relu(float* y, const float* bias, size_t rows, int channels, int relu, void* stream);

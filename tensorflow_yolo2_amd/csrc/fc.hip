@@ -18,6 +18,7 @@
 #include "../../include/yolo2_hip.h"
 #include "common.h"
 #include "kernels.h"
+#include "optim_math.h"
 
 namespace y2 {
 int set_error(int code, const char* msg);
@@ -251,6 +252,78 @@ __global__ __launch_bounds__(256) void fc_dw_kernel(const float* __restrict__ x,
     }
 }
 
+// The same product with the guarded Adam update of the weight in its epilogue (round 5): dW is NEVER stored.  The
+// fully connected layer of the ResNet swap's grid head (src/pascal/pascal_train_resnet.py:41-46) holds 100352 x 4096
+// weights -- 1.64 GB; writing its gradient, scanning it for the overflow guard and reading it back in the optimizer
+// were 3 of the 10 passes over that size per step.  ctrl: the control block of y2_adam_step_guarded AFTER its
+// advance (found_inf decides, lr_t applies); the arithmetic is optim_math.h's, bit for bit what the flat kernel does
+// with the stored gradient.
+struct FcCtrlView { int found_inf, step, skipped, reserved; float lr_t; };
+template <typename T, int MS>
+__global__ __launch_bounds__(256) void fc_dw_adam_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ W, float* __restrict__ Mo, float* __restrict__ Vo,
+                                                         int M, int K, int N, int tiles_per_chunk, const FcCtrlView* ctrl,
+                                                         float b1, float b2, float eps, float gmult) {
+    if (ctrl->found_inf) return;          // overflowed gradients somewhere in the step: nothing moves
+    const float lr_t = ctrl->lr_t;
+    constexpr int KPL = Elem<T>::kPerFrag, KS = 2 * KPL;
+    typedef typename Elem<T>::frag frag_t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l32 = lane & 31, kg = lane >> 5;
+    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    if (k0 >= K) return;
+    const int kc = min(k0 + l32, K - 1);
+    frag_t fa[MS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) {
+        float v[KPL];
+#pragma unroll
+        for (int e = 0; e < KPL; ++e) {
+            const int m = ms * KS + kg * KPL + e;
+            v[e] = m < M ? x[(size_t)m * K + kc] : 0.f;
+        }
+        fa[ms] = fc_frag<T>(v);
+    }
+    const int ntiles = (N + 31) / 32;
+    const int t0 = blockIdx.y * tiles_per_chunk;
+    int t1 = t0 + tiles_per_chunk;
+    if (t1 > ntiles) t1 = ntiles;
+    for (int t = t0; t < t1; ++t) {
+        const int n = t * 32 + l32, nc = min(n, N - 1);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int ms = 0; ms < MS; ++ms) {
+            float v[KPL];
+#pragma unroll
+            for (int e = 0; e < KPL; ++e) {
+                const int m = ms * KS + kg * KPL + e;
+                v[e] = m < M ? dy[(size_t)m * N + nc] : 0.f;
+            }
+            mma32(acc, fa[ms], fc_frag<T>(v));
+        }
+        if (n < N) {
+            float pw[16], pm[16], pv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {      // all loads of the tile first
+                const int k = k0 + acc_row(q, kg);
+                const size_t o = (size_t)(k < K ? k : K - 1) * N + n;
+                pw[q] = W[o]; pm[q] = Mo[o]; pv[q] = Vo[o];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = k0 + acc_row(q, kg);
+                if (k < K) {
+                    adam_update(pw[q], pm[q], pv[q], acc[q] * gmult, lr_t, b1, b2, eps);
+                    const size_t o = (size_t)k * N + n;
+                    W[o] = pw[q]; Mo[o] = pm[q]; Vo[o] = pv[q];
+                }
+            }
+        }
+    }
+}
+
 static int fc_fail(int code, const char* msg) { return set_error(code, msg); }
 #define FCHK(expr)                                                    \
     do {                                                              \
@@ -333,6 +406,30 @@ static int fc_backward_T(const float* x, const float* w, const float* dy, float*
     FCHK(hipGetLastError());
     return Y2_OK;
 }
+template <typename T>
+static int fc_adam_T(const float* x, const float* dy, float* w, float* m, float* v, int M, int K, int N, const void* ctrl,
+                     float b1, float b2, float eps, float gmult, hipStream_t s) {
+    constexpr int KS = 2 * Elem<T>::kPerFrag;
+    const int kw = ((K + 31) / 32 + 3) / 4;            // workgroups along K
+    const int ntiles = (N + 31) / 32;
+    int chunks = 2048 / kw;
+    if (chunks > ntiles / 4) chunks = ntiles / 4;
+    if (chunks < 1) chunks = 1;
+    const int tpc = (ntiles + chunks - 1) / chunks;
+    chunks = (ntiles + tpc - 1) / tpc;
+    const dim3 grid(kw, chunks);
+    const int ms = (M + KS - 1) / KS;
+#define FC_DWA(MSv) hipLaunchKernelGGL((fc_dw_adam_kernel<T, MSv>), grid, dim3(256), 0, s, x, dy, w, m, v, M, K, N, tpc, \
+                                       (const FcCtrlView*)ctrl, b1, b2, eps, gmult)
+    if (ms <= 1) FC_DWA(1);
+    else if (ms <= 2) FC_DWA(2);
+    else if (ms <= 4) FC_DWA(4);
+    else if (ms <= 8) FC_DWA(8);
+    else FC_DWA(16);
+#undef FC_DWA
+    FCHK(hipGetLastError());
+    return Y2_OK;
+}
 }  // namespace y2
 
 using namespace y2;
@@ -347,6 +444,20 @@ int y2_fully_connected(const float* x, const float* w, const float* bias, float*
         case 0: return fc_forward_T<float>(x, w, bias, y, rows, in_features, out_features, relu, s);
         case 1: return fc_forward_T<half_t>(x, w, bias, y, rows, in_features, out_features, relu, s);
         case 2: return fc_forward_T<bf16_t>(x, w, bias, y, rows, in_features, out_features, relu, s);
+    }
+    return fc_fail(Y2_ERR_ARG, "bad dtype");
+}
+int y2_fc_adam_apply_guarded(const float* x, const float* dz, float* w, float* m, float* v, int rows, int in_features,
+                             int out_features, int dtype, const void* ctrl, float beta1, float beta2, float eps,
+                             float grad_mult, void* stream) {
+    if (!x || !dz || !w || !m || !v || !ctrl) return fc_fail(Y2_ERR_ARG, "fully connected: null tensor");
+    if (rows < 1 || rows > 128) return fc_fail(Y2_ERR_ARG, "fully connected: 1..128 rows (the batch) per call");
+    if (in_features < 1 || out_features < 1) return fc_fail(Y2_ERR_ARG, "fully connected: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case 0: return fc_adam_T<float>(x, dz, w, m, v, rows, in_features, out_features, ctrl, beta1, beta2, eps, grad_mult, s);
+        case 1: return fc_adam_T<half_t>(x, dz, w, m, v, rows, in_features, out_features, ctrl, beta1, beta2, eps, grad_mult, s);
+        case 2: return fc_adam_T<bf16_t>(x, dz, w, m, v, rows, in_features, out_features, ctrl, beta1, beta2, eps, grad_mult, s);
     }
     return fc_fail(Y2_ERR_ARG, "bad dtype");
 }

@@ -981,14 +981,17 @@ def fully_connected(x, w, bias=None, relu=True, dtype="f32"):
     return y
 
 
-def fully_connected_backward(x, w, dz, dtype="f32", want_dx=True, dw_out=None):
-    """dz = gradient at the pre-activation [rows, out] -> (dx [rows, in] or None, dw [in, out])"""
+def fully_connected_backward(x, w, dz, dtype="f32", want_dx=True, dw_out=None, want_dw=True):
+    """dz = gradient at the pre-activation [rows, out] -> (dx [rows, in] or None, dw [in, out] or None)"""
     lib = _lib.load()
     _chk(x, w, dz)
     m, k = x.shape
     n = w.shape[1]
     assert tuple(dz.shape) == (m, n)
     dx = torch.empty_like(x) if want_dx else None
+    if not want_dw:
+        check(lib.y2_fully_connected_backward(_ptr(x), _ptr(w), _ptr(dz), _ptr(dx), None, m, k, n, _lib.DTYPES[dtype], _stream()))
+        return dx, None
     if dw_out is not None:
         assert dw_out.is_cuda and dw_out.dtype == torch.float32 and dw_out.is_contiguous() and dw_out.numel() == w.numel()
         dw = dw_out

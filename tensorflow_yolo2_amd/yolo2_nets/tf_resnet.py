@@ -65,7 +65,7 @@ class ResNet50Yolo:
 
     def __init__(self, batch, image_size=224, B=2, num_class=20, dtype="f32", blocks=None, root_depth=64,
                  fc_hidden=4096, seed=0, device="cuda:0", learning_rate=0.0005, keep_prob=0.5, loss_scale=None,
-                 graph=False, graph_check_every=16, fused=None, link=None):
+                 graph=False, graph_check_every=16, fused=None, link=None, fuse_fc1=None):
         """dtype: arithmetic of the convolution / FC contractions.  "f32" (default: the reference's precision).  With
         "f16" the gradient of the loss is multiplied by a dynamic loss scale before the backward pass (activation
         gradients 50 layers deep at batch 4 fall below f16's normal range otherwise), the scale is divided out inside
@@ -91,6 +91,13 @@ class ResNet50Yolo:
         self.vars = variable_list(self.blocks, root_depth, fc_hidden, self.S * self.S * self.out_c, self.S)
         self.layout = variable_list(self.blocks, root_depth, fc_hidden, self.S * self.S * self.out_c, self.S,
                                     hidden_bias=self.fused)
+        # fuse_fc1 (round 5; the guarded half-precision modes): yolo_fc1/weights (1.64 GB at full width) sits LAST in the
+        # flat buffers and its gradient is never stored -- the train step updates it with y2_fc_adam_apply_guarded from
+        # the layer's input and dz after the overflow scan + guarded Adam of everything in front of it
+        self.fuse_fc1 = (dtype != "f32" and not os.environ.get("Y2_RESNET_NO_FC1_FUSE")) if fuse_fc1 is None else \
+            (bool(fuse_fc1) and dtype != "f32")
+        if self.fuse_fc1:
+            self.layout = [e for e in self.layout if e[0] != "yolo_fc1/weights"] + [e for e in self.layout if e[0] == "yolo_fc1/weights"]
         n_train = sum(int(np.prod(s)) for (_n, s, t) in self.layout if t)
         n_state = sum(int(np.prod(s)) for (_n, s, t) in self.layout if not t)
         self.params = torch.zeros(n_train, dtype=torch.float32, device=self.device)      # ONE flat buffer: one Adam
@@ -389,8 +396,9 @@ class ResNet50Yolo:
         self.tape = tape
         return fc2.view(n, self.S, self.S, self.out_c)
 
-    def backward(self, dgrid):
-        """gradients of every trainable variable into self.grads"""
+    def backward(self, dgrid, skip_fc1_dw=False):
+        """gradients of every trainable variable into self.grads (skip_fc1_dw: all but yolo_fc1/weights, whose update is
+        fused with its gradient in the train step: _fc1_operands keeps the layer's input and dz)"""
         assert self.tape is not None
         n = self.batch
         _k, feat, flat, fc1, h, fc2, use_drop, seed = self.tape[-1]
@@ -399,8 +407,12 @@ class ResNet50Yolo:
                                            dw_out=self.g["yolo_fc2/weights"])
         dfc1 = E.dropout(dh, self.keep_prob, seed) if use_drop else dh                      # same mask, same 1/keep scale
         dz1, _ = E.bias_relu_backward(dfc1, fc1, True, dbias_out=self.g["yolo_fc1/biases"])
-        dflat, _ = E.fully_connected_backward(flat, self.p["yolo_fc1/weights"], dz1, self.dtype,
-                                              dw_out=self.g["yolo_fc1/weights"])
+        if skip_fc1_dw:
+            dflat, _ = E.fully_connected_backward(flat, self.p["yolo_fc1/weights"], dz1, self.dtype, want_dw=False)
+            self._fc1_operands = (flat, dz1)
+        else:
+            dflat, _ = E.fully_connected_backward(flat, self.p["yolo_fc1/weights"], dz1, self.dtype,
+                                                  dw_out=self.g["yolo_fc1/weights"])
         dx = dflat.reshape(feat.shape).contiguous()
         dx2 = None          # a fused unit leaves its input gradient as two addends (main branch, shortcut): the unit below
         for rec in reversed(self.tape[:-1]):    # folds their sum into its own join's backward, anything else adds them first
@@ -493,14 +505,31 @@ class ResNet50Yolo:
         lib = E._lib.load()
         if self.loss_scale != 1.0:
             E.check(lib.y2_scale(E._ptr(dnet), dnet.numel(), self.loss_scale, E._stream()))
-        self.backward(dnet)
-        n = self.params.numel()
-        E.check(lib.y2_grad_check_full(E._ptr(self.grads), n, E._ptr(self.ctrl), E._stream()))
-        E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
-                                         E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+        self._guarded_update(lib, dnet)
         self.params_changed()       # the fused stacks re-pack their filters at the top of the next forward (captured with it)
         self.tape = None
         return loss, ious, mask
+
+    def _guarded_update(self, lib, dnet):
+        """overflow scan + guarded Adam of one step (dnet: run the backward pass first).  fuse_fc1: everything in front of
+        yolo_fc1/weights is scanned and updated from the stored gradients (its bias gradient, the column sum of dz, stands
+        guard for the weight's own), then the weight is updated from the layer's input and dz without its gradient ever
+        being stored"""
+        fused = self.fuse_fc1
+        if dnet is not None:
+            self.backward(dnet, skip_fc1_dw=fused)
+        n = self.offset["yolo_fc1/weights"][0] if fused else self.params.numel()
+        E.check(lib.y2_grad_check_full(E._ptr(self.grads), n, E._ptr(self.ctrl), E._stream()))
+        E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
+                                         E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+        if fused:
+            flat, dz1 = self._fc1_operands
+            o, cnt = self.offset["yolo_fc1/weights"]
+            E.check(lib.y2_fc_adam_apply_guarded(E._ptr(flat), E._ptr(dz1), E._ptr(self.params[o:o + cnt]), E._ptr(self.m[o:o + cnt]),
+                                                 E._ptr(self.v[o:o + cnt]), flat.shape[0], flat.shape[1], dz1.shape[1],
+                                                 E._lib.DTYPES[self.dtype], E._ptr(self.ctrl), 0.9, 0.999, 1e-8,
+                                                 1.0 / self.loss_scale, E._stream()))
+            self._fc1_operands = None
 
     def _follow_ctrl(self):
         """host read of the device control block: step count, skipped steps -> loss scale (graph mode)"""
@@ -563,7 +592,7 @@ class ResNet50Yolo:
         lib = E._lib.load()
         if self.loss_scale != 1.0:
             E.check(lib.y2_scale(E._ptr(dnet), dnet.numel(), self.loss_scale, E._stream()))
-        self.backward(dnet)
+        self.backward(dnet, skip_fc1_dw=self.guard and self.fuse_fc1)
         n = self.params.numel()
         if not self.guard:
             self.t += 1
@@ -573,9 +602,7 @@ class ResNet50Yolo:
             return loss, ious, mask
         # half precision: full overflow scan, then the guarded update (skipped as a whole on the device when any
         # gradient is inf / NaN; the step counter and TF's lr_t live in ctrl)
-        E.check(lib.y2_grad_check_full(E._ptr(self.grads), n, E._ptr(self.ctrl), E._stream()))
-        E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
-                                         E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+        self._guarded_update(lib, None)
         self.params_changed()
         c = self.ctrl.cpu()                      # this untuned batch-4 path can afford the host read every step
         self.t = int(c[1])
