@@ -25,8 +25,11 @@ struct EpiCfg {
 };
 
 // phases 2 and 3 (after the wave's patch has been written)
+// cstride / coff (conv_epilogue16 callers that run the epilogue in TWO passes over halves of a wave's couts, because the
+// fp32 patch of the whole tile does not fit LDS): the couts of wave column wc start at n0 + wc * cstride + coff
 template <typename T, int WP, int WC, int TP, int TC, int EABL = 0>
-Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane, int m0, int n0, int pt, int ct);
+Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane, int m0, int n0, int pt, int ct,
+                                 int cstride = TC * 32, int coff = 0);
 
 // must be entered by ALL threads of the block, after a barrier that retires every read
 // of the staging buffers (the patch aliases them)
@@ -72,13 +75,13 @@ Y2_DEV int perm16(int c) { return c < 4 ? 2 * c : (c >= 12 ? 2 * (c - 8) : 2 * (
 // PERM: the accumulator columns are dealt by perm16 (the patch is written in pixel order either way)
 template <typename T, int WP, int WC, int TP, int TC, bool PERM = false>
 Y2_DEV void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[2 * TC][2 * TP], char* smem, int w, int lane, int m0,
-                            int n0, int pt, int ct) {
+                            int n0, int pt, int ct, int cstride = TC * 32, int coff = 0) {
     typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
     constexpr int SZ = Cfg::SZ, EROW = Cfg::EROW;
     const int wc = w % WC;
     const int r16 = PERM ? perm16(lane & 15) : (lane & 15), g4 = lane >> 4;
     char* ew = smem + w * Cfg::EPW;
-    const int cw0 = n0 + wc * TC * 32;
+    const int cw0 = n0 + wc * cstride + coff;
 #pragma unroll
     for (int i = 0; i < 2 * TC; ++i) {
         const int cl = i * 16 + 4 * g4;
@@ -97,16 +100,17 @@ Y2_DEV void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[2 * TC][2 * TP], cha
             else *(u32x4*)dst = *(const u32x4*)o;
         }
     }
-    conv_epilogue_finish<T, WP, WC, TP, TC, 0>(a, smem, w, lane, m0, n0, pt, ct);
+    conv_epilogue_finish<T, WP, WC, TP, TC, 0>(a, smem, w, lane, m0, n0, pt, ct, cstride, coff);
 }
 
 template <typename T, int WP, int WC, int TP, int TC, int EABL>
-Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane, int m0, int n0, int pt, int ct) {
+Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane, int m0, int n0, int pt, int ct,
+                                 int cstride, int coff) {
     typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BP = Cfg::BP, EROW = Cfg::EROW;
     const int wp = w / WC, wc = w % WC;
     char* ew = smem + w * Cfg::EPW;
-    const int cw0 = n0 + wc * TC * 32;  // first cout of this wave
+    const int cw0 = n0 + wc * cstride + coff;  // first cout of this wave
     if (EABL & 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     else __syncthreads();
 
@@ -285,7 +289,7 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
                     S1 += (double)q[cl];
                     S2 += (double)q[TC * 32 + cl];
                 }
-                const int co = n0 + c;
+                const int co = n0 + wcs * cstride + coff + cl;
                 if (co < a.ldy) {
                     const double md = S1 / (double)BP;
                     const double m2 = S2 - S1 * md;
@@ -323,7 +327,7 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
                     S2 += q[64 * EPC + g * CPR * EPC + idx];
                 }
             }
-            const int co = n0 + c;
+            const int co = n0 + wcs * cstride + coff + cl;
             if (co < a.ldy) {
                 if (bw) {
                     a.bw_psum[((size_t)pt * 2 + 0) * a.ldy + co] = S1;

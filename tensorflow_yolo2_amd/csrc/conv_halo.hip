@@ -364,20 +364,23 @@ int haloq_tile_choice(int W, int row_bytes, int Cout, int M, int elem_size) {
     const int wsmall = no52 ? 26 : 52;
     if (!(W <= wsmall && Cout > 64 && M >= 384 * 8 && (row_bytes % 128) == 0)) return HQ_NONE;
     const bool narrow = ((M + 383) / 384) * ((Cout + 127) / 128) < 160;
-    // the f32 epilogue patch of a 384 x 128 (and 512 x 128) tile does not fit LDS: 256 x 128 on 16x16 tiles there
+    // the f32 epilogue patch of a 384 x 128 (and 512 x 128) tile does not fit LDS: 256 x 128 on 16x16 tiles there.
+    // elem_size 6 = the split-operand mode (fp32 output, but its 16x16-tile kernel runs the epilogue in two passes over
+    // halves of the wave's couts -- conv_haloq.hip EPI2 -- so the 384 x 128 tile is available; the 512 x 128 one is not)
+    const bool split = elem_size == 6;
     const int legacy = narrow ? HQ_384x64 : (elem_size == 4 ? HQ_256x128_M16 : HQ_384x128_M16);
     if (legacy_only) return legacy;
-    struct Cand { int id, bp, bc; double eff; bool f32_ok; };
-    static const Cand cand[] = {{HQ_384x128_M16, 384, 128, 1.00, false}, {HQ_256x128_M16, 256, 128, 0.95, true},
-                                {HQ_384x64, 384, 64, 0.80, true},        {HQ_512x128, 512, 128, 1.02, false},
-                                {HQ_256x128, 256, 128, 0.92, true},      {HQ_512x64, 512, 64, 0.90, true},
-                                {HQ_256x64, 256, 64, 0.74, true}};
+    struct Cand { int id, bp, bc; double eff; bool f32_ok, split_ok; };
+    static const Cand cand[] = {{HQ_384x128_M16, 384, 128, 1.00, false, true}, {HQ_256x128_M16, 256, 128, 0.95, true, true},
+                                {HQ_384x64, 384, 64, 0.80, true, true},        {HQ_512x128, 512, 128, 1.02, false, false},
+                                {HQ_256x128, 256, 128, 0.92, true, true},      {HQ_512x64, 512, 64, 0.90, true, true},
+                                {HQ_256x64, 256, 64, 0.74, true, true}};
     double lc = 0.0, bc = 0.0;
     int best = legacy;
     for (const Cand& c : cand)
         if (c.id == legacy) lc = bc = hq_cost(M, Cout, c.bp, c.bc, c.eff);
     for (const Cand& c : cand) {
-        if (elem_size == 4 ? !c.f32_ok : c.id == HQ_256x128_M16) continue;
+        if (split ? !c.split_ok : (elem_size == 4 ? !c.f32_ok : c.id == HQ_256x128_M16)) continue;
         const double v = hq_cost(M, Cout, c.bp, c.bc, c.eff);
         if (v < bc) { bc = v; best = c.id; }
     }
@@ -406,7 +409,7 @@ int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgra
     static const bool no52 = getenv("Y2_NO_HALOQ_52") != nullptr;
     const int wsmall = no52 ? 26 : 52;
     if (!(W <= wsmall || (W > 52 && W <= 104) || (W > 104 && Cout <= 32))) return 0;
-    const int tile = haloq_tile_choice(W, row_bytes, Cout, M, elem_size);
+    const int tile = haloq_tile_choice(W, row_bytes, Cout, M, split ? 6 : elem_size);
     return (tile == HQ_384x128_M16 || tile == HQ_256x128_M16) ? 2 : 1;
 }
 

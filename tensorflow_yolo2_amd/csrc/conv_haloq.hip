@@ -631,7 +631,23 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
 #pragma unroll
             for (int j = 0; j < TP16; ++j) acc[i][j] *= kSplitWScaleInv;
     }
-    conv_epilogue16<YT, WP, WC, TP, TC, CPT>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    // The fp32 patch of a 384 x 128 tile (8 waves x 96 pixels x 64 couts x 4 B) does not fit LDS: the split-operand mode runs
+    // the epilogue in TWO passes over halves of every wave's couts (the f32 mode takes 256 x 128 tiles instead)
+    constexpr bool EPI2 = SPLIT && (TC % 2 == 0) && EpiCfg<YT, WP, WC, TP, TC>::LDS > 160 * 1024;
+    if constexpr (EPI2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 acch[TC16 / 2][TP16];
+#pragma unroll
+            for (int i = 0; i < TC16 / 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TP16; ++j) acch[i][j] = acc[h * (TC16 / 2) + i][j];
+            if (h) __syncthreads();      // pass 0's patch and the statistics scratch that aliases it are dead
+            conv_epilogue16<YT, WP, WC, TP, TC / 2, CPT>(a, acch, smem, w, lane, m0, n0, pt, ct, TC * 32, h * (TC / 2) * 32);
+        }
+    } else {
+        conv_epilogue16<YT, WP, WC, TP, TC, CPT>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    }
 }
 
 // compact image: pixels [m0 - W - 1, m0 + BP + W], rounded up to whole 16-row groups
@@ -655,7 +671,9 @@ static size_t haloq_lds(int arows, bool adb, bool cpt) {
 }
 template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool M16, bool CPT, int TAPS = 9>
 static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
-    typedef EpiCfg<typename Types<T>::out_t, WP, WC, TP, TC> Epi;
+    typedef typename Types<T>::out_t YT_;
+    constexpr bool EPI2 = Types<T>::kSplit && M16 && (TC % 2 == 0) && EpiCfg<YT_, WP, WC, TP, TC>::LDS > 160 * 1024;
+    typedef EpiCfg<YT_, WP, WC, TP, EPI2 ? TC / 2 : TC> Epi;     // (EPI2: the epilogue runs in two passes, conv_haloq16_kernel)
     constexpr int BP = WP * TP * 32, BC = WC * TC * 32, RPI = 64 / (BKB / 16);
     if ((a.C * (int)sizeof(typename Types<T>::op_t)) % BKB != 0) return hipErrorInvalidValue;
     const int arows = CPT ? haloq_rows_compact(a.W, BP, TAPS) : haloq_rows(a.H, a.W, BP, RPI);
@@ -803,14 +821,14 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
     }
     if (a.Cout > 64) {
         hipError_t e = hipErrorOutOfMemory;
-        const int tile = haloq_tile_choice(a.W, kb, a.Cout, a.M, (int)sizeof(YT));
+        const int tile = haloq_tile_choice(a.W, kb, a.Cout, a.M, Types<T>::kSplit ? 6 : (int)sizeof(YT));
         if (tile != HQ_NONE) {
             // the tile (and with it the filter pack: 16-row fragments for the _M16 kernels, 32-row ones otherwise) is
             // decided by ONE function for bind and launch time (conv_halo.hip haloq_tile_choice).  (Round 2 fell through
             // to a 32x32-tile kernel on the 16-row pack in the f32 mode -- wrong outputs from batch 24 up at 416x416.)
             switch (tile) {
                 case HQ_384x128_M16:
-                    if constexpr (sizeof(YT) == 2) { *bp = 384; return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s); }
+                    if constexpr (sizeof(YT) == 2 || Types<T>::kSplit) { *bp = 384; return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s); }
                     return hipErrorInvalidValue;
                 case HQ_256x128_M16: *bp = 256; return haloq_pick<T, 4, 2, 2, 2, 128, true>(a, s);
                 case HQ_384x64: *bp = 384; return haloq_pick<T, 4, 2, 3, 1, 128>(a, s);

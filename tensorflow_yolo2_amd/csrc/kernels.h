@@ -294,6 +294,7 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);       // 
 hipError_t launch_wgrad9(int dtype, const WgradArgs& a, hipStream_t s);      // 3x3: nine taps per block
 hipError_t launch_wgrad_auto(int dtype, const WgradArgs& a, hipStream_t s);
 // around a split-K launch (a.splitk resolved): chooses slab or atomics (zero-filling dW for the latter) / sums the slab
+int wgrad_finish_max_parts();      // Y2_WGRAD_FINISH (0 = the in-kernel sum is off: the default)
 hipError_t wgrad_split_prepare(WgradArgs& a, hipStream_t s);
 hipError_t wgrad_split_finish(const WgradArgs& a, hipStream_t s);
 

@@ -18,6 +18,14 @@
 #include "conv_epilogue.h"
 #include "kernels.h"
 #include "wgrad_finish.h"
+// The in-kernel split-K sum (wgrad_finish.h) measured slower in every form (profiles/r05_ab_wgrad_finish.txt) and its mere
+// presence cost the weight gradients 1.8 % (2.53 vs 2.49 ms per step, same box): it is compiled into the DEVELOPMENT
+// library only (make dev, Y2_WGRAD_FINISH=<max partials>); the product kernels store their partials plainly.
+#ifdef Y2_DEVBUILD
+#define Y2_FIN_STORE(p, v) do { if (a.cnt_stride) slab_store((p), (v)); else *(p) = (v); } while (0)
+#else
+#define Y2_FIN_STORE(p, v) (*(p) = (v))
+#endif
 
 namespace y2 {
 
@@ -193,12 +201,13 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
                 if (ci < a.Cin && co < a.Cout) {
                     const size_t o = ((size_t)tap * a.Cin + ci) * a.Cout + co;
                     if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[i][j][q] * a.scale;
-                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * a.taps * a.Cin * a.Cout + o; if (a.cnt_stride) slab_store(sp, acc[i][j][q]); else *sp = acc[i][j][q]; }
+                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * a.taps * a.Cin * a.Cout + o; Y2_FIN_STORE(sp, acc[i][j][q]); }
                     else atomicAdd(a.dW + o, acc[i][j][q] * a.scale);
                 }
             }
         }
-    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h)
+#ifdef Y2_DEVBUILD
+    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h; development library only)
         const size_t nn = (size_t)a.taps * a.Cin * a.Cout;
         splitk_finish(s_fin, a.tile_cnt + (size_t)((tap * nIT + it) * nOT + ot) * a.cnt_stride, a.part0 + split, a.splitk * a.quads,
                       [&](int first, int stride, int count, bool final) __attribute__((always_inline)) {
@@ -220,12 +229,16 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
                 }
         });
     }
+#endif
 }
 
 template <typename T, int WI, int WO, int TI, int TO, int NS = 2>
 static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     typedef WgCfg<T, WI, WO, TI, TO, NS> Cfg;
     static_assert(Cfg::LDS + 16 <= 160 * 1024, "LDS");
+    // (the finish flag of the opt-in in-kernel sum sits behind the staging buffers: 16 more bytes only when it is on --
+    //  a request of exactly 1/2 or 1/3 of the CU's LDS must stay that)
+    const int fin16 = wgrad_finish_max_parts() > 0 ? 16 : 0;
     auto kern = wgrad_kernel<T, WI, WO, TI, TO, NS>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -250,7 +263,7 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     }
     hipError_t e = wgrad_split_prepare(a, s);
     if (e != hipSuccess) return e;
-    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS + 16, s, a);
+    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS + fin16, s, a);
     return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 
@@ -306,6 +319,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (sl == 0 && i < n4) ((f32x4*)dW)[i] = t * scale;
 }
 
+int wgrad_finish_max_parts() {
+#ifdef Y2_DEVBUILD
+    static const int v = getenv("Y2_WGRAD_FINISH") ? atoi(getenv("Y2_WGRAD_FINISH")) : 0;
+    return v;
+#else
+    return 0;      // the in-kernel sum exists in the development library only (see the top of this file)
+#endif
+}
 hipError_t wgrad_split_prepare(WgradArgs& a, hipStream_t s) {
     a.cnt_stride = 0;
     if (a.splitk * a.quads <= 1) return hipSuccess;
@@ -317,8 +338,7 @@ hipError_t wgrad_split_prepare(WgradArgs& a, hipStream_t s) {
     // sc1 atomics instead of fences 9.71 ms (the ONE block that completes a group of 16 partials of a 64-KB tile reads
     // 1 MB through 4-byte sc1 loads, a few in flight per lane: a serial tail per tile where the separate kernel spreads
     // the same reads over the whole chip in 6 us)
-    static const int finish_max = getenv("Y2_WGRAD_FINISH") ? atoi(getenv("Y2_WGRAD_FINISH")) : 0;
-    const bool sum_kernel = a.splitk * a.quads > finish_max;
+    const bool sum_kernel = a.splitk * a.quads > wgrad_finish_max_parts();
     if (!no_slab && a.slab && (n & 3) == 0 && (size_t)a.splitk * a.quads * n <= a.slab_floats) {
         // in-kernel sum (wgrad_finish.h) where the caller lent counters: one set per dW tile.  The tile count is bounded by
         // the smallest tiles any kernel form uses (32 x 32 per tap)

@@ -14,6 +14,14 @@
 #include "conv_epilogue.h"
 #include "kernels.h"
 #include "wgrad_finish.h"
+// The in-kernel split-K sum (wgrad_finish.h) measured slower in every form (profiles/r05_ab_wgrad_finish.txt) and its mere
+// presence cost the weight gradients 1.8 % (2.53 vs 2.49 ms per step, same box): it is compiled into the DEVELOPMENT
+// library only (make dev, Y2_WGRAD_FINISH=<max partials>); the product kernels store their partials plainly.
+#ifdef Y2_DEVBUILD
+#define Y2_FIN_STORE(p, v) do { if (a.cnt_stride) slab_store((p), (v)); else *(p) = (v); } while (0)
+#else
+#define Y2_FIN_STORE(p, v) (*(p) = (v))
+#endif
 
 namespace y2 {
 
@@ -217,12 +225,13 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
                 if (ci < a.Cin) {
                     const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
                     if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[t][j][q] * a.scale;
-                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * 9 * a.Cin * a.Cout + o; if (a.cnt_stride) slab_store(sp, acc[t][j][q]); else *sp = acc[t][j][q]; }
+                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * 9 * a.Cin * a.Cout + o; Y2_FIN_STORE(sp, acc[t][j][q]); }
                     else atomicAdd(a.dW + o, acc[t][j][q] * a.scale);
                 }
             }
     }
-    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h)
+#ifdef Y2_DEVBUILD
+    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h; development library only)
         const size_t n9 = (size_t)9 * a.Cin * a.Cout;
         splitk_finish(s_fin, a.tile_cnt + (size_t)(it * nOT + ot) * a.cnt_stride, a.part0 + split, a.splitk * a.quads,
                       [&](int first, int stride, int count, bool final) __attribute__((always_inline)) {
@@ -245,6 +254,7 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
             }
         });
     }
+#endif
 }
 
 template <typename T, int WI, int WO, int NS, int TG, int KS = 1, int CW = 1>
@@ -418,12 +428,13 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin
                 if (ci < a.Cin) {
                     const size_t o = ((size_t)(T0 + t) * a.Cin + ci) * a.Cout + co;
                     if (a.splitk == 1 && a.quads == 1) a.dW[o] = acc[t][q] * a.scale;
-                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * 9 * a.Cin * a.Cout + o; if (a.cnt_stride) slab_store(sp, acc[t][q]); else *sp = acc[t][q]; }
+                    else if (a.slab) { float* sp = a.slab + (size_t)(a.part0 + split) * 9 * a.Cin * a.Cout + o; Y2_FIN_STORE(sp, acc[t][q]); }
                     else atomicAdd(a.dW + o, acc[t][q] * a.scale);
                 }
             }
     }
-    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h)
+#ifdef Y2_DEVBUILD
+    if (a.slab && a.cnt_stride) {     // the split-K sum rides in this kernel (wgrad_finish.h; development library only)
         const size_t n9 = (size_t)9 * a.Cin * a.Cout;
         splitk_finish(s_fin, a.tile_cnt + (size_t)(it * nOT + ot) * a.cnt_stride, a.part0 + split, a.splitk * a.quads,
                       [&](int first, int stride, int count, bool final) __attribute__((always_inline)) {
@@ -442,6 +453,7 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin
                 }
         });
     }
+#endif
 }
 
 template <typename T, int WI, int WO, int TG, int KS = 1>
@@ -469,9 +481,12 @@ static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0)
     const int G = (wrows + Cfg::BKP - 1) / Cfg::BKP;
     int lgR = 7;
     while ((1 << lgR) < Cfg::BKP * (G + 1)) ++lgR;
-    const size_t lds = ((size_t)Cfg::ROWX << lgR) + 2 * (size_t)Cfg::YS + 16;     // + the finish flag (wgrad_finish.h)
+    // (+ 16 bytes for the finish flag of the opt-in in-kernel sum, wgrad_finish.h, only when it is on: a request of
+    //  exactly 1/2 or 1/3 of the CU's LDS must stay that -- the blocks-per-CU count below depends on it)
+    const size_t fin16 = wgrad_finish_max_parts() > 0 ? 16 : 0;
+    const size_t lds = ((size_t)Cfg::ROWX << lgR) + 2 * (size_t)Cfg::YS + fin16;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    a.fin_lds_off = (int)lds - 16;
+    a.fin_lds_off = (int)(lds - fin16);
     auto kern = wgrad9r_kernel<T, WI, WO, TG, KS>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
@@ -511,9 +526,10 @@ static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s, int blocks_target = 
     // stages drain to zero and take whole pieces only
     const int gran = NS > 2 ? Cfg::RPIX * Cfg::NW : Cfg::RPIX;
     wrows = (wrows + gran - 1) / gran * gran;
-    size_t lds = NS * ((size_t)wrows * Cfg::ROWX + Cfg::YS) + 16;     // + the finish flag (wgrad_finish.h)
+    const size_t fin16 = wgrad_finish_max_parts() > 0 ? 16 : 0;     // the finish flag (wgrad_finish.h), when that form is on
+    size_t lds = NS * ((size_t)wrows * Cfg::ROWX + Cfg::YS) + fin16;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
-    a.fin_lds_off = (int)lds - 16;
+    a.fin_lds_off = (int)(lds - fin16);
     auto kern = wgrad9_kernel<T, WI, WO, NS, TG, KS, CW>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
