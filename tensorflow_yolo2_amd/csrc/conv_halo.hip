@@ -367,8 +367,10 @@ int haloq_tile_choice(int W, int row_bytes, int Cout, int M, int elem_size) {
     // the f32 epilogue patch of a 384 x 128 (and 512 x 128) tile does not fit LDS: 256 x 128 on 16x16 tiles there.
     // elem_size 6 = the split-operand mode (fp32 output, but its 16x16-tile kernel runs the epilogue in two passes over
     // halves of the wave's couts -- conv_haloq.hip EPI2 -- so the 384 x 128 tile is available; the 512 x 128 one is not)
-    const bool split = elem_size == 6;
-    const int legacy = narrow ? HQ_384x64 : (elem_size == 4 ? HQ_256x128_M16 : HQ_384x128_M16);
+    // (round 5, later: the exact-f32 mode takes the two-pass epilogue too -- Y2_F32_TILE_256=1 restores its 256 x 128 tiles)
+    static const bool f32_256 = getenv("Y2_F32_TILE_256") != nullptr;
+    const bool split = elem_size == 6 || (elem_size == 4 && !f32_256);
+    const int legacy = narrow ? HQ_384x64 : ((elem_size == 4 && f32_256) ? HQ_256x128_M16 : HQ_384x128_M16);
     if (legacy_only) return legacy;
     struct Cand { int id, bp, bc; double eff; bool f32_ok, split_ok; };
     static const Cand cand[] = {{HQ_384x128_M16, 384, 128, 1.00, false, true}, {HQ_256x128_M16, 256, 128, 0.95, true, true},

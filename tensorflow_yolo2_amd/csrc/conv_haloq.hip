@@ -631,9 +631,9 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
 #pragma unroll
             for (int j = 0; j < TP16; ++j) acc[i][j] *= kSplitWScaleInv;
     }
-    // The fp32 patch of a 384 x 128 tile (8 waves x 96 pixels x 64 couts x 4 B) does not fit LDS: the split-operand mode runs
-    // the epilogue in TWO passes over halves of every wave's couts (the f32 mode takes 256 x 128 tiles instead)
-    constexpr bool EPI2 = SPLIT && (TC % 2 == 0) && EpiCfg<YT, WP, WC, TP, TC>::LDS > 160 * 1024;
+    // The fp32 patch of a 384 x 128 tile (8 waves x 96 pixels x 64 couts x 4 B) does not fit LDS: the modes with fp32 outputs
+    // (split operands, exact f32) run the epilogue in TWO passes over halves of every wave's couts
+    constexpr bool EPI2 = sizeof(YT) == 4 && (TC % 2 == 0) && EpiCfg<YT, WP, WC, TP, TC>::LDS > 160 * 1024;
     if constexpr (EPI2) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -672,7 +672,7 @@ static size_t haloq_lds(int arows, bool adb, bool cpt) {
 template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool M16, bool CPT, int TAPS = 9>
 static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
     typedef typename Types<T>::out_t YT_;
-    constexpr bool EPI2 = Types<T>::kSplit && M16 && (TC % 2 == 0) && EpiCfg<YT_, WP, WC, TP, TC>::LDS > 160 * 1024;
+    constexpr bool EPI2 = sizeof(YT_) == 4 && M16 && (TC % 2 == 0) && EpiCfg<YT_, WP, WC, TP, TC>::LDS > 160 * 1024;
     typedef EpiCfg<YT_, WP, WC, TP, EPI2 ? TC / 2 : TC> Epi;     // (EPI2: the epilogue runs in two passes, conv_haloq16_kernel)
     constexpr int BP = WP * TP * 32, BC = WC * TC * 32, RPI = 64 / (BKB / 16);
     if ((a.C * (int)sizeof(typename Types<T>::op_t)) % BKB != 0) return hipErrorInvalidValue;
@@ -828,8 +828,8 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
             // to a 32x32-tile kernel on the 16-row pack in the f32 mode -- wrong outputs from batch 24 up at 416x416.)
             switch (tile) {
                 case HQ_384x128_M16:
-                    if constexpr (sizeof(YT) == 2 || Types<T>::kSplit) { *bp = 384; return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s); }
-                    return hipErrorInvalidValue;
+                    *bp = 384;       // (fp32 outputs: the epilogue runs in two passes, conv_haloq16_kernel EPI2)
+                    return haloq_pick<T, 4, 2, 3, 2, 128, true>(a, s);
                 case HQ_256x128_M16: *bp = 256; return haloq_pick<T, 4, 2, 2, 2, 128, true>(a, s);
                 case HQ_384x64: *bp = 384; return haloq_pick<T, 4, 2, 3, 1, 128>(a, s);
                 case HQ_512x128:
