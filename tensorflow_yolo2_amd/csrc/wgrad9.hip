@@ -56,11 +56,18 @@ Y2_DEV int wg9_swz(int row) {
 
 // NS LDS stages; NS-1 K steps of LDS-DMA stay in flight across the raw barrier (counted vmcnt):
 // with one wave per SIMD (as many waves as the dW tiling yields) this is what hides HBM latency.
-template <typename T, int WI, int WO, int NS, int TG, int T0, int NTAP, int KS = 1, int CW = 1>
+// PL2 (f16x2 mode, round 5): x and dy are SPLIT tensors -- a cell is [C halves hi][C halves lo] -- and the block forms all
+// three plane products itself: both planes of the X window and of the dY tile are staged per K step (2x the LDS of the
+// one-plane form) and every fragment pair feeds three MFMAs, hi hi + lo hi + hi lo, into ONE accumulator.  Against
+// three launches on plane pairs (WgradArgs::quads, the first form of the mode): 2/3 of the staging and of the LDS
+// fragment reads per MFMA, one partial tile per split instead of three.
+template <typename T, int WI, int WO, int NS, int TG, int T0, int NTAP, int KS = 1, int CW = 1, bool PL2 = false>
 Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
     typedef Wg9Cfg<T, WI, WO, TG, KS, CW> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
+    constexpr int NPL = PL2 ? 2 : 1;
+    static_assert(!PL2 || SZ == 2, "two planes: 16-bit operands");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = w % (WI * WO);
@@ -84,9 +91,10 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
     if (s_end > ksteps) s_end = ksteps;
     const int nsteps = (int)(s_end > s_begin ? s_end - s_begin : 0);
 
-    const int xs_bytes = wrows * ROWX;              // one X window
-    const int stage_bytes = xs_bytes + Cfg::YS;
+    const int xs_bytes = wrows * ROWX;              // one X window (of one plane)
+    const int stage_bytes = NPL * (xs_bytes + Cfg::YS);      // [X hi][X lo][dY hi][dY lo]
     const int xpieces = wrows / Cfg::RPIX;
+    const int xplaneB = a.Cin * SZ, yplaneB = a.Cdy * SZ;    // PL2: byte distance of the lo plane inside a cell
     const long kb = s_begin * BKP;
     // window of step s starts at bordered position kb + s*BKP - pitch - 1 (top-left tap)
     const char* xg = (const char*)a.x + ((kb - pitch - 1) * a.xpitch + ci0) * SZ;
@@ -105,15 +113,19 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
         const char* xs = xg + (long)st * xstep;
         const char* ys = yg + (long)st * ystep;
         char* lb = smem + buf * stage_bytes;
-        for (int i = w; i < xpieces; i += NW) {
-            const int row = i * Cfg::RPIX + lrx;
-            const uint32_t off = (uint32_t)row * (uint32_t)(a.xpitch * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
-            glds16(xs + off, lb + i * 1024);
-        }
 #pragma unroll
-        for (int i = 0; i < Cfg::IPWY; ++i) {
-            const int ii = i * NW + w;
-            if ((i + 1) * NW <= Cfg::NIY || ii < Cfg::NIY) glds16(ys + voffy[i], lb + xs_bytes + ii * 1024);
+        for (int pl = 0; pl < NPL; ++pl) {
+            for (int i = w; i < xpieces; i += NW) {
+                const int row = i * Cfg::RPIX + lrx;
+                const uint32_t off = (uint32_t)row * (uint32_t)(a.xpitch * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
+                glds16(xs + pl * xplaneB + off, lb + pl * xs_bytes + i * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < Cfg::IPWY; ++i) {
+                const int ii = i * NW + w;
+                if ((i + 1) * NW <= Cfg::NIY || ii < Cfg::NIY)
+                    glds16(ys + pl * yplaneB + voffy[i], lb + NPL * xs_bytes + pl * Cfg::YS + ii * 1024);
+            }
         }
     };
 
@@ -132,7 +144,7 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
     for (int t = 0; t < NTAP; ++t) shift[t] = ((T0 + t) / 3) * pitch + ((T0 + t) % 3);
 
     // loads per wave per stage (the launcher makes the X window a multiple of RPIX*NW rows)
-    const int lps = xpieces / NW + Cfg::NIY / NW;
+    const int lps = NPL * (xpieces / NW + Cfg::NIY / NW);
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nsteps) stage(s0, s0);
@@ -147,7 +159,7 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
         cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
         ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
         const char* xs = smem + buf * stage_bytes;
-        const char* ys = xs + xs_bytes;
+        const char* ys = xs + NPL * xs_bytes;
         if constexpr (SZ == 2) {
             // dY fragment address (no tap shift): rows kg*16 + 8*hh + qq (+4)
             const int fy = wg9_swz<ROWY, SZ>(qq);
@@ -167,34 +179,43 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
             // while the nine MFMAs of group kg issue (one wave per SIMD: nothing else hides the
             // ~100-cycle LDS latency; the compiler's own schedule keeps only one fragment ahead).
             typedef typename Elem<T>::frag frag_t;
-            frag_t fa0[NTAP], fa1[NTAP], fb0[CW], fb1[CW];
-            auto load_group = [&](int kg, frag_t (&fa)[NTAP], frag_t (&fb)[CW]) {
+            frag_t fa0[NPL][NTAP], fa1[NPL][NTAP], fb0[NPL][CW], fb1[NPL][CW];
+            auto load_group = [&](int kg, frag_t (&fa)[NPL][NTAP], frag_t (&fb)[NPL][CW]) {
 #pragma unroll
-                for (int j = 0; j < CW; ++j) {
-                    const char* py = pyb[j] + kg * 16 * ROWY;
-                    fb[j] = tr_frag<T>(py, py + 4 * ROWY);
-                }
+                for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-                for (int t = 0; t < NTAP; ++t) {
-                    const char* px = pxb[t] + kg * 16 * ROWX;
-                    fa[t] = tr_frag<T>(px, px + 4 * ROWX);
+                    for (int j = 0; j < CW; ++j) {
+                        const char* py = pyb[j] + pl * Cfg::YS + kg * 16 * ROWY;
+                        fb[pl][j] = tr_frag<T>(py, py + 4 * ROWY);
+                    }
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) {
+                        const char* px = pxb[t] + pl * xs_bytes + kg * 16 * ROWX;
+                        fa[pl][t] = tr_frag<T>(px, px + 4 * ROWX);
+                    }
                 }
+            };
+            auto mma_group = [&](frag_t (&fa)[NPL][NTAP], frag_t (&fb)[NPL][CW]) {
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                    for (int j = 0; j < CW; ++j) {
+                        mma32(acc[t][j], fa[0][t], fb[0][j]);
+                        if constexpr (PL2) {
+                            mma32(acc[t][j], fa[1][t], fb[0][j]);      // x lo * dy hi
+                            mma32(acc[t][j], fa[0][t], fb[1][j]);      // x hi * dy lo
+                        }
+                    }
             };
             load_group(0, fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kg = 0; kg < BKP / 16; kg += 2) {
                 load_group(kg + 1, fa1, fb1);
-#pragma unroll
-                for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-                    for (int j = 0; j < CW; ++j) mma32(acc[t][j], fa0[t], fb0[j]);
+                mma_group(fa0, fb0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (kg + 2 < BKP / 16) load_group(kg + 2, fa0, fb0);
-#pragma unroll
-                for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-                    for (int j = 0; j < CW; ++j) mma32(acc[t][j], fa1[t], fb1[j]);
+                mma_group(fa1, fb1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -257,16 +278,16 @@ Y2_DEV void wg9_body(const WgradArgs& a, int wrows, char* smem, int* s_fin) {
 #endif
 }
 
-template <typename T, int WI, int WO, int NS, int TG, int KS = 1, int CW = 1>
+template <typename T, int WI, int WO, int NS, int TG, int KS = 1, int CW = 1, bool PL2 = false>
 __global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9_kernel(WgradArgs a, int wrows) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* const s_fin = (int*)(smem + a.fin_lds_off);
     if constexpr (TG == 1) {
-        wg9_body<T, WI, WO, NS, 1, 0, 9, KS, CW>(a, wrows, smem, s_fin);
+        wg9_body<T, WI, WO, NS, 1, 0, 9, KS, CW, PL2>(a, wrows, smem, s_fin);
     } else {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (w < WI * WO) wg9_body<T, WI, WO, NS, 2, 0, 5, KS, CW>(a, wrows, smem, s_fin);   // same barrier count in both arms
-        else wg9_body<T, WI, WO, NS, 2, 5, 4, KS, CW>(a, wrows, smem, s_fin);
+        if (w < WI * WO) wg9_body<T, WI, WO, NS, 2, 0, 5, KS, CW, PL2>(a, wrows, smem, s_fin);   // same barrier count in both arms
+        else wg9_body<T, WI, WO, NS, 2, 5, 4, KS, CW, PL2>(a, wrows, smem, s_fin);
     }
 }
 
@@ -290,11 +311,12 @@ Y2_DEV typename Elem<T>::frag tr_frag_off(uint32_t o0, uint32_t o1) {
     return __builtin_bit_cast(typename Elem<T>::frag, both);
 }
 
-template <typename T, int WI, int WO, int TG, int T0, int NTAP, int KS = 1>
+template <typename T, int WI, int WO, int TG, int T0, int NTAP, int KS = 1, bool PL2 = false>
 Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin) {
     typedef Wg9Cfg<T, WI, WO, TG, KS> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
+    constexpr int NPL = PL2 ? 2 : 1;          // PL2: both operand planes of the split-operand mode (see wg9_body)
     static_assert(SZ == 2, "ring form: 16-bit elements");
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -327,7 +349,8 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin
     const char* xg = (const char*)a.x + ((kb - pitch - 1) * a.xpitch + ci0) * SZ;   // window row 0 of step 0
     const char* yg = (const char*)a.dy + (kb * a.ypitch + co0) * SZ;
     const long xstep = (long)BKP * a.xpitch * SZ, ystep = (long)BKP * a.ypitch * SZ;
-    char* const ybase = smem + ringB;
+    char* const ybase = smem + NPL * ringB;      // [ring hi][ring lo][dY: buffer x plane]
+    const int xplaneB = a.Cin * SZ, yplaneB = a.Cdy * SZ;
 
     const int lrx = lane / Cfg::LPRX, lsx = lane % Cfg::LPRX;
     uint32_t voffy[Cfg::IPWY];
@@ -340,20 +363,24 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin
     auto stage_x = [&](int g) {   // BKP rows: BKP / RPIX pieces of 1 KiB (aligned: a piece never wraps)
         const char* xs = xg + (long)g * xstep;
         char* dst = smem + (((uint32_t)g * (uint32_t)BKP * ROWX) & maskB);
-        for (int i = w; i < BKP / Cfg::RPIX; i += NW) {
-            const int row = i * Cfg::RPIX + lrx;   // row & 3 == LDS row & 3 (groups are 64-row aligned)
-            const uint32_t off = (uint32_t)row * (uint32_t)(a.xpitch * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
-            glds16(xs + off, dst + i * 1024);
-        }
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+            for (int i = w; i < BKP / Cfg::RPIX; i += NW) {
+                const int row = i * Cfg::RPIX + lrx;   // row & 3 == LDS row & 3 (groups are 64-row aligned)
+                const uint32_t off = (uint32_t)row * (uint32_t)(a.xpitch * SZ) + ((lsx ^ wg9_swz<ROWX, SZ>(row)) * 16);
+                glds16(xs + pl * xplaneB + off, dst + pl * ringB + i * 1024);
+            }
     };
     auto stage_y = [&](int st, int buf) {
         const char* ys = yg + (long)st * ystep;
-        char* lb = ybase + buf * Cfg::YS;
+        char* lb = ybase + buf * NPL * Cfg::YS;
 #pragma unroll
-        for (int i = 0; i < Cfg::IPWY; ++i) {
-            const int ii = i * NW + w;
-            if ((i + 1) * NW <= Cfg::NIY || ii < Cfg::NIY) glds16(ys + voffy[i], lb + ii * 1024);
-        }
+        for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+            for (int i = 0; i < Cfg::IPWY; ++i) {
+                const int ii = i * NW + w;
+                if ((i + 1) * NW <= Cfg::NIY || ii < Cfg::NIY) glds16(ys + pl * yplaneB + voffy[i], lb + pl * Cfg::YS + ii * 1024);
+            }
     };
 
     f32x16 acc[NTAP];
@@ -387,19 +414,33 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin
             stage_x(st + G);
             stage_y(st + 1, (st + 1) & 1);
         }
-        const char* ys = ybase + (st & 1) * Cfg::YS;
+        const char* ys = ybase + (st & 1) * NPL * Cfg::YS;
         const int fy = wg9_swz<ROWY, SZ>(qq);
         const char* pyb = ys + (8 * hh + qq) * ROWY + (((wo * 4 + 2 * g1 + (pp >> 1)) ^ fy) * 16) + (pp & 1) * 8;
         typedef typename Elem<T>::frag frag_t;
-        frag_t fa0[NTAP], fa1[NTAP], fb0, fb1;
-        auto load_group = [&](int kg, frag_t (&fa)[NTAP], frag_t& fb) {
-            const char* py = pyb + kg * 16 * ROWY;
-            fb = tr_frag<T>(py, py + 4 * ROWY);
+        frag_t fa0[NPL][NTAP], fa1[NPL][NTAP], fb0[NPL], fb1[NPL];
+        auto load_group = [&](int kg, frag_t (&fa)[NPL][NTAP], frag_t (&fb)[NPL]) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+                const char* py = pyb + pl * Cfg::YS + kg * 16 * ROWY;
+                fb[pl] = tr_frag<T>(py, py + 4 * ROWY);
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) {
+                    // (the second ring starts ringB further: a multiple of the ring size, so the OR of the column bits holds)
+                    const uint32_t o0 = (((rbB[t] + (uint32_t)(kg * 16 * ROWX)) & maskB) | cb[t]) + (uint32_t)pl * ringB;
+                    const uint32_t o1 = (((rbB[t] + (uint32_t)((kg * 16 + 4) * ROWX)) & maskB) | cb[t]) + (uint32_t)pl * ringB;
+                    fa[pl][t] = tr_frag_off<T>(o0, o1);
+                }
+            }
+        };
+        auto mma_group = [&](frag_t (&fa)[NPL][NTAP], frag_t (&fb)[NPL]) {
 #pragma unroll
             for (int t = 0; t < NTAP; ++t) {
-                const uint32_t o0 = ((rbB[t] + (uint32_t)(kg * 16 * ROWX)) & maskB) | cb[t];
-                const uint32_t o1 = ((rbB[t] + (uint32_t)((kg * 16 + 4) * ROWX)) & maskB) | cb[t];
-                fa[t] = tr_frag_off<T>(o0, o1);
+                mma32(acc[t], fa[0][t], fb[0]);
+                if constexpr (PL2) {
+                    mma32(acc[t], fa[1][t], fb[0]);      // x lo * dy hi
+                    mma32(acc[t], fa[0][t], fb[1]);      // x hi * dy lo
+                }
             }
         };
         load_group(0, fa0, fb0);
@@ -407,12 +448,10 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin
 #pragma unroll
         for (int kg = 0; kg < BKP / 16; kg += 2) {
             load_group(kg + 1, fa1, fb1);
-#pragma unroll
-            for (int t = 0; t < NTAP; ++t) mma32(acc[t], fa0[t], fb0);
+            mma_group(fa0, fb0);
             __builtin_amdgcn_sched_barrier(0);
             if (kg + 2 < BKP / 16) load_group(kg + 2, fa0, fb0);
-#pragma unroll
-            for (int t = 0; t < NTAP; ++t) mma32(acc[t], fa1[t], fb1);
+            mma_group(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -456,23 +495,23 @@ Y2_DEV void wg9r_body(const WgradArgs& a, int lgR, int G, char* smem, int* s_fin
 #endif
 }
 
-template <typename T, int WI, int WO, int TG, int KS = 1>
+template <typename T, int WI, int WO, int TG, int KS = 1, bool PL2 = false>
 __global__ __launch_bounds__(WI* WO* TG * 64) void wgrad9r_kernel(WgradArgs a, int lgR, int G) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* const s_fin = (int*)(smem + a.fin_lds_off);
     if constexpr (TG == 1) {
-        wg9r_body<T, WI, WO, 1, 0, 9, KS>(a, lgR, G, smem, s_fin);
+        wg9r_body<T, WI, WO, 1, 0, 9, KS, PL2>(a, lgR, G, smem, s_fin);
     } else {
         const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        if (w < WI * WO) wg9r_body<T, WI, WO, 2, 0, 5, KS>(a, lgR, G, smem, s_fin);
-        else wg9r_body<T, WI, WO, 2, 5, 4, KS>(a, lgR, G, smem, s_fin);
+        if (w < WI * WO) wg9r_body<T, WI, WO, 2, 0, 5, KS, PL2>(a, lgR, G, smem, s_fin);
+        else wg9r_body<T, WI, WO, 2, 5, 4, KS, PL2>(a, lgR, G, smem, s_fin);
     }
 }
 
 // blocks_target: split-K so that tiles * splitk ~ blocks_target; 0 = one full wave of resident
 // blocks (256 CUs x blocks per CU by LDS, at most 3: measured best on every long-row shape --
 // 1.5 waves of blocks cost 30 % at 104x104)
-template <typename T, int WI, int WO, int TG, int KS = 1>
+template <typename T, int WI, int WO, int TG, int KS = 1, bool PL2 = false>
 static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0) {
     typedef Wg9Cfg<T, WI, WO, TG, KS> Cfg;
     static_assert(Cfg::NIY % Cfg::NW == 0, "dY pieces must split evenly over waves");
@@ -484,10 +523,11 @@ static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0)
     // (+ 16 bytes for the finish flag of the opt-in in-kernel sum, wgrad_finish.h, only when it is on: a request of
     //  exactly 1/2 or 1/3 of the CU's LDS must stay that -- the blocks-per-CU count below depends on it)
     const size_t fin16 = wgrad_finish_max_parts() > 0 ? 16 : 0;
-    const size_t lds = ((size_t)Cfg::ROWX << lgR) + 2 * (size_t)Cfg::YS + fin16;
+    const size_t lds = (PL2 ? 2 : 1) * (((size_t)Cfg::ROWX << lgR) + 2 * (size_t)Cfg::YS) + fin16;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
     a.fin_lds_off = (int)(lds - fin16);
-    auto kern = wgrad9r_kernel<T, WI, WO, TG, KS>;
+    if (PL2) a.quads = 1;       // the three plane products are formed inside the block
+    auto kern = wgrad9r_kernel<T, WI, WO, TG, KS, PL2>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
     const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
@@ -516,7 +556,7 @@ static hipError_t wg9r_launch(WgradArgs a, hipStream_t s, int blocks_target = 0)
     return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 
-template <typename T, int WI, int WO, int NS, int TG = 1, int KS = 1, int CW = 1>
+template <typename T, int WI, int WO, int NS, int TG = 1, int KS = 1, int CW = 1, bool PL2 = false>
 static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s, int blocks_target = 0) {
     typedef Wg9Cfg<T, WI, WO, TG, KS, CW> Cfg;
     static_assert(Cfg::NIY % Cfg::NW == 0, "dY pieces must split evenly over waves");
@@ -527,10 +567,11 @@ static hipError_t wg9_launch_ns(WgradArgs a, hipStream_t s, int blocks_target = 
     const int gran = NS > 2 ? Cfg::RPIX * Cfg::NW : Cfg::RPIX;
     wrows = (wrows + gran - 1) / gran * gran;
     const size_t fin16 = wgrad_finish_max_parts() > 0 ? 16 : 0;     // the finish flag (wgrad_finish.h), when that form is on
-    size_t lds = NS * ((size_t)wrows * Cfg::ROWX + Cfg::YS) + fin16;
+    size_t lds = NS * (PL2 ? 2 : 1) * ((size_t)wrows * Cfg::ROWX + Cfg::YS) + fin16;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
     a.fin_lds_off = (int)(lds - fin16);
-    auto kern = wgrad9_kernel<T, WI, WO, NS, TG, KS, CW>;
+    if (PL2) a.quads = 1;       // the three plane products are formed inside the block
+    auto kern = wgrad9_kernel<T, WI, WO, NS, TG, KS, CW, PL2>;
     const int nIT = (a.Cin + Cfg::BI - 1) / Cfg::BI, nOT = (a.Cout + Cfg::BO - 1) / Cfg::BO;
     const long Mp = (long)bbody_pixels(a.N, a.H, a.W);
     const long ksteps = (Mp + Cfg::BKP - 1) / Cfg::BKP;
@@ -591,6 +632,16 @@ static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
 #endif
         if (a.W >= minw) {
             hipError_t e;
+            // f16x2 mode: both planes in the ring (PL2, see wg9_body), 64-pixel K steps (the two rings of the 128-pixel form
+            // leave no room at 104 / 208)
+            static const bool quads_form_r = getenv("Y2_SPLIT_WGRAD_QUADS") != nullptr;
+            if (a.quads == 3 && !quads_form_r) {
+                if (a.Cin >= 64) e = wg9r_launch<T, 2, 1, 2, 1, true>(a, s);
+                else if (a.Cdy >= 64) e = wg9r_launch<T, 1, 2, 2, 1, true>(a, s);
+                else e = wg9r_launch<T, 1, 1, 2, 1, true>(a, s);
+                if (e != hipErrorOutOfMemory) return e;
+                (void)hipGetLastError();
+            }
             // 64 ci x 32 co tiles with 128-pixel K steps measured best at 52 and 104 (3-7 % over 64-pixel
             // steps); 32-channel inputs (208x208): 32 ci x 64 co tiles, 64-pixel steps
             if (a.Cin >= 64) e = wg9r_launch<T, 2, 1, 2, 2>(a, s);
@@ -606,6 +657,16 @@ static hipError_t wg9_T(const WgradArgs& a, hipStream_t s) {
                 e = lds2 <= 80 * 1024 ? wg9r_launch<T, 1, 2, 2, 2>(a, s) : wg9r_launch<T, 1, 2, 2>(a, s);
             }
             else e = wg9r_launch<T, 1, 1, 2>(a, s);
+            if (e != hipErrorOutOfMemory) return e;
+            (void)hipGetLastError();
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        // f16x2 mode (a.quads == 3): both operand planes staged per K step, the three plane products in one block (PL2) --
+        // 64-pixel K steps so that two blocks still share a CU's LDS.  Y2_SPLIT_WGRAD_QUADS=1: three launches on plane pairs
+        static const bool quads_form = getenv("Y2_SPLIT_WGRAD_QUADS") != nullptr;
+        if (a.quads == 3 && a.Cin >= 64 && !quads_form) {
+            hipError_t e = wg9_launch_ns<T, 2, 1, 2, 2, 1, 1, true>(a, s);
             if (e != hipErrorOutOfMemory) return e;
             (void)hipGetLastError();
         }
