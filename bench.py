@@ -654,8 +654,10 @@ def main():
         # HBM traffic of the same kernels from the committed rocprofv3 PMC passes (separate
         # FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the gfx950 correction), bytes per launch
         try:
-            tpath = [q for q in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
-                     if os.path.exists(os.path.join(ROOT, "profiles", q))][0]
+            # the NEWEST committed counter pass of the headline command (r05 > r04e > r04 > ...)
+            import glob
+            tpath = sorted(os.path.basename(q) for q in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json"))
+                           if "resnet" not in q)[-1]
             tj = json.load(open(os.path.join(ROOT, "profiles", tpath)))
             sel = [v for k, v in tj.items() if "conv_halo" in k or "conv_igemm_kernel" in k or "conv_rf" in k or
                    "wgrad9" in k or "wgrad_kernel" in k]

@@ -253,6 +253,8 @@ static void plan(y2_ctx* c) {
         // round 4, 16-bit types: the linear form keeps NO conv output of the first layer, only 3 index bits per element
         // (kernels.h Conv1PoolArgs::idx3); Y2_CONV1_YSEL=1 (and the f32 parity mode) keep ysel + 2 index bits
         static const bool keep_ysel = getenv("Y2_CONV1_YSEL") != nullptr;
+        // (f16x2: the layer runs the f32 kernels, which are bound by their fp32 matrix instructions -- the 3-bit form was tried
+        //  there and changes nothing: 401 / 1155 us forward / backward either way)
         const bool nosel = lin1 && dtype_plain(c->dtype) != 0 && !keep_ysel;
         y.ysel = (y.pool && (!y.first3 || (lin1 && !nosel))) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
         y.idx0 = lin1 ? take((size_t)c->N * y.Ho * y.Wo * (y.ldy * sz / 16) * (nosel ? sizeof(unsigned) : sizeof(unsigned short)) + 256) : 0;
