@@ -235,14 +235,16 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
 template <typename T, int WI, int WO, int TI, int TO, int NS = 2>
 static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     typedef WgCfg<T, WI, WO, TI, TO, NS> Cfg;
-    static_assert(Cfg::LDS + 16 <= 160 * 1024, "LDS");
+    static_assert(Cfg::LDS <= 160 * 1024, "LDS");
     // (the finish flag of the opt-in in-kernel sum sits behind the staging buffers: 16 more bytes only when it is on --
     //  a request of exactly 1/2 or 1/3 of the CU's LDS must stay that)
-    const int fin16 = wgrad_finish_max_parts() > 0 ? 16 : 0;
+    const int fin16 = (wgrad_finish_max_parts() > 0 && Cfg::LDS + 16 <= 160 * 1024) ? 16 : 0;
+    if (!fin16) a.tile_cnt = nullptr;      // no room (or no wish) for the finish flag: the separate sum kernel
     auto kern = wgrad_kernel<T, WI, WO, TI, TO, NS>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS + 16);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           Cfg::LDS + 16 <= 160 * 1024 ? Cfg::LDS + 16 : Cfg::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
