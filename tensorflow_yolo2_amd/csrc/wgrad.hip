@@ -59,13 +59,15 @@ Y2_DEV int wg_swz(int row) {
     return 0;
 }
 
-template <typename T, int WI, int WO, int TI, int TO, int NS>
+// PL2 (f16x2 mode): both planes of x and dy staged per K step, the three plane products in one block (wgrad9.hip wg9_body)
+template <typename T, int WI, int WO, int TI, int TO, int NS, bool PL2 = false>
 __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
     typedef WgCfg<T, WI, WO, TI, TO, NS> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BI = Cfg::BI, BO = Cfg::BO, BKP = Cfg::BKP;
     constexpr int ROWX = Cfg::ROWX, ROWY = Cfg::ROWY;
+    constexpr int NPL = PL2 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int* const s_fin = (int*)(smem + Cfg::LDS);      // the finish flag sits behind the staging buffers (wgrad_finish.h)
+    int* const s_fin = (int*)(smem + NPL * Cfg::LDS);      // the finish flag sits behind the staging buffers (wgrad_finish.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = w / WO, wo = w % WO;
@@ -111,14 +113,19 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
         const int sl = (lane % Cfg::LPRY) ^ wg_swz<ROWY, SZ>(row);
         voffy[i] = (uint32_t)row * (uint32_t)(a.ypitch * SZ) + sl * 16;
     }
+    const int xplaneB = a.Cin * SZ, yplaneB = a.Cdy * SZ;      // PL2: byte distance of the lo plane inside a cell
     auto stage = [&](int st, int buf) {
         const char* xs = xg + (long)st * xstep;
         const char* ys = yg + (long)st * ystep;
-        char* lb = smem + buf * Cfg::STAGE;
+        char* lb = smem + buf * NPL * Cfg::STAGE;         // [X hi][X lo][dY hi][dY lo]
 #pragma unroll
-        for (int i = 0; i < Cfg::IPWX; ++i) glds16(xs + voffx[i], lb + (i * NW + w) * 1024);
+        for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-        for (int i = 0; i < Cfg::IPWY; ++i) glds16(ys + voffy[i], lb + Cfg::XS + (i * NW + w) * 1024);
+            for (int i = 0; i < Cfg::IPWX; ++i) glds16(xs + pl * xplaneB + voffx[i], lb + pl * Cfg::XS + (i * NW + w) * 1024);
+#pragma unroll
+            for (int i = 0; i < Cfg::IPWY; ++i)
+                glds16(ys + pl * yplaneB + voffy[i], lb + NPL * Cfg::XS + pl * Cfg::YS + (i * NW + w) * 1024);
+        }
     };
 
     f32x16 acc[TI][TO];
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
     // transposed-read lane constants (f16/bf16)
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
 
-    constexpr int lps = Cfg::IPWX + Cfg::IPWY;     // LDS-DMA pieces per wave and stage
+    constexpr int lps = NPL * (Cfg::IPWX + Cfg::IPWY);     // LDS-DMA pieces per wave and stage
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nsteps) stage(s0, s0);
@@ -147,30 +154,39 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
         const int buf = cbuf;
         cbuf = (cbuf + 1 == NS) ? 0 : cbuf + 1;
         ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
-        const char* xs = smem + buf * Cfg::STAGE;
-        const char* ys = xs + Cfg::XS;
+        const char* xs = smem + buf * NPL * Cfg::STAGE;
+        const char* ys = xs + NPL * Cfg::XS;
         if constexpr (SZ == 2) {
             const int fx = wg_swz<ROWX, SZ>(qq), fy = wg_swz<ROWY, SZ>(qq);
 #pragma unroll
             for (int kg = 0; kg < BKP / 16; ++kg) {
-                typename Elem<T>::frag fa[TI], fb[TO];
+                typename Elem<T>::frag fa[NPL][TI], fb[NPL][TO];
                 const int row0 = kg * 16 + 8 * hh + qq;
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const int slot = (((wi * TI + i) * 4 + 2 * g1 + (pp >> 1)) ^ fx);
-                    const char* p = xs + row0 * ROWX + slot * 16 + (pp & 1) * 8;
-                    fa[i] = tr_frag<T>(p, p + 4 * ROWX);
-                }
+                for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-                for (int j = 0; j < TO; ++j) {
-                    const int slot = (((wo * TO + j) * 4 + 2 * g1 + (pp >> 1)) ^ fy);
-                    const char* p = ys + row0 * ROWY + slot * 16 + (pp & 1) * 8;
-                    fb[j] = tr_frag<T>(p, p + 4 * ROWY);
+                    for (int i = 0; i < TI; ++i) {
+                        const int slot = (((wi * TI + i) * 4 + 2 * g1 + (pp >> 1)) ^ fx);
+                        const char* p = xs + pl * Cfg::XS + row0 * ROWX + slot * 16 + (pp & 1) * 8;
+                        fa[pl][i] = tr_frag<T>(p, p + 4 * ROWX);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TO; ++j) {
+                        const int slot = (((wo * TO + j) * 4 + 2 * g1 + (pp >> 1)) ^ fy);
+                        const char* p = ys + pl * Cfg::YS + row0 * ROWY + slot * 16 + (pp & 1) * 8;
+                        fb[pl][j] = tr_frag<T>(p, p + 4 * ROWY);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < TO; ++j) mma32(acc[i][j], fa[i], fb[j]);
+                    for (int j = 0; j < TO; ++j) {
+                        mma32(acc[i][j], fa[0][i], fb[0][j]);
+                        if constexpr (PL2) {
+                            mma32(acc[i][j], fa[1][i], fb[0][j]);      // x lo * dy hi
+                            mma32(acc[i][j], fa[0][i], fb[1][j]);      // x hi * dy lo
+                        }
+                    }
             }
         } else {
 #pragma unroll
@@ -232,19 +248,28 @@ __global__ __launch_bounds__(WI* WO * 64) void wgrad_kernel(WgradArgs a) {
 #endif
 }
 
-template <typename T, int WI, int WO, int TI, int TO, int NS = 2>
+template <typename T, int WI, int WO, int TI, int TO, int NS = 2, bool PL2 = false>
 static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     typedef WgCfg<T, WI, WO, TI, TO, NS> Cfg;
     static_assert(Cfg::LDS <= 160 * 1024, "LDS");
+    if constexpr (sizeof(T) == 2 && !PL2 && 2 * Cfg::LDS <= 160 * 1024) {
+        // f16x2 mode: both planes staged, the three plane products in one block (one partial per split instead of three)
+        static const bool quads_form = getenv("Y2_SPLIT_WGRAD_QUADS") != nullptr;
+        if (a.quads == 3 && !quads_form) {
+            a.quads = 1;
+            return wg_launch<T, WI, WO, TI, TO, NS, true>(a, s, 256);      // twice the LDS: one block per CU
+        }
+    }
+    constexpr int LDSB = (PL2 ? 2 : 1) * Cfg::LDS;
     // (the finish flag of the opt-in in-kernel sum sits behind the staging buffers: 16 more bytes only when it is on --
     //  a request of exactly 1/2 or 1/3 of the CU's LDS must stay that)
-    const int fin16 = (wgrad_finish_max_parts() > 0 && Cfg::LDS + 16 <= 160 * 1024) ? 16 : 0;
+    const int fin16 = (wgrad_finish_max_parts() > 0 && LDSB + 16 <= 160 * 1024) ? 16 : 0;
     if (!fin16) a.tile_cnt = nullptr;      // no room (or no wish) for the finish flag: the separate sum kernel
-    auto kern = wgrad_kernel<T, WI, WO, TI, TO, NS>;
+    auto kern = wgrad_kernel<T, WI, WO, TI, TO, NS, PL2>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS + 16 <= 160 * 1024 ? Cfg::LDS + 16 : Cfg::LDS);
+                                           LDSB + 16 <= 160 * 1024 ? LDSB + 16 : LDSB);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -256,7 +281,7 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
         // 1x1: with float atomics the partial tiles cost as much as the streaming reads and one block per CU was
         // the optimum; through the slab two per CU are (scripts/bench_wgrad.py: 38 -> 33.5 us at 26x26 / 13x13);
         // 3x3 fallback: ~6 per CU
-        const int target = a.taps == 1 ? (a.slab && target1 == 256 ? 512 : target1) : 1536;
+        const int target = a.taps == 1 ? (a.slab && target1 == 256 && !PL2 ? 512 : target1) : 1536;
         long sk = (target + tiles - 1) / tiles;
         const long maxsk = (ksteps + 7) / 8;         // at least 8 K steps per block
         if (sk > maxsk) sk = maxsk;
@@ -265,7 +290,7 @@ static hipError_t wg_launch(WgradArgs a, hipStream_t s, int target1 = 256) {
     }
     hipError_t e = wgrad_split_prepare(a, s);
     if (e != hipSuccess) return e;
-    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), Cfg::LDS + fin16, s, a);
+    e = wgrad_launch_quads(kern, dim3(tiles * a.splitk), dim3(Cfg::NT), LDSB + fin16, s, a);
     return e != hipSuccess ? e : wgrad_split_finish(a, s);
 }
 
