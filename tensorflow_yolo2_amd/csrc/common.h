@@ -153,6 +153,27 @@ Y2_DEV void mma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
 
+// Split-operand products formed IN REGISTERS from fp32 data (the 3-channel first layer of the f16x2 mode, whose
+// operands are fp32 in memory: conv1.hip / conv1_wgrad.hip XS forms): eight fp32 values -> one hi and one lo fragment,
+// and the three plane products of one 32x32x16 step (small terms first).  The two f32x4 halves are the two 16-byte
+// fragments a lane holds of a 32-wide fp32 k range (Elem<float>): the k order inside the MFMA is a permutation applied
+// identically to both operands, so the sum is unchanged.
+Y2_DEV void split_frag8(const f32x4& a, const f32x4& b, float scale, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float va = a[k] * scale, vb = b[k] * scale;
+        hi[k] = (half_t)va;
+        hi[4 + k] = (half_t)vb;
+        lo[k] = (half_t)(va - (float)hi[k]);
+        lo[4 + k] = (half_t)(vb - (float)hi[4 + k]);
+    }
+}
+Y2_DEV void mma32_split(f32x16& acc, const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+}
+
 Y2_DEV int acc_row(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
 
 // 16-byte vector of T (a "chunk"): load/store + per-element float access

@@ -153,12 +153,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(Conv1Args a) {
 // Statistics-only pass (first pass of the pooled first layer): no output, so no transpose either --
 // every lane keeps bias-shifted sums of its 16 couts (values rounded to T as they WILL be stored by
 // the second pass) over all its tiles; lanes are reduced once, at the end.
-template <typename T>
+// XS (f16x2 mode, T = float: round 5): the fp32 operands are split into (hi, lo) halves in registers and a filter row is
+// three v_mfma_f32_32x32x16_f16 (common.h mma32_split; filters times kSplitWScale) instead of eight
+// v_mfma_f32_32x32x2_f32 -- the exact-fp32 form is bound by its matrix instructions (16x the f16 cycles per product).
+template <typename T, bool XS = false>
 __global__ __launch_bounds__(256) void conv1_stats_kernel(Conv1Args a) {
     typedef typename Elem<T>::frag frag_t;
     struct __attribute__((packed, aligned(8))) UFrag { frag_t v; };
     constexpr int SZ = sizeof(T);
     constexpr int KGC = 16 * SZ / 32;
+    static_assert(!XS || SZ == 4, "the in-register split reads fp32 operands");
     __shared__ float st[4 * 32 * 3];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,6 +173,11 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(Conv1Args a) {
 #pragma unroll
         for (int g = 0; g < KGC; ++g)
             fw[kh][g] = *(const frag_t*)((const char*)a.w + ((r32 * 3 + kh) * 16) * SZ + 32 * g + 16 * hh);
+    f16x8 fwh[3], fwl[3];
+    if constexpr (XS) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) split_frag8(fw[kh][0], fw[kh][KGC - 1], kSplitWScale, fwh[kh], fwl[kh]);
+    }
     float bq[16], s1[16], s2[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -198,16 +207,27 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(Conv1Args a) {
                 fx[r][g] = ((const UFrag*)((const char*)a.x4 + base + (r < 3 || row1 ? r : 2) * rowpitch + 32 * g + 16 * hh))->v;
         const float vm = (w0 + r32 < a.W) ? 1.f : 0.f;
         const int cols = a.W - w0 < 32 ? a.W - w0 : 32;
+        f16x8 fxh[4], fxl[4];
+        if constexpr (XS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split_frag8(fx[r][0], fx[r][KGC - 1], 1.0f, fxh[r], fxl[r]);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             if (r == 1 && !row1) break;
             f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            if constexpr (XS) {
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+                for (int kh = 0; kh < 3; ++kh) mma32_split(acc, fwh[kh], fwl[kh], fxh[r + kh], fxl[r + kh]);
+                acc *= kSplitWScaleInv;
+            } else {
 #pragma unroll
-                for (int g = 0; g < KGC; ++g) mma32(acc, fw[kh][g], fx[r + kh][g]);
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int g = 0; g < KGC; ++g) mma32(acc, fw[kh][g], fx[r + kh][g]);
+            }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const float d = (Elem<T>::to_f32(Elem<T>::from_f32(acc[q] + bq[q])) - bq[q]) * vm;
@@ -254,11 +274,14 @@ __global__ __launch_bounds__(256) void conv1_stats_kernel(Conv1Args a) {
 }
 
 hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
-    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
+    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer reads fp32 operands (exact fp32, or Conv1Args::xs)
     dim3 g(a.nblocks), b(256);
     if (a.stats_only) {
         switch (dtype) {
-            case 0: hipLaunchKernelGGL(conv1_stats_kernel<float>, g, b, 0, s, a); break;
+            case 0:
+                if (a.xs) hipLaunchKernelGGL((conv1_stats_kernel<float, true>), g, b, 0, s, a);
+                else hipLaunchKernelGGL(conv1_stats_kernel<float>, g, b, 0, s, a);
+                break;
             case 1: hipLaunchKernelGGL(conv1_stats_kernel<half_t>, g, b, 0, s, a); break;
             case 2: hipLaunchKernelGGL(conv1_stats_kernel<bf16_t>, g, b, 0, s, a); break;
             default: return hipErrorInvalidValue;
@@ -290,12 +313,14 @@ hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s) {
 // the ~400 vector instructions a tile cost; the kernel is bound by vector issue, not by HBM) drops out.
 // TRACK 2 (Conv1PoolArgs::idx3; training, 16-bit types): the same maximum first, then the first position that holds it by
 // equality, and 3 bits per element (position, activation branch) instead of any conv output.
-template <typename T, bool STOREY, int TRACK>
+// XS: as conv1_stats_kernel (f16x2 mode: the SAME three-product sequence, so both passes see the same conv output).
+template <typename T, bool STOREY, int TRACK, bool XS = false>
 __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
     typedef typename Elem<T>::frag frag_t;
     struct __attribute__((packed, aligned(8))) UFrag { frag_t v; };
     constexpr int SZ = sizeof(T);
     constexpr int KGC = 16 * SZ / 32;
+    static_assert(!XS || SZ == 4, "the in-register split reads fp32 operands");
     constexpr int EROW = 32 * SZ + 16;
     constexpr int EPC = 16 / SZ;
     constexpr int CPR = 32 / EPC;            // chunks per pixel row (4: f16/bf16, 8: f32)
@@ -312,6 +337,11 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
 #pragma unroll
         for (int g = 0; g < KGC; ++g)
             fw[kh][g] = *(const frag_t*)((const char*)a.w + ((r32 * 3 + kh) * 16) * SZ + 32 * g + 16 * hh);
+    f16x8 fwh[3], fwl[3];
+    if constexpr (XS) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) split_frag8(fw[kh][0], fw[kh][KGC - 1], kSplitWScale, fwh[kh], fwl[kh]);
+    }
     float b4[4][4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4)
@@ -345,14 +375,25 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
         const int sg = tile % nseg, pr = tile / nseg;
         const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho, w0 = sg * 32;
         f32x16 acc[2];
+        f16x8 fxh[4], fxl[4];
+        if constexpr (XS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split_frag8(fx[r][0], fx[r][KGC - 1], 1.0f, fxh[r], fxl[r]);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[r][q] = 0.f;
+            if constexpr (XS) {
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+                for (int kh = 0; kh < 3; ++kh) mma32_split(acc[r], fwh[kh], fwl[kh], fxh[r + kh], fxl[r + kh]);
+                acc[r] *= kSplitWScaleInv;
+            } else {
 #pragma unroll
-                for (int g = 0; g < KGC; ++g) mma32(acc[r], fw[kh][g], fx[r + kh][g]);
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int g = 0; g < KGC; ++g) mma32(acc[r], fw[kh][g], fx[r + kh][g]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -482,24 +523,27 @@ __global__ __launch_bounds__(256) void conv1_pool_kernel(Conv1PoolArgs a) {
 
 bool conv1_pool_ok(int H, int W, int pool, int cout) { return pool && (H % 2) == 0 && (W % 2) == 0 && cout == 32; }
 
-template <typename T>
+template <typename T, bool XS = false>
 static void conv1_pool_T(const Conv1PoolArgs& a, hipStream_t s) {
     dim3 g(a.nblocks), b(256);
     if (a.store_y) {
-        if (a.idx3) hipLaunchKernelGGL((conv1_pool_kernel<T, true, 2>), g, b, 0, s, a);
-        else if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, true, 1>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((conv1_pool_kernel<T, true, 0>), g, b, 0, s, a);
+        if (a.idx3) hipLaunchKernelGGL((conv1_pool_kernel<T, true, 2, XS>), g, b, 0, s, a);
+        else if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, true, 1, XS>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((conv1_pool_kernel<T, true, 0, XS>), g, b, 0, s, a);
     } else {
-        if (a.idx3) hipLaunchKernelGGL((conv1_pool_kernel<T, false, 2>), g, b, 0, s, a);
-        else if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, false, 1>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((conv1_pool_kernel<T, false, 0>), g, b, 0, s, a);
+        if (a.idx3) hipLaunchKernelGGL((conv1_pool_kernel<T, false, 2, XS>), g, b, 0, s, a);
+        else if (a.ysel) hipLaunchKernelGGL((conv1_pool_kernel<T, false, 1, XS>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((conv1_pool_kernel<T, false, 0, XS>), g, b, 0, s, a);
     }
 }
 
 hipError_t launch_conv1_pool(int dtype, const Conv1PoolArgs& a, hipStream_t s) {
-    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
+    dtype = dtype_plain(dtype);      // f16x2: fp32 operands (exact fp32, or Conv1PoolArgs::xs)
     switch (dtype) {
-        case 0: conv1_pool_T<float>(a, s); break;
+        case 0:
+            if (a.xs) conv1_pool_T<float, true>(a, s);
+            else conv1_pool_T<float>(a, s);
+            break;
         case 1: conv1_pool_T<half_t>(a, s); break;
         case 2: conv1_pool_T<bf16_t>(a, s); break;
         default: return hipErrorInvalidValue;

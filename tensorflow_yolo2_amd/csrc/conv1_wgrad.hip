@@ -390,7 +390,10 @@ constexpr int kLinItems = 0;     // items (pooled pixel x chunk) per thread held
 // NOSEL (kernels.h Conv1PoolArgs::idx3): no conv output is read; the slope of the activation at the arg-max comes with
 // the position (3 bits per channel), and this kernel's S2 records stay zero -- conv1_lin_s2_kernel adds sum g * y as one
 // record from the reduced X(dz)
-template <typename T, bool GRAM, bool NOSEL>
+// XS (f16x2 mode, T = float: round 5): the fp32 row images are read as in the exact-fp32 form, split into (hi, lo) halves
+// in registers, and X(dz) / G are three v_mfma_f32_32x32x16_f16 per 16-pixel group and product (common.h mma32_split)
+// instead of eight v_mfma_f32_32x32x2_f32: 15 matrix instructions of 32 cycles per group instead of 40 of 64.
+template <typename T, bool GRAM, bool NOSEL, bool XS = false>
 __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1WgradLinArgs a, float* part) {
     // also the BN-backward REDUCE of this layer, for free: dA and ysel pass through here anyway, and nothing in this
     // kernel needs the sums (S1 = sum g, S2 = sum g * ysel -> psum[block][2][32]; the finalize runs after it)
@@ -553,6 +556,37 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                         mma32(g11, fa1, fg1);
                         mma32(g12, fa1, fg2);
                         mma32(g22, fa2, fg2);
+                    }
+                } else if constexpr (XS) {
+                    // lane (r32, hh) holds k = pixels w0 + 8 hh .. + 7 of its row (A: patch element r32, B: cout r32)
+                    f32x4 bv[2], a1v[2], a2v[2], m1v[2], m2v[2];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int pix = w0 + 8 * hh + j;
+                        bv[j >> 2][j & 3] = *(const float*)(dzr + pix * DYP + r32 * 4);
+                        const float a1 = *(const float*)(x_l + (r + (r32 >> 4)) * x_bytes + pix * XP + (r32 & 15) * 4);
+                        const float a2 = *(const float*)(x_l + (r + 2) * x_bytes + pix * XP + (r32 & 15) * 4);
+                        a1v[j >> 2][j & 3] = a1;
+                        a2v[j >> 2][j & 3] = a2;
+                        if constexpr (GRAM) {       // k-padding pixels hold the next row's data: masked out of one side
+                            const bool in = pix < a.W;
+                            m1v[j >> 2][j & 3] = in ? a1 : 0.f;
+                            m2v[j >> 2][j & 3] = in ? a2 : 0.f;
+                        }
+                    }
+                    f16x8 bh, bl, a1h, a1l, a2h, a2l;
+                    split_frag8(bv[0], bv[1], 1.0f, bh, bl);
+                    split_frag8(a1v[0], a1v[1], 1.0f, a1h, a1l);
+                    split_frag8(a2v[0], a2v[1], 1.0f, a2h, a2l);
+                    mma32_split(acc1, a1h, a1l, bh, bl);
+                    mma32_split(acc2, a2h, a2l, bh, bl);
+                    if constexpr (GRAM) {
+                        f16x8 m1h, m1l, m2h, m2l;
+                        split_frag8(m1v[0], m1v[1], 1.0f, m1h, m1l);
+                        split_frag8(m2v[0], m2v[1], 1.0f, m2h, m2l);
+                        mma32_split(g11, a1h, a1l, m1h, m1l);
+                        mma32_split(g12, a1h, a1l, m2h, m2l);
+                        mma32_split(g22, a2h, a2l, m2h, m2l);
                     }
                 } else {
 #pragma unroll
@@ -961,7 +995,7 @@ hipError_t launch_conv1_gram_stats(int dtype, const Conv1GramStatsArgs& a, hipSt
     return hipErrorInvalidValue;
 }
 
-template <typename T>
+template <typename T, bool XS = false>
 static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
     constexpr int SZ = sizeof(T);
     const int Wp = (a.W + 15) & ~15;
@@ -973,8 +1007,8 @@ static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
     const bool nosel = a.idx3 != nullptr;
     if (nosel && !(a.Wf && a.bias)) return hipErrorInvalidValue;
-    auto kern = nosel ? (a.gram ? conv1_wgrad_lin_kernel<T, false, true> : conv1_wgrad_lin_kernel<T, true, true>)
-                      : (a.gram ? conv1_wgrad_lin_kernel<T, false, false> : conv1_wgrad_lin_kernel<T, true, false>);
+    auto kern = nosel ? (a.gram ? conv1_wgrad_lin_kernel<T, false, true, XS> : conv1_wgrad_lin_kernel<T, true, true, XS>)
+                      : (a.gram ? conv1_wgrad_lin_kernel<T, false, false, XS> : conv1_wgrad_lin_kernel<T, true, false, XS>);
     static size_t attr[4] = {0, 0, 0, 0};        // per kernel form of this T
     const int form = (nosel ? 2 : 0) + (a.gram ? 1 : 0);
     if (lds > attr[form]) {
@@ -1006,9 +1040,9 @@ bool conv1_wgrad_lin_ok(int H, int W, int pool, int ldy, int elem_size) {
 size_t conv1_wgrad_lin_scratch_floats() { return (size_t)kLinAcc * (kLinMid + 512); }
 
 hipError_t launch_conv1_wgrad_lin(int dtype, const Conv1WgradLinArgs& a, hipStream_t s) {
-    dtype = dtype_plain(dtype);      // f16x2: the 3-channel layer computes in exact fp32
+    dtype = dtype_plain(dtype);      // f16x2: fp32 operands (exact fp32, or Conv1WgradLinArgs::xs)
     switch (dtype) {
-        case 0: return c1lin_T<float>(a, s);
+        case 0: return a.xs ? c1lin_T<float, true>(a, s) : c1lin_T<float>(a, s);
         case 1: return c1lin_T<half_t>(a, s);
         case 2: return c1lin_T<bf16_t>(a, s);
     }

@@ -110,6 +110,9 @@ struct Conv1Args {
     int N, H, W, M;
     int nblocks;        // persistent grid size == number of partials
     int stats_only;     // 1: batch-norm partials only, y is not written (first pass of the pooled form)
+    // f16x2 mode, stats_only pass: the fp32 operands are split into half planes in registers and a filter row is three f16
+    // matrix instructions (conv1.hip XS forms; set together with Conv1PoolArgs::xs / Conv1WgradLinArgs::xs)
+    int xs = 0;
 };
 hipError_t launch_conv1_fwd(int dtype, const Conv1Args& a, hipStream_t s);
 // pooled first layer, second pass: conv again + BN + leaky + 2x2 max pool -> y (optional) and the pooled output
@@ -135,6 +138,7 @@ struct Conv1PoolArgs {
     // gradient forms anyway (conv1_wgrad.hip conv1_lin_s2_kernel).  Set instead of ysel / idx.
     unsigned* idx3 = nullptr;
     int out_split = 0;  // f16x2 mode (T = float kernels): `out` is a split tensor ([32 halves hi][32 halves lo] per cell)
+    int xs = 0;         // f16x2 mode: split-operand products formed in registers (Conv1Args::xs)
 };
 // backward reduce pass of the same layer with the conv output recomputed (x4 + dA in, psum out)
 struct Conv1BnBwdArgs {
@@ -193,6 +197,7 @@ struct Conv1WgradLinArgs {
     float* psum;                // out: BN-backward partial sums [blocks][2][32] (S1, S2) -- the reduce pass rides here
     int* nblocks_out;           // host: number of partial records written
     int N, H, W;
+    int xs = 0;                 // f16x2 mode (T = float kernel): X(dz) and G from split-operand f16 products (Conv1Args::xs)
 };
 struct Conv1DwFinalizeArgs {
     const float* acc;           // the 16 slice sums (added here)

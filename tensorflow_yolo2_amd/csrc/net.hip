@@ -110,6 +110,12 @@ struct y2_ctx {
     // pooled 3-channel first layer, training: the linear form of its backward pass (conv1_wgrad.hip) -- its conv
     // output is never stored
     bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
+    // f16x2: the 3-channel layer's passes form split-operand products in registers (conv1.hip XS forms) wherever no
+    // exact-fp32 fallback recomputes its conv output (the linear-form backward, or no backward at all)
+    bool xs1() const {
+        static const bool off = getenv("Y2_CONV1_NO_XS") != nullptr;
+        return dtype_split(dtype) && !off && (lin1() || !bound_training);
+    }
     bool nosel1() const { return lin1() && L[0].ysel == 0; }     // ... and not even the arg-max outputs (Conv1PoolArgs::idx3)
     size_t o_infertab = 0;      // BnInferLayer per layer (one prepare launch for all inference-mode layers)
     size_t o_packtab = 0, o_chkranges = 0, o_smallranges = 0, o_lin = 0, o_nfflag = 0, o_slab = 0;
@@ -707,6 +713,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             a.nblocks = nb > 1024 ? 1024 : nb;      // = statistics records (the plan reserves 2048 rows; 1024 vs 2048: -4 us)
             P = a.nblocks;
             a.stats_only = pool1 ? 1 : 0;
+            a.xs = (pool1 && c->xs1()) ? 1 : 0;
             // round 4: the statistics of the pooled first layer come from the Gram matrix of the input patches (below)
             static const bool no_gram = getenv("Y2_NO_CONV1_GRAM") != nullptr;
             // Half-precision modes only: their stored activations carry 5e-4 of rounding noise, against which the ~1e-6
@@ -780,6 +787,7 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             q.nblocks = (tiles + 3) / 4 > 2048 ? 2048 : (tiles + 3) / 4;
             q.store_y = (c->bound_training && !c->lin1()) ? 1 : 0;
             q.out_split = dtype_split(c->dtype) ? 1 : 0;
+            q.xs = c->xs1() ? 1 : 0;
             if (c->nosel1()) q.idx3 = (unsigned*)(c->ws + y.idx0);
             else if (c->lin1()) { q.ysel = c->ws + y.ysel; q.idx = (unsigned short*)(c->ws + y.idx0); }
             HIPCHK(launch_conv1_pool(c->dtype, q, s));
@@ -935,6 +943,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 int nbl = 0;
                 g.nblocks_out = &nbl;
                 g.N = c->N; g.H = y.H; g.W = y.W;
+                g.xs = c->xs1() ? 1 : 0;
                 HIPCHK(launch_conv1_wgrad_lin(c->dtype, g, s));
                 b.P = nbl;
             } else if (rec1) {   // pooled first layer: recompute the conv output instead of reading it (80 -> 24 B/pixel)
