@@ -398,25 +398,35 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
     // also the BN-backward REDUCE of this layer, for free: dA and ysel pass through here anyway, and nothing in this
     // kernel needs the sums (S1 = sum g, S2 = sum g * ysel -> psum[block][2][32]; the finalize runs after it)
     constexpr int SZ = sizeof(T), EPC = 16 / SZ, CPP = 32 / EPC;
-    constexpr int DYP = 32 * SZ, XP = 4 * SZ;
+    // XS: the LDS row images are TWO half planes (hi, lo) in the 16-bit types' layout -- dz is split once where it is
+    // scattered, x once where it is staged -- and the matrix section is the 16-bit one on plane pairs
+    constexpr int LSZ = XS ? 2 : SZ;
+    constexpr int DYP = 32 * LSZ, XP = 4 * LSZ;
+    static_assert(!XS || SZ == 4, "the in-register split reads fp32 operands");
     constexpr int NTH = kLinThreads, NW = NTH / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int Wp = (a.W + 15) & ~15;
+    const int nseg = a.nseg > 1 ? a.nseg : 1;          // column segments per row pair (Conv1WgradLinArgs::nseg)
+    const int Wp = nseg > 1 ? a.ws : ((a.W + 15) & ~15);
     const int dz_bytes = Wp * DYP;
     const int x_bytes = ((Wp + 4) * XP + 15) & ~15;
-    char* dz_l = smem;                   // [2 rows][Wp][32]
-    char* x_l = smem + 2 * dz_bytes;     // [4 rows][x_bytes]
+    char* dz_l = smem;                   // [2 rows][Wp][32]            (XS: [2 planes][2 rows][Wp][32] halves)
+    char* x_l = smem + (XS ? 4 : 2) * dz_bytes;     // [4 rows][x_bytes]  (XS: [2 planes][4 rows][x_bytes])
     const int x_chunks = x_bytes / 16;
+    const int dz_plane = 2 * dz_bytes, x_plane = 4 * x_bytes;      // XS: byte distance of the lo plane
     const int Ho = a.H / 2, Wo = a.W / 2;
     const int prs = a.N * Ho;
     const int r32 = lane & 31, hh = lane >> 5;
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
 
-    for (int i = tid; i < 2 * (Wp - a.W) * CPP; i += NTH) {     // k-padding pixels of the dz rows: zero, once
-        const int r = i / ((Wp - a.W) * CPP), j = i % ((Wp - a.W) * CPP);
-        *(u32x4*)(dz_l + r * dz_bytes + a.W * DYP + j * 16) = u32x4{0, 0, 0, 0};
+    {   // k-padding pixels of the dz rows: zero, once
+        constexpr int LCPP = DYP / 16;      // 16-byte chunks per pixel of an LDS row image
+        const int padw = nseg > 1 ? 0 : Wp - a.W;       // (segments: zeroed per unit, below)
+        for (int i = tid; i < (XS ? 4 : 2) * padw * LCPP; i += NTH) {
+            const int r = i / (padw * LCPP), j = i % (padw * LCPP);
+            *(u32x4*)(dz_l + r * dz_bytes + a.W * DYP + j * 16) = u32x4{0, 0, 0, 0};
+        }
     }
     const int ch = tid % CPP, c0 = ch * EPC;
     float sc[EPC], sh[EPC];
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
 
-    const int nitems = Wo * CPP;
+    int nitems = Wo * CPP;
     // the dA / ysel / idx of a row pair are requested while the MFMAs of the previous one run (two blocks of eight
     // waves per CU: in-place loads leave the HBM latency of every row pair exposed)
     u32x4 pda[kLinItems ? kLinItems : 1], pys[kLinItems ? kLinItems : 1];
@@ -474,6 +484,24 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
             s1[e] += g;
             gz[e] = Elem<T>::from_f32(g);
         }
+        if constexpr (XS) {
+            half_t gh[EPC], gl[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) split_f16(gz[e], gh[e], gl[e]);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                half_t oh[EPC], ol[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const bool here = ((ix >> (IB * e)) & 3u) == (unsigned)d;
+                    oh[e] = here ? gh[e] : (half_t)0.f;
+                    ol[e] = here ? gl[e] : (half_t)0.f;
+                }
+                char* dst = dz_l + (d >> 1) * dz_bytes + (size_t)(2 * wo + (d & 1)) * DYP + ch * 8;
+                *(u32x2*)dst = *(const u32x2*)oh;
+                *(u32x2*)(dst + dz_plane) = *(const u32x2*)ol;
+            }
+        } else {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             Chunk<T> o;
@@ -481,13 +509,17 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
             for (int e = 0; e < EPC; ++e) o.v[e] = (((ix >> (IB * e)) & 3u) == (unsigned)d) ? gz[e] : Elem<T>::from_f32(0.f);
             st_chunk<T>(dz_l + (d >> 1) * dz_bytes + (size_t)(2 * wo + (d & 1)) * DYP + ch * 16, o);
         }
+        }
     };
-    if (kLinItems && (int)blockIdx.x < prs) prefetch(blockIdx.x);
-    for (int pr = blockIdx.x; pr < prs; pr += gridDim.x) {
+    for (int un = blockIdx.x; un < prs * nseg; un += gridDim.x) {
+        const int pr = un / nseg, seg = un - pr * nseg;
+        const int cbeg = seg * Wp;                                  // first pixel column of this unit
+        const int Wv = a.W - cbeg < Wp ? a.W - cbeg : Wp;           // its width (nseg == 1: the whole row, a.W)
+        nitems = (Wv / 2) * CPP;
         const int n = pr / Ho, ho = pr - n * Ho, h0 = 2 * ho;
-        const char* xrow = (const char*)a.x4 + (bpix(n, h0, 0, a.H, a.W) - (size_t)(a.W + 2)) * XP;
-        const size_t xpitch = (size_t)(a.W + 1) * XP;
-        const size_t prow = ((size_t)n * Ho + ho) * Wo;
+        const char* xrow = (const char*)a.x4 + (bpix(n, h0, 0, a.H, a.W) - (size_t)(a.W + 2) + (size_t)cbeg) * (4 * SZ);
+        const size_t xpitch = (size_t)(a.W + 1) * (4 * SZ);
+        const size_t prow = ((size_t)n * Ho + ho) * Wo + cbeg / 2;
         // this row pair's first kBatch items per thread: every load issued before the first one is used (left to the
         // compiler the loop below loads, waits and processes item by item: three to four exposed latencies per row pair)
         constexpr int kBatch = kLinItems ? 0 : 4;
@@ -506,12 +538,69 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                 }
             }
         }
+        // XS: the four fp32 input rows come through registers (every load issued before the barrier), are split once and
+        // land as two half planes in the 16-bit types' image layout (4 halves per pixel)
+        constexpr int kXB = XS ? 4 : 1;      // (register budget: 256 with two blocks per CU)
+        const int xpix = Wp + 4;           // pixels per staged row (x_bytes / XP)
+        u32x4 xv[kXB];
+        if constexpr (XS) {
+#pragma unroll
+            for (int k = 0; k < kXB; ++k) {
+                const int i = tid + k * NTH;
+                if (i < 4 * xpix) xv[k] = *(const u32x4*)(xrow + (i / xpix) * xpitch + (size_t)(i % xpix) * 16);
+            }
+        }
         __syncthreads();   // previous row pair fully consumed
+        if (nseg > 1 && Wv < Wp) {      // a narrower last segment: its k-padding pixels held the previous unit's dz
+            constexpr int LCPP = DYP / 16;
+            for (int i = tid; i < (XS ? 4 : 2) * (Wp - Wv) * LCPP; i += NTH) {
+                const int r = i / ((Wp - Wv) * LCPP), j = i % ((Wp - Wv) * LCPP);
+                *(u32x4*)(dz_l + r * dz_bytes + Wv * DYP + j * 16) = u32x4{0, 0, 0, 0};
+            }
+        }
+        // XS (fp32 dA: 6.5 items per thread at W = 416): a second batch of items is requested here, behind the barrier, and
+        // lands while the input rows are split and the first batch is scattered (the tail loop below pays one exposed
+        // latency per item)
+        constexpr int kBatch2 = (XS && NOSEL) ? 3 : 0;
+        u32x4 bda2[kBatch2 ? kBatch2 : 1], bys2[kBatch2 ? kBatch2 : 1];
+        unsigned bix2[kBatch2 ? kBatch2 : 1];
+#pragma unroll
+        for (int k = 0; k < kBatch2; ++k) {
+            const int item = tid + (kBatch + k) * NTH;
+            if (item < nitems) {
+                bda2[k] = *(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16);
+                if constexpr (NOSEL) {
+                    bix2[k] = a.idx3[prow * CPP + item];
+                } else {
+                    bys2[k] = *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16);
+                    bix2[k] = a.idx[prow * CPP + item];
+                }
+            }
+        }
+        if constexpr (XS) {
+            auto put = [&](int i, const u32x4& v) {
+                const f32x4 f = __builtin_bit_cast(f32x4, v);
+                half_t h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_f16(f[e], h[e], l[e]);
+                char* dst = x_l + (i / xpix) * x_bytes + (i % xpix) * XP;
+                *(u32x2*)dst = *(const u32x2*)h;
+                *(u32x2*)(dst + x_plane) = *(const u32x2*)l;
+            };
+#pragma unroll
+            for (int k = 0; k < kXB; ++k) {
+                const int i = tid + k * NTH;
+                if (i < 4 * xpix) put(i, xv[k]);
+            }
+            for (int i = tid + kXB * NTH; i < 4 * xpix; i += NTH)      // wider images: the rest in place
+                put(i, *(const u32x4*)(xrow + (i / xpix) * xpitch + (size_t)(i % xpix) * 16));
+        } else {
         for (int kh = 0; kh < 4; ++kh)
             for (int i0 = w * 64; i0 < x_chunks; i0 += NTH) {
                 const int i = i0 + lane;
                 if (i < x_chunks) glds16(xrow + kh * xpitch + (size_t)i * 16, x_l + kh * x_bytes + i0 * 16);
             }
+        }
 #pragma unroll
         for (int k = 0; k < kLinItems; ++k) {
             const int item = tid + k * NTH;
@@ -522,17 +611,21 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
             const int item = tid + k * NTH;
             if (item < nitems) process(bda[k], NOSEL ? bda[k] : bys[k], bix[k], item);
         }
-        for (int item = tid + (kLinItems + kBatch) * NTH; item < nitems; item += NTH) {    // wider images: the rest in place
+#pragma unroll
+        for (int k = 0; k < kBatch2; ++k) {
+            const int item = tid + (kBatch + k) * NTH;
+            if (item < nitems) process(bda2[k], NOSEL ? bda2[k] : bys2[k], bix2[k], item);
+        }
+        for (int item = tid + (kLinItems + kBatch + kBatch2) * NTH; item < nitems; item += NTH) {    // wider images: the rest in place
             const u32x4 dar = *(const u32x4*)((const char*)a.dA + (prow * CPP + item) * 16);
             if constexpr (NOSEL) process(dar, dar, a.idx3[prow * CPP + item], item);
             else process(dar, *(const u32x4*)((const char*)a.ysel + (prow * CPP + item) * 16), a.idx[prow * CPP + item], item);
         }
-        if (kLinItems && pr + (int)gridDim.x < prs) prefetch(pr + gridDim.x);
         __syncthreads();   // LDS-DMA drained (vmcnt(0)) and the dz images complete
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const char* dzr = dz_l + r * dz_bytes;
-            for (int s = w; s * 16 < a.W; s += NW) {
+            for (int s = w; s * 16 < Wv; s += NW) {
                 const int w0 = s * 16;
                 if constexpr (SZ == 2) {
                     const int pix = w0 + 8 * hh + qq;
@@ -548,42 +641,36 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                     mma32(acc2, fa2, fb);
                     if constexpr (GRAM) {
                         typename Elem<T>::frag fg1 = fa1, fg2 = fa2;
-                        if (w0 + 16 > a.W) {
+                        if (w0 + 16 > Wv) {
 #pragma unroll
                             for (int j = 0; j < 8; ++j)
-                                if (w0 + 8 * hh + j >= a.W) { fg1[j] = (T)0.f; fg2[j] = (T)0.f; }
+                                if (w0 + 8 * hh + j >= Wv) { fg1[j] = (T)0.f; fg2[j] = (T)0.f; }
                         }
                         mma32(g11, fa1, fg1);
                         mma32(g12, fa1, fg2);
                         mma32(g22, fa2, fg2);
                     }
                 } else if constexpr (XS) {
-                    // lane (r32, hh) holds k = pixels w0 + 8 hh .. + 7 of its row (A: patch element r32, B: cout r32)
-                    f32x4 bv[2], a1v[2], a2v[2], m1v[2], m2v[2];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int pix = w0 + 8 * hh + j;
-                        bv[j >> 2][j & 3] = *(const float*)(dzr + pix * DYP + r32 * 4);
-                        const float a1 = *(const float*)(x_l + (r + (r32 >> 4)) * x_bytes + pix * XP + (r32 & 15) * 4);
-                        const float a2 = *(const float*)(x_l + (r + 2) * x_bytes + pix * XP + (r32 & 15) * 4);
-                        a1v[j >> 2][j & 3] = a1;
-                        a2v[j >> 2][j & 3] = a2;
-                        if constexpr (GRAM) {       // k-padding pixels hold the next row's data: masked out of one side
-                            const bool in = pix < a.W;
-                            m1v[j >> 2][j & 3] = in ? a1 : 0.f;
-                            m2v[j >> 2][j & 3] = in ? a2 : 0.f;
-                        }
-                    }
-                    f16x8 bh, bl, a1h, a1l, a2h, a2l;
-                    split_frag8(bv[0], bv[1], 1.0f, bh, bl);
-                    split_frag8(a1v[0], a1v[1], 1.0f, a1h, a1l);
-                    split_frag8(a2v[0], a2v[1], 1.0f, a2h, a2l);
+                    // the 16-bit section on plane pairs: three products per accumulator (common.h mma32_split)
+                    const int pix = w0 + 8 * hh + qq;
+                    const char* pb = dzr + pix * DYP + (16 * g1 + 4 * pp) * 2;
+                    const f16x8 bh = tr_frag<half_t>(pb, pb + 4 * DYP);
+                    const f16x8 bl = tr_frag<half_t>(pb + dz_plane, pb + dz_plane + 4 * DYP);
+                    const char* pa1 = x_l + (r + g1) * x_bytes + (pix + pp) * XP;
+                    const f16x8 a1h = tr_frag<half_t>(pa1, pa1 + 4 * XP);
+                    const f16x8 a1l = tr_frag<half_t>(pa1 + x_plane, pa1 + x_plane + 4 * XP);
+                    const char* pa2 = x_l + (r + 2) * x_bytes + (pix + pp) * XP;
+                    const f16x8 a2h = tr_frag<half_t>(pa2, pa2 + 4 * XP);
+                    const f16x8 a2l = tr_frag<half_t>(pa2 + x_plane, pa2 + x_plane + 4 * XP);
                     mma32_split(acc1, a1h, a1l, bh, bl);
                     mma32_split(acc2, a2h, a2l, bh, bl);
                     if constexpr (GRAM) {
-                        f16x8 m1h, m1l, m2h, m2l;
-                        split_frag8(m1v[0], m1v[1], 1.0f, m1h, m1l);
-                        split_frag8(m2v[0], m2v[1], 1.0f, m2h, m2l);
+                        f16x8 m1h = a1h, m1l = a1l, m2h = a2h, m2l = a2l;
+                        if (w0 + 16 > Wv) {       // k-padding pixels hold the next row's data: masked out of one side
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (w0 + 8 * hh + j >= Wv) { m1h[j] = m1l[j] = m2h[j] = m2l[j] = (half_t)0.f; }
+                        }
                         mma32_split(g11, a1h, a1l, m1h, m1l);
                         mma32_split(g12, a1h, a1l, m2h, m2l);
                         mma32_split(g22, a2h, a2l, m2h, m2l);
@@ -592,7 +679,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
 #pragma unroll
                     for (int k2 = 0; k2 < 8; ++k2) {
                         const int pix = w0 + 2 * k2 + hh;
-                        const float vm = pix < a.W ? 1.f : 0.f;
+                        const float vm = pix < Wv ? 1.f : 0.f;
                         const float b = *(const float*)(dzr + pix * DYP + r32 * 4);
                         const float a1 = *(const float*)(x_l + (r + (r32 >> 4)) * x_bytes + pix * XP + (r32 & 15) * 4);
                         const float a2 = *(const float*)(x_l + (r + 2) * x_bytes + pix * XP + (r32 & 15) * 4);
@@ -996,10 +1083,20 @@ hipError_t launch_conv1_gram_stats(int dtype, const Conv1GramStatsArgs& a, hipSt
 }
 
 template <typename T, bool XS = false>
-static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
+static hipError_t c1lin_T(const Conv1WgradLinArgs& a0, hipStream_t s) {
     constexpr int SZ = sizeof(T);
-    const int Wp = (a.W + 15) & ~15;
-    size_t lds = 2 * (size_t)Wp * 32 * SZ + 4 * (size_t)((((Wp + 4) * 4 * SZ) + 15) & ~15);
+    Conv1WgradLinArgs a = a0;
+    int Wp = (a.W + 15) & ~15;
+    auto images = [](int wp) { return 2 * (size_t)wp * 32 * SZ + 4 * (size_t)((((wp + 4) * 4 * SZ) + 15) & ~15); };
+    size_t lds = images(Wp);
+    if (XS && lds > 80 * 1024) {     // fp32-wide row images: column segments, so that two workgroups share a CU
+        static const int want = getenv("Y2_CONV1_LIN_NSEG") ? atoi(getenv("Y2_CONV1_LIN_NSEG")) : 2;    // (A/B knob)
+        a.nseg = want < 1 ? 1 : (want > 8 ? 8 : want);
+        a.ws = ((a.W + a.nseg - 1) / a.nseg + 15) & ~15;
+        while (a.nseg > 1 && (a.nseg - 1) * a.ws >= a.W) --a.nseg;     // no empty segment
+        if (a.nseg == 1) a.ws = 0;
+        else lds = images(Wp = a.ws);
+    }
     size_t red = 4 * (size_t)kLinAcc * sizeof(float);
     const size_t red2 = 2 * (size_t)kLinThreads * (16 / SZ) * sizeof(float);
     if (red < red2) red = red2;
@@ -1016,7 +1113,7 @@ static hipError_t c1lin_T(const Conv1WgradLinArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr[form] = lds;
     }
-    const int prs = a.N * (a.H / 2);
+    const int prs = a.N * (a.H / 2) * (a.nseg > 1 ? a.nseg : 1);
     const int nb = prs < 512 ? prs : 512;
     float* part = a.acc + (size_t)kLinMid * kLinAcc;        // [nb][kLinAcc] behind the slice sums
     if (a.nblocks_out) *a.nblocks_out = nb;

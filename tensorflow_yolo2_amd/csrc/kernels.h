@@ -198,6 +198,9 @@ struct Conv1WgradLinArgs {
     int* nblocks_out;           // host: number of partial records written
     int N, H, W;
     int xs = 0;                 // f16x2 mode (T = float kernel): X(dz) and G from split-operand f16 products (Conv1Args::xs)
+    // set by the launcher: a row pair is worked in nseg column segments of ws pixels (a multiple of 16) so that the LDS row
+    // images of the fp32-wide form leave room for two workgroups per CU
+    int nseg = 1, ws = 0;
 };
 struct Conv1DwFinalizeArgs {
     const float* acc;           // the 16 slice sums (added here)

@@ -261,7 +261,9 @@ static void plan(y2_ctx* c) {
         static const bool keep_ysel = getenv("Y2_CONV1_YSEL") != nullptr;
         // (f16x2: the layer runs the f32 kernels, which are bound by their fp32 matrix instructions -- the 3-bit form was tried
         //  there and changes nothing: 401 / 1155 us forward / backward either way)
-        const bool nosel = lin1 && dtype_plain(c->dtype) != 0 && !keep_ysel;
+        static const bool xs_off = getenv("Y2_CONV1_NO_XS") != nullptr;
+        static const bool xs_sel = getenv("Y2_CONV1_XS_YSEL") != nullptr;
+        const bool nosel = lin1 && (dtype_plain(c->dtype) != 0 || (dtype_split(c->dtype) && !xs_off && !xs_sel)) && !keep_ysel;
         y.ysel = (y.pool && (!y.first3 || (lin1 && !nosel))) ? take((size_t)c->N * y.Ho * y.Wo * y.ldy * sz + 256) : 0;
         y.idx0 = lin1 ? take((size_t)c->N * y.Ho * y.Wo * (y.ldy * sz / 16) * (nosel ? sizeof(unsigned) : sizeof(unsigned short)) + 256) : 0;
         if (lin1) c->o_lin = take(conv1_wgrad_lin_scratch_floats() * sizeof(float));

@@ -122,6 +122,9 @@ STACKS = [
     ("no-image-layer", [(3, 32, 64, 1), (3, 64, 128, 0), (1, 128, 64, 0), (3, 64, 32, 0)], 2, 32, None),
     ("wide", [(3, 128, 256, 1), (3, 256, 512, 0), (1, 512, 256, 0), (3, 256, 512, 1), (3, 512, 1024, 0), (1, 1024, 30, 0)], 8, 28, None),
     ("avgpool-tail", [(3, 3, 32, 1), (3, 32, 64, 1), (1, 64, 1000, 0)], 4, 28, 7),
+    # a 400-wide image: the first layer's linear-form backward works a row pair in two column segments of 208 pixels (its
+    # fp32-wide LDS row images leave room for two workgroups per CU), the second one narrower (conv1_wgrad.hip nseg / ws)
+    ("pooled-first-layer-two-segments", [(3, 3, 32, 1), (3, 32, 64, 1), (1, 64, 30, 0)], 1, 400, None),
 ]
 
 
