@@ -238,4 +238,14 @@ __host__ __device__ inline size_t bbody_pixels(int N, int H, int W) {
     return (size_t)N * (H + 1) * (W + 1) + (size_t)(W + 1) + 1;
 }
 
+// window-major pixel order of a pooled layer's convolution tiles (kernels.h ConvArgs::aff_pool): position q of the
+// order -> NHW pixel index; H and W even
+Y2_DEV int pool_order_pixel(int q, int H, int W) {
+    const int Wo = W >> 1, Ho = H >> 1;
+    const int win = q >> 2, d = q & 3;
+    const int t = win / Wo, wo = win - t * Wo;
+    const int n = t / Ho, ho = t - n * Ho;
+    return (n * H + 2 * ho + (d >> 1)) * W + 2 * wo + (d & 1);
+}
+
 }  // namespace y2

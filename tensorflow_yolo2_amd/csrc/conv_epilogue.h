@@ -150,6 +150,34 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
             sc[e] = cv ? a.aff_scale[cch + e] : 0.f;
             sh[e] = cv ? a.aff_shift[cch + e] : 0.f;
         }
+        if (a.aff_pool) {
+            // pooled layer (ConvArgs::aff_pool): the patch rows are in window-major order, four consecutive rows = one
+            // 2x2 window; the maximum on z = y * scale + shift, then the activation (bn.hip pool_window, bit for bit)
+            constexpr int NWIN = TP * 32 / 4;              // windows of this wave
+            const int Ho = a.H >> 1, Wo = a.W >> 1;
+#pragma unroll
+            for (int it = 0; it * RPIe < NWIN; ++it) {
+                const int wrow = it * RPIe + prow0;
+                const uint32_t u = (uint32_t)(mw0 >> 2) + (uint32_t)wrow;          // window index (n, ho, wo)
+                if (wrow < NWIN && (int)(4 * u) < a.M && cv) {
+                    const char* pr = ew + 4 * wrow * EROW + ch * 16;
+                    const Chunk<T> v0 = ld_chunk<T>(pr), v1 = ld_chunk<T>(pr + EROW), v2 = ld_chunk<T>(pr + 2 * EROW),
+                                   v3 = ld_chunk<T>(pr + 3 * EROW);
+                    const uint32_t t = u / (uint32_t)Wo, wo = u - t * (uint32_t)Wo;
+                    const uint32_t n = t / (uint32_t)Ho, ho = t - n * (uint32_t)Ho;
+                    Chunk<T> o;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const float z0 = Elem<T>::to_f32(v0.v[e]) * sc[e] + sh[e], z1 = Elem<T>::to_f32(v1.v[e]) * sc[e] + sh[e];
+                        const float z2 = Elem<T>::to_f32(v2.v[e]) * sc[e] + sh[e], z3 = Elem<T>::to_f32(v3.v[e]) * sc[e] + sh[e];
+                        const float zm = fmaxf(fmaxf(fmaxf(-INFINITY, z0), z1), fmaxf(z2, z3));
+                        o.v[e] = Elem<T>::from_f32(leaky_s(zm, a.aff_slope));
+                    }
+                    st_chunk<T>((char*)a.aff_out + (bpix((int)n, (int)ho, (int)wo, Ho, Wo) * a.ldy + cch) * SZ, o);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int prow = it * RPIe + prow0;

@@ -429,6 +429,17 @@ bool conv_affine_ok(int dtype, const ConvArgs& a) {
     return a.M > 0 && (unsigned)a.M < 0x7FFFFFFFu;
 }
 
+// Pooled layers in the fold (ConvArgs::aff_pool): the conv_haloq kernels on the bordered image (their tiles take any
+// pixel order inside a contiguous run of cells); whole windows only; not the K-split small launches.
+// Y2_NO_POOL_FOLD=1: A/B switch.
+bool conv_affine_pool_ok(int dtype, const ConvArgs& a) {
+    static const bool off = getenv("Y2_NO_POOL_FOLD") != nullptr;
+    static const bool compact = getenv("Y2_HALO_COMPACT") && atoi(getenv("Y2_HALO_COMPACT")) != 0;
+    if (off || compact || !conv_affine_ok(dtype, a)) return false;
+    if (a.taps != 9 || (a.H & 1) || (a.W & 1) || a.M < 384 * 8) return false;
+    return conv_filter_layout(a.taps, a.W, a.C * dtype_kbytes(dtype), a.Cout, a.M, 0, (int)dtype_size(dtype), 0) != 0;
+}
+
 // Kernel policy (measured on MI355X, scripts/bench_conv.py and profile_layers.py):
 //   3x3, rows <= 52 / 104 / the 208-wide 32-channel dgrad : conv_haloq (halo image + register filters)
 //   3x3, what conv_haloq's K-chunk sizes do not divide     : conv_halo  (halo image + LDS filter ring)

@@ -107,9 +107,11 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         const int h = rem / a.W, ww = rem - h * a.W;
         return (long)bpix(n, h, ww, a.H, a.W);
     };
+    // pooled layers in the inference fold (ConvArgs::aff_pool): the tile's positions are in window-major order
+    auto pixq = [&](int q) -> int { return a.aff_pool ? pool_order_pixel(q, a.H, a.W) : q; };
     const int p_last = (m0 + BP - 1 < a.M) ? m0 + BP - 1 : a.M - 1;
-    const long lo = CPT ? 0 : bpos(m0) - pitch - 1;
-    const int nrows = CPT ? arows : (int)(bpos(p_last) + pitch + 1 - lo) + 1;
+    const long lo = CPT ? 0 : bpos(pixq(m0)) - pitch - 1;
+    const int nrows = CPT ? arows : (int)(bpos(pixq(p_last)) + pitch + 1 - lo) + 1;
     const int npieces = (nrows + RPI - 1) / RPI;
     const int abytes = arows * BKB;
     const int rowbytes = a.C * SZ;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
             rowtlB[j] = (p - m0) * BKB;
         } else {
             fmk[j] = 0;
-            rowtlB[j] = (int)(bpos(p) - pitch - 1 - lo) * BKB;
+            rowtlB[j] = (int)(bpos(pixq(p)) - pitch - 1 - lo) * BKB;
         }
     }
     // LDS byte offset (from smem) and swizzle key of every pixel fragment row for tap (kh_, kw_) of chunk cc.  A tap that
@@ -438,9 +440,11 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         const int h = rem / a.W, ww = rem - h * a.W;
         return (long)bpix(n, h, ww, a.H, a.W);
     };
+    // pooled layers in the inference fold (ConvArgs::aff_pool): the tile's positions are in window-major order
+    auto pixq = [&](int q) -> int { return a.aff_pool ? pool_order_pixel(q, a.H, a.W) : q; };
     const int p_last = (m0 + BP - 1 < a.M) ? m0 + BP - 1 : a.M - 1;
-    const long lo = CPT ? 0 : bpos(m0) - pitch - 1;
-    const int nrows = CPT ? arows : (int)(bpos(p_last) + pitch + 1 - lo) + 1;
+    const long lo = CPT ? 0 : bpos(pixq(m0)) - pitch - 1;
+    const int nrows = CPT ? arows : (int)(bpos(pixq(p_last)) + pitch + 1 - lo) + 1;
     const int npieces = (nrows + RPI - 1) / RPI;
     const int abytes = arows * BKB;
     const int rowbytes = a.C * SZ;
@@ -525,7 +529,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
             rowtlB[j] = (p - m0) * BKB;
         } else {
             fmk[j] = 0;
-            rowtlB[j] = (int)(bpos(p) - pitch - 1 - lo) * BKB;
+            rowtlB[j] = (int)(bpos(pixq(p)) - pitch - 1 - lo) * BKB;
         }
     }
     // LDS byte offset (from smem) and swizzle key of every pixel fragment row for tap (kh_, kw_) of chunk cc.  A tap that
@@ -656,7 +660,16 @@ static bool halo_compact() {
     static const bool on = getenv("Y2_HALO_COMPACT") && atoi(getenv("Y2_HALO_COMPACT")) != 0;
     return on;
 }
-static int haloq_rows(int H, int W, int BP, int RPI) {
+// pool: the tile's pixels in window-major order (ConvArgs::aff_pool) -- a run of BP / 4 windows touches at most
+// ceil((Wo - 1 + BP / 4) / Wo) row pairs
+static int haloq_rows(int H, int W, int BP, int RPI, int pool = 0) {
+    if (pool) {
+        const int pitch = W + 1, Wo = W / 2, Ho = H / 2, nwin = BP / 4;
+        const int pairs = (nwin + 2 * Wo - 2) / Wo;
+        const int img_cross = (nwin - 1) / (Ho * Wo) + 1;
+        const int nrows = 2 * pairs * pitch + img_cross * pitch + 2 * (pitch + 1) + 1;
+        return (nrows + RPI - 1) / RPI * RPI;
+    }
     const int pitch = W + 1;
     const int rows_cross = (BP - 1) / W + 1;
     const int img_cross = (BP - 1) / (H * W) + 1;
@@ -676,7 +689,8 @@ static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
     typedef EpiCfg<YT_, WP, WC, TP, EPI2 ? TC / 2 : TC> Epi;     // (EPI2: the epilogue runs in two passes, conv_haloq16_kernel)
     constexpr int BP = WP * TP * 32, BC = WC * TC * 32, RPI = 64 / (BKB / 16);
     if ((a.C * (int)sizeof(typename Types<T>::op_t)) % BKB != 0) return hipErrorInvalidValue;
-    const int arows = CPT ? haloq_rows_compact(a.W, BP, TAPS) : haloq_rows(a.H, a.W, BP, RPI);
+    const int arows = CPT ? haloq_rows_compact(a.W, BP, TAPS) : haloq_rows(a.H, a.W, BP, RPI, a.aff_pool);
+    if (CPT && a.aff_pool) return hipErrorInvalidValue;
     if (CPT && arows > 0xFFFF) return hipErrorOutOfMemory;
     size_t lds = haloq_lds<BKB>(arows, ADB, CPT);
     if (lds < (size_t)Epi::LDS) lds = Epi::LDS;
@@ -706,7 +720,7 @@ static hipError_t haloq_pick(const ConvArgs& a, hipStream_t s) {
             return haloq_launch<T, WP, WC, TP, TC, BKB, true, M16, true>(a, s);
         return haloq_launch<T, WP, WC, TP, TC, BKB, false, M16, true>(a, s);
     }
-    const size_t arows = haloq_rows(a.H, a.W, BP, RPI);
+    const size_t arows = haloq_rows(a.H, a.W, BP, RPI, a.aff_pool);
     if (nchunks > 1 && 2 * arows * BKB <= 150 * 1024) return haloq_launch<T, WP, WC, TP, TC, BKB, true, M16, false>(a, s);
     return haloq_launch<T, WP, WC, TP, TC, BKB, false, M16, false>(a, s);
 }

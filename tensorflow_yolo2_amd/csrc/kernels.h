@@ -54,6 +54,11 @@ struct ConvArgs {
     float aff_slope = 0.1f;           // activation slope of this layer
     uint32_t aff_magW = 0, aff_magH = 0;   // m / W = (m * magW) >> shW for m < 2^31 (Granlund-Montgomery), same for H
     int aff_shW = 0, aff_shH = 0;
+    // POOLED layers in the fold (round 5; conv_haloq kernels, even H and W): the tile's pixels run in WINDOW-MAJOR order
+    // q = ((n Ho + ho) Wo + wo) 4 + 2 dh + dw (common.h pool_order_pixel), so a tile holds whole 2x2 windows -- four
+    // consecutive rows of the epilogue patch -- and the stored value is leaky(max over the window of T(conv + b) * scale
+    // + shift) at the pooled position of aff_out [N][H/2+2][W/2+2][ldy]: bn_act_kernel's pool_window arithmetic
+    int aff_pool = 0;
     // K split over workgroups for launches of a few hundred to a few thousand pixels (conv_haloq.hip: haloq_ks): the
     // caller lends ks_floats floats of scratch; the launcher decides whether and how deep to split (ks_splits is its own)
     float* ks_scratch = nullptr;
@@ -77,6 +82,8 @@ inline void conv_set_affine(ConvArgs& a, const float* scale, const float* shift,
 }
 // which launches take the folded form (else: y + the bn_act pass)
 bool conv_affine_ok(int dtype, const ConvArgs& a);
+// ... and which POOLED layers do (ConvArgs::aff_pool; conv_affine_ok holds too)
+bool conv_affine_pool_ok(int dtype, const ConvArgs& a);
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
 hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels); // + filters via registers

@@ -738,10 +738,12 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             // inference statistics, no pool, a consumer layer: scale / shift / leaky ride in the conv epilogue and the
             // activation goes straight into the consumer's bordered input (no y, no bn_act pass).  Training
             // bindings keep y: a later y2_backward of a frozen-core graph reads it.
-            if (!training && !y.pool && l + 1 < nl && !c->bound_training && y.ldy == c->L[l + 1].cin_s &&
-                conv_affine_ok(c->dtype, a)) {
+            // (round 5: pooled layers on the conv_haloq kernels too -- window-major tiles, ConvArgs::aff_pool)
+            if (!training && l + 1 < nl && !c->bound_training && y.ldy == c->L[l + 1].cin_s &&
+                (y.pool ? conv_affine_pool_ok(c->dtype, a) : conv_affine_ok(c->dtype, a))) {
                 conv_set_affine(a, scale, shift, c->ws + c->L[l + 1].xin + c->in_geom(l + 1).base_off(sz));
                 a.aff_slope = y.slope;
+                a.aff_pool = y.pool ? 1 : 0;
                 folded = true;
             }
             { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }
