@@ -97,7 +97,15 @@ class ResNet50Yolo:
         self.fuse_fc1 = (dtype != "f32" and not os.environ.get("Y2_RESNET_NO_FC1_FUSE")) if fuse_fc1 is None else \
             (bool(fuse_fc1) and dtype != "f32")
         if self.fuse_fc1:
-            self.layout = [e for e in self.layout if e[0] != "yolo_fc1/weights"] + [e for e in self.layout if e[0] == "yolo_fc1/weights"]
+            rest = [e for e in self.layout if e[0] != "yolo_fc1/weights"]
+            # the 1.64 GB matrix starts on a 256-byte boundary of the flat buffer: fc.hip takes 16-byte loads only from
+            # 16-byte-aligned rows (round 5: behind yolo_fc2/biases' 1470 floats it sat at offset 2 mod 4 and the forward
+            # and dx products ran their scalar-load forms: dx 666 us instead of 440).  A layout-only slot of zeros: its
+            # gradient stays zero, Adam leaves it at zero.
+            pad = (-sum(int(np.prod(sh)) for (_n, sh, t) in rest if t)) % 64
+            if pad:
+                rest.append(("yolo_fc1/_align" + HIDDEN, (pad,), True))
+            self.layout = rest + [e for e in self.layout if e[0] == "yolo_fc1/weights"]
         n_train = sum(int(np.prod(s)) for (_n, s, t) in self.layout if t)
         n_state = sum(int(np.prod(s)) for (_n, s, t) in self.layout if not t)
         self.params = torch.zeros(n_train, dtype=torch.float32, device=self.device)      # ONE flat buffer: one Adam
