@@ -127,6 +127,44 @@ def trace(d, out, steps):
     print("wrote", out, "union %.1f us over %d launches, span %.1f us" % (union / 1e3, len(iv), span / 1e3))
 
 
+def step_between(d, out, marker):
+    """one steady-state step = the dispatches between the last two occurrences of a kernel that runs once per step
+    (ResNet swap: rn_conv7_fwd_kernel): dispatch count, span, busy time (union of all intervals), per-kernel totals"""
+    rows = [r for r in csv.DictReader(open(find(d, "*_kernel_trace.csv"))) if r["Kind"] == "KERNEL_DISPATCH"]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+    if len(marks) < 2:
+        raise SystemExit("marker kernel seen fewer than twice")
+    step = rows[marks[-2]:marks[-1]]
+    t0 = int(step[0]["Start_Timestamp"])
+    span = int(rows[marks[-1]]["Start_Timestamp"]) - t0
+    iv = sorted((int(r["Start_Timestamp"]) - t0, int(r["End_Timestamp"]) - t0) for r in step)
+    union, cur0, cur1 = 0, None, None
+    for a, b in iv:
+        if cur1 is None or a > cur1:
+            if cur1 is not None:
+                union += cur1 - cur0
+            cur0, cur1 = a, b
+        elif b > cur1:
+            cur1 = b
+    union += cur1 - cur0
+    acc = {}
+    for r in step:
+        k = short(r["Kernel_Name"])
+        v = acc.setdefault(k, [0, 0])
+        v[0] += 1
+        v[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    with open(out, "w", newline="") as f:
+        f.write("# one step of %s (between two %s): %d dispatches, span %.1f us, busy (union of intervals) %.1f us, sum of "
+                "durations %.1f us\n" % (os.path.basename(d.rstrip("/")), marker, len(step), span / 1e3, union / 1e3,
+                                         sum(b - a for a, b in iv) / 1e3))
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls_per_step", "total_us", "avg_us"])
+        for k, (n, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, n, "%.1f" % (t / 1e3), "%.2f" % (t / 1e3 / n)])
+    print("wrote", out, "%d dispatches, span %.1f us, busy %.1f us" % (len(step), span / 1e3, union / 1e3))
+
+
 def sq(d, out):
     acc = {}
     names = []
@@ -187,6 +225,8 @@ def gbps(stats_csv, hbm_json, out):
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+    elif sys.argv[1] == "step":
+        step_between(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "sq":
         sq(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "gbps":
