@@ -347,7 +347,7 @@ static int fc_forward_T(const float* x, const float* w, const float* bias, float
     slices = (ksteps + sps - 1) / sps;
     const size_t MN = (size_t)M * N;
     float* part = (float*)op_scratch(s, (size_t)slices * MN * sizeof(float));
-    if (!part) return fc_fail(Y2_ERR_HIP, "fully connected: no scratch memory for the split-K partials");
+    if (!part) return op_scratch_error();     // (op_scratch left the reason in the error state)
     const dim3 grid((nwt + 3) / 4, slices);
     const bool vec = aligned16(x, nullptr);
     const int mt = (M + 31) / 32;

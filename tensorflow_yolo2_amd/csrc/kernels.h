@@ -488,6 +488,7 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t s);
 
 // per-(device, stream) scratch of the graph-level operators (split partial sums); grows on demand, never shrinks
 void* op_scratch(hipStream_t s, size_t bytes);
+int op_scratch_error();      // code of the last null return of op_scratch on this thread (its message is already in y2_last_error)
 int* op_counters(hipStream_t s, size_t ints);      // zeroed, self-cleaning tile counters (WgradArgs::tile_cnt)
 constexpr size_t kWgCntInts = 65536;
 

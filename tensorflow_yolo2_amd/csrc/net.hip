@@ -893,7 +893,16 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         static const bool off = getenv("Y2_NO_WGRAD_OVERLAP") != nullptr;
         if (off) c->overlap_wgrad = 0;
         else {
-            HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            // Y2_SIDE_PRIORITY=low|high: the weight-gradient stream at the device's least / greatest queue priority (A/B:
+            // the dgrad -> BN-backward chain on the caller's stream is the critical path of the backward pass)
+            static const char* prio = getenv("Y2_SIDE_PRIORITY");
+            int least = 0, greatest = 0;
+            if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+                HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio[0] == 'l' ? least : greatest));
+            } else {
+                (void)hipGetLastError();
+                HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            }
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
         }

@@ -58,24 +58,38 @@ static inline unsigned grid_for(size_t total, unsigned cap = 16384) {
 // a NEW buffer; the old ones stay alive until the process ends (they are a few MB).  Growth during a stream capture
 // is refused (hipMalloc is not capturable and the graph would keep the too-small pointer): the caller fails loudly.
 namespace y2 {
+// A null return leaves the reason in the library's error state (y2_last_error) and its code in op_scratch_error():
+// callers return THAT code and do not overwrite the message ("scratch would have to grow during a stream
+// capture" used to be replaced by a generic "no scratch memory").
+static thread_local int g_scratch_err = Y2_OK;
+int op_scratch_error() { return g_scratch_err != Y2_OK ? g_scratch_err : set_error(Y2_ERR_HIP, "operator scratch: allocation failed"); }
 void* op_scratch(hipStream_t s, size_t bytes) {
     static std::mutex mu;
     static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> pool;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    g_scratch_err = Y2_OK;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        g_scratch_err = set_error(Y2_ERR_HIP, "operator scratch: no current device");
+        return nullptr;
+    }
     std::lock_guard<std::mutex> lock(mu);
     auto& e = pool[std::make_pair(dev, s)];
     if (e.second < bytes) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
         if (cap != hipStreamCaptureStatusNone) {
-            set_error(Y2_ERR_STATE, "operator scratch would have to grow during a stream capture: run one eager step first");
+            g_scratch_err = set_error(Y2_ERR_STATE, "operator scratch would have to grow during a stream capture: run one eager step first");
             return nullptr;
         }
         // generous first size: the largest request of the ResNet-50 swap at batch 32 is < 8 MB
         const size_t want = bytes < (16u << 20) ? (16u << 20) : bytes + bytes / 2;
         void* p = nullptr;
-        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            g_scratch_err = set_error(Y2_ERR_HIP, "operator scratch: hipMalloc failed (out of device memory)");
+            return nullptr;
+        }
         e.first = p;          // the previous buffer (if any) is deliberately leaked: a graph may still replay into it
         e.second = want;
     }
@@ -823,7 +837,7 @@ int y2_maxpool3x3s2_backward(const float* x, const float* dy, float* dx, int N, 
     if (!x || !dy || !dx) return rfail(Y2_ERR_ARG, "null tensor");
     const size_t total = (size_t)N * H * W * C, outs = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
     unsigned char* arg = (unsigned char*)op_scratch((hipStream_t)stream, outs);
-    if (!arg) return rfail(Y2_ERR_HIP, "max pool backward: no scratch memory for the arg-max bytes");
+    if (!arg) return op_scratch_error();      // (op_scratch left the reason in the error state)
     hipLaunchKernelGGL(rn_maxpool3_arg_kernel, dim3(grid_for(outs)), dim3(256), 0, (hipStream_t)stream, x, arg, N, H, W, C);
     hipLaunchKernelGGL(rn_maxpool3_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, arg, dy, dx, N, H, W, C);
     RCHK(hipGetLastError());
@@ -849,7 +863,7 @@ int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int
     const int rows = N * ((H + 1) / 2);
     const int blocks = rows < 512 ? rows : 512;
     float* part = (float*)op_scratch(s, (size_t)blocks * 147 * Cout * sizeof(float));
-    if (!part) return rfail(Y2_ERR_HIP, "no scratch memory for the filter-gradient partials");
+    if (!part) return op_scratch_error();
     hipLaunchKernelGGL(rn_conv7_wgrad_kernel, dim3(blocks), dim3(kC7Threads), lds, s, x, dy, part, N, H, W, Cout);
     hipLaunchKernelGGL(rn_sum_partials_kernel, dim3((147 * Cout + 63) / 64), dim3(256), 0, s, part, dw, blocks, 147 * Cout);
     RCHK(hipGetLastError());

@@ -65,8 +65,20 @@ class ForwardGraph:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, stream=self._stream):
             net.forward(self.input, is_training_core, is_training_head, out=self.output, update_moving=False)
+        self._modes = (is_training_core, is_training_head)
+        self._gen = net._host_param_gen
 
     def replay(self):
+        # load_params / init_params / params_changed re-pack the filters at the NEXT eager forward, outside any graph
+        # (a replay silently ran the packs baked in at capture time).  One eager forward on the capture
+        # stream brings the packed copies the graph reads up to date; the fused optimizer steps re-pack on the device
+        # into those same buffers and need nothing.
+        if self.net._host_param_gen != self._gen:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                self.net.forward(self.input, self._modes[0], self._modes[1], out=self.output, update_moving=False)
+            torch.cuda.current_stream().wait_stream(self._stream)
+            self._gen = self.net._host_param_gen
         self._graph.replay()
         return self.output
 
@@ -82,6 +94,7 @@ class Network:
                  tail_k=7, training=True, device="cuda:0", grad_scale=None, bessel=False, share_with=None,
                  buffers=None):
         self.lib = _lib.load()
+        self._host_param_gen = 0        # bumped whenever the parameters change on a path that re-packs at the next forward
         if not torch.cuda.is_available():
             raise _lib.Y2Error("no MI355X visible: tensorflow_yolo2_amd has no CPU path")
         self.device = torch.device(device)
@@ -208,6 +221,7 @@ class Network:
     def init_params(self, seed=0):
         """darknet.py:10-17 initial values, generated on the device."""
         check(self.lib.y2_init_params(self.h, seed, _stream()))
+        self._host_param_gen += 1
 
     def load_params(self, layers):
         """layers: list of dicts with numpy arrays W, b, gamma, beta, moving_mean, moving_var."""
@@ -217,6 +231,7 @@ class Network:
             for k in PARAM_KEYS + STATE_KEYS:
                 v[k].copy_(torch.as_tensor(np.asarray(p[k], np.float32)).to(self.device))
         check(self.lib.y2_params_changed(self.h))
+        self._host_param_gen += 1
         if self.store is not None:
             self.store.version += 1
 
@@ -232,6 +247,7 @@ class Network:
 
     def params_changed(self):
         check(self.lib.y2_params_changed(self.h))
+        self._host_param_gen += 1
 
     # ---- execution -------------------------------------------------------
     def forward(self, images, is_training_core=True, is_training_head=True, out=None, update_moving=False, join=None):
@@ -263,7 +279,8 @@ class Network:
         `.input` (float32 NHWC, or uint8 BGR with uint8=True), call `.replay()`, read `.output` ([N,S,S,C] fp32; valid
         after a synchronisation of the current stream).  Two eager passes run first on the capture stream (filter packs,
         kernel attributes: neither may happen inside a capture).  The moving statistics are never updated by a replay.
-        A later load_params / optimizer step re-packs the filters outside the graph: call forward_graph again."""
+        After a later load_params / init_params / params_changed the next replay first refreshes the packed filters
+        with one eager forward (ForwardGraph.replay)."""
         return ForwardGraph(self, is_training_core, is_training_head, uint8)
 
     def update_moving_stats(self):

@@ -58,3 +58,32 @@ def test_forward_graph_replays_the_detection_forward():
             torch.cuda.synchronize()
             assert torch.equal(got_u, want_u), (dtype, i, "uint8")
         assert torch.equal(net.state, state0)
+
+
+def test_forward_graph_follows_a_parameter_reload():
+    """a ForwardGraph replays the filter packs of its capture; load_params / init_params re-pack only at the
+    next eager forward.  The replay now refreshes the packs first: a graph captured on one set of parameters gives the
+    eager bits of ANOTHER set loaded afterwards, with no eager forward in between."""
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    core = [(k, ci, co, int(p)) for (k, ci, co, p) in R.scaled_spec(R.CORE_SPEC, 4)]
+    head = [(3, core[-1][2], 256, 0), (1, 256, 30, 0)]
+    size = 224
+    net = E.Network(core + head, 1, size, size, dtype="f16", core_layers=len(core), training=False)
+    net.init_params(3)
+    g = net.forward_graph(False, True)
+    x = torch.as_tensor(synthetic.images(1, size, 60)).cuda()
+    first = g(x).clone()
+    torch.cuda.synchronize()
+    other = E.Network(core + head, 1, size, size, dtype="f16", core_layers=len(core), training=False)
+    other.init_params(4)
+    net.load_params(other.export_params())
+    got = g(x).clone()                       # no eager forward since the reload
+    torch.cuda.synchronize()
+    want = other.forward(x, False, True)
+    torch.cuda.synchronize()
+    assert not torch.equal(first, want)
+    assert torch.equal(got, want)
+    got2 = g(x).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got2, want)
