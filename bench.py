@@ -540,6 +540,7 @@ def main():
                     help="detector: the reference's Darknet-19 grid detector (the headline); yolov2: the north star's "
                          "anchor model (passthrough + anchor loss), not in the reference")
     ap.add_argument("--graph", action="store_true", help="resnet50: replay the step from one HIP graph")
+    ap.add_argument("--own-stream", action="store_true", help="run on a torch side stream instead of the default (NULL) stream")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (single-GPU functional test)")
     ap.add_argument("--all-ranks-on-gpu0", action="store_true", help="functional test of the N>1 path on one GPU")
     args = ap.parse_args()
@@ -574,6 +575,8 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     device = "cuda:%d" % local_rank
     torch.cuda.set_device(device)
+    if args.own_stream:
+        torch.cuda.set_stream(torch.cuda.Stream(device=device))
 
     size, bs = args.image_size, args.batch
     S = size // 32

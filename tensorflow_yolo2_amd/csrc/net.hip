@@ -897,7 +897,15 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
             // the dgrad -> BN-backward chain on the caller's stream is the critical path of the backward pass)
             static const char* prio = getenv("Y2_SIDE_PRIORITY");
             int least = 0, greatest = 0;
-            if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            // Y2_SIDE_CUS=<n>: the weight-gradient stream may use only the first n compute units of the mask (A/B: the
+            // small kernels of the dgrad -> BN-backward chain wait for wave slots behind its long-running workgroups).
+            // Such a stream synchronises with the NULL stream: the caller's stream must be another one.
+            static const int side_cus = getenv("Y2_SIDE_CUS") ? atoi(getenv("Y2_SIDE_CUS")) : 0;
+            if (side_cus > 0) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < side_cus && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+                HIPCHK(hipExtStreamCreateWithCUMask(&c->side, 8, mask));
+            } else if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
                 HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio[0] == 'l' ? least : greatest));
             } else {
                 (void)hipGetLastError();
