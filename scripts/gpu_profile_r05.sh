@@ -2,9 +2,9 @@
 # Round-5 profile recipe (run through gpurun from the repo root).  As gpu_profile_r04.sh for the headline (C4) command --
 # kernel trace + stats with the production streams and serialised, SQ / FETCH / WRITE counter passes, per-layer tables --
 # plus the split-operand mode (--dtype f16x2: trace + stats + per-layer table), the exact-f32 mode's per-layer table, and
-# the ResNet swap's kernel statistics (batch 32).
+# the ResNet swap's kernel table of one applied, graph-replayed step (batch 32).
 # rocprofv3 rule of this pool: the program goes directly after `--`; --pmc passes carry no other trace domain.
-TAG=${1:-r05}
+TAG=${1:-r05e}
 PMC=${2:-1}          # 0: skip the counter passes
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
@@ -13,7 +13,7 @@ B="python3 bench.py --steps $K --warmup $W --no-cpu-baseline --no-f32-mode --no-
 X2="python3 bench.py --dtype f16x2 --steps $K --warmup $W --no-cpu-baseline --no-f32-mode --no-extra-legs --kernel-events off --sustain-steps 0 --fed-steps 0"
 C3="python3 bench.py --model classifier"
 C2="python3 bench.py --forward-only --batch 32 --steps $K --warmup $W --no-cpu-baseline --no-f32-mode --kernel-events off --sustain-steps 0"
-RN="python3 bench.py --model resnet50 --batch 32 --steps $K --warmup $W --no-cpu-baseline"
+RN="python3 bench.py --model resnet50 --batch 32 --graph --steps 6 --warmup 4 --no-cpu-baseline"
 O=gpurun_out
 rm -rf $O/${TAG}_trace_overlap $O/${TAG}_trace_serial $O/${TAG}_trace_f16x2 $O/${TAG}_trace_c3 $O/${TAG}_trace_c2 $O/${TAG}_trace_rn $O/${TAG}_sq $O/${TAG}_sq2 $O/${TAG}_fetch $O/${TAG}_write
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace_overlap -o run --output-format csv -- $B > $O/${TAG}_trace_overlap.log 2>&1
@@ -32,7 +32,8 @@ python3 scripts/summarize_profiles.py stats $O/${TAG}_trace_f16x2 $O/${TAG}_stat
 python3 scripts/summarize_profiles.py trace $O/${TAG}_trace_f16x2 $O/${TAG}_timeline_f16x2.csv $ALL
 python3 scripts/summarize_profiles.py stats $O/${TAG}_trace_c3 $O/${TAG}_stats_c3.csv 23        # 3 warm-up + 20 timed steps
 python3 scripts/summarize_profiles.py stats $O/${TAG}_trace_c2 $O/${TAG}_stats_c2_forward.csv $ALL
-python3 scripts/summarize_profiles.py stats $O/${TAG}_trace_rn $O/${TAG}_stats_resnet50_bs32.csv $ALL
+# one APPLIED graph-replayed step (bench settles the loss scale first): the dispatches between the last two root convolutions
+python3 scripts/summarize_profiles.py step $O/${TAG}_trace_rn $O/${TAG}_resnet50_step.csv rn_conv7_fwd_kernel
 python3 scripts/profile_layers.py > $O/${TAG}_layers_per_layer_us.txt 2>&1
 DTYPE=f16x2 python3 scripts/profile_layers.py > $O/${TAG}_layers_f16x2.txt 2>&1
 DTYPE=f32 python3 scripts/profile_layers.py > $O/${TAG}_layers_f32.txt 2>&1

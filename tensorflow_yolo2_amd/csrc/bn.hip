@@ -340,7 +340,26 @@ Y2_DEV void fin_slab_merge(const BnFinalizeArgs& f, int cbase, double (*red)[kSl
     const int ci = cv ? cc : 0;
     const double sft = f.P > 0 ? (double)f.part_mean[ci] : 0.0;
     double n = 0.0, A = 0.0, B = 0.0;
-    for (int p = sl; p < f.P; p += 4) {
+    int p = sl;
+    for (; p + 28 < f.P; p += 32) {           // eight list steps' loads up front (every block of the slab repeats this merge)
+        float rk[8], rm[8], r2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t q = (size_t)(p + 4 * u) * f.ldp + ci;
+            rk[u] = f.part_cnt[p + 4 * u];
+            rm[u] = f.part_mean[q];
+            r2[u] = f.part_m2[q];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double k = rk[u];
+            const double d = (double)rm[u] - sft;
+            n += k;
+            A += k * d;
+            B += (double)r2[u] + k * d * d;
+        }
+    }
+    for (; p < f.P; p += 4) {
         const size_t q = (size_t)p * f.ldp + ci;
         const double k = f.part_cnt[p];
         const double d = (double)f.part_mean[q] - sft;
@@ -701,16 +720,51 @@ __global__ __launch_bounds__(SLN * kFinCh) void bn_bwd_finalize_kernel(BnBwdArgs
     const int c = blockIdx.x * kFinCh + cl;
     const bool cv = c < a.C;
     const int cc = cv ? c : 0;
+    // The kernel is a chain of dependent HBM round trips on the backward critical path, run beside the weight gradients
+    // of the layer above (memory latency under that load is several times the idle one: 24 us per launch in the
+    // production step against 8 serialised): both sums' records of EIGHT list steps are requested before the first is
+    // added (16 loads in flight instead of 4).  The order of every accumulator's additions is that of the four-step
+    // loop it replaces: the sums are bit-identical.
     double t[2] = {0.0, 0.0};
-    for (int k = 0; k < 2; ++k) {
-        double v4[4] = {0, 0, 0, 0};
+    {
+        double v4[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         int p = sl;
-        for (; p + 3 * kFinSl < P; p += 4 * kFinSl) {
+        for (; p + 7 * kFinSl < P; p += 8 * kFinSl) {
+            float r[2][8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v4[u] += (double)a.psum[((size_t)(p + u * kFinSl) * 2 + k) * a.ldy + cc];
+            for (int u = 0; u < 8; ++u) {
+                const size_t q = (size_t)(p + u * kFinSl) * 2 * a.ldy + cc;
+                r[0][u] = a.psum[q];
+                r[1][u] = a.psum[q + a.ldy];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v4[0][u & 3] += (double)r[0][u];
+                v4[1][u & 3] += (double)r[1][u];
+            }
         }
-        for (; p < P; p += kFinSl) v4[0] += (double)a.psum[((size_t)p * 2 + k) * a.ldy + cc];
-        t[k] = fin_block_sum<kFinSl * kFinCh / 64>((v4[0] + v4[1]) + (v4[2] + v4[3]), red, sl, cl);
+        for (; p + 3 * kFinSl < P; p += 4 * kFinSl) {
+            float r[2][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t q = (size_t)(p + u * kFinSl) * 2 * a.ldy + cc;
+                r[0][u] = a.psum[q];
+                r[1][u] = a.psum[q + a.ldy];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v4[0][u] += (double)r[0][u];
+                v4[1][u] += (double)r[1][u];
+            }
+        }
+        for (; p < P; p += kFinSl) {
+            const size_t q = (size_t)p * 2 * a.ldy + cc;
+            v4[0][0] += (double)a.psum[q];
+            v4[1][0] += (double)a.psum[q + a.ldy];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            t[k] = fin_block_sum<kFinSl * kFinCh / 64>((v4[k][0] + v4[k][1]) + (v4[k][2] + v4[k][3]), red, sl, cl);
     }
     if (sl == 0 && cv) {
         const double m = (double)a.N * a.H * a.W;
@@ -747,7 +801,19 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
         const bool cv = cc < a.C;
         const int ci = cv ? cc : 0;
         double t0 = 0.0, t1 = 0.0;
-        for (int p = sl; p < a.P; p += 4) {
+        int p = sl;
+        for (; p + 28 < a.P; p += 32) {       // eight list steps' loads up front (see bn_bwd_finalize_kernel); same order
+            float r0[8], r1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t q = (size_t)(p + 4 * u) * 2 * a.ldy + ci;
+                r0[u] = a.psum[q];
+                r1[u] = a.psum[q + a.ldy];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t0 += (double)r0[u]; t1 += (double)r1[u]; }
+        }
+        for (; p < a.P; p += 4) {
             t0 += (double)a.psum[((size_t)p * 2 + 0) * a.ldy + ci];
             t1 += (double)a.psum[((size_t)p * 2 + 1) * a.ldy + ci];
         }
