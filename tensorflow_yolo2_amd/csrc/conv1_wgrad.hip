@@ -769,9 +769,20 @@ __global__ __launch_bounds__(256) void conv1_lin_reduce_kernel(const float* part
     if (b1 > nblocks) b1 = nblocks;
     float v4[4] = {0.f, 0.f, 0.f, 0.f};
     int b = b0;
-    for (; b + 3 < b1; b += 4)
+    for (; b + 7 < b1; b += 8) {       // eight records' loads up front; the accumulators add in the four-record loop's order
+        float r[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v4[u] += part[(size_t)(b + u) * kLinAcc + i];
+        for (int u = 0; u < 8; ++u) r[u] = part[(size_t)(b + u) * kLinAcc + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v4[u & 3] += r[u];
+    }
+    for (; b + 3 < b1; b += 4) {
+        float r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = part[(size_t)(b + u) * kLinAcc + i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v4[u] += r[u];
+    }
     for (; b < b1; ++b) v4[0] += part[(size_t)b * kLinAcc + i];
     mid[(size_t)blockIdx.y * kLinAcc + i] = (v4[0] + v4[1]) + (v4[2] + v4[3]);
 }
@@ -787,7 +798,15 @@ __global__ __launch_bounds__(1024) void conv1_lin_s2_kernel(const float* mid, co
     const int co = threadIdx.x & 31, sl = threadIdx.x >> 5;
     {                                                // S1 of the block records: slice sl takes records sl, sl + 32, ...
         double s1 = 0.0;
-        for (int p = sl; p < P; p += 32) s1 += (double)psum[((size_t)p * 2 + 0) * 32 + co];
+        int p = sl;
+        for (; p + 7 * 32 < P; p += 8 * 32) {      // eight records' loads up front (this one-block kernel is a chain of
+            float r[8];                            // dependent loads at the tail of the backward pass); same order
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = psum[((size_t)(p + 32 * u) * 2 + 0) * 32 + co];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s1 += (double)r[u];
+        }
+        for (; p < P; p += 32) s1 += (double)psum[((size_t)p * 2 + 0) * 32 + co];
         red1[sl][co] = s1;
     }
     __syncthreads();

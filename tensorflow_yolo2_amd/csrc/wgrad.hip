@@ -328,9 +328,21 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
         int s = sl;
-        for (; s + 3 * SL < sk; s += 4 * SL) {
+        // eight splits' loads up front (the kernel runs beside the dgrads: memory latency under that load is what it
+        // waits for); every accumulator adds in the order of the four-split loop it replaces: the same bits
+        for (; s + 7 * SL < sk; s += 8 * SL) {
+            f32x4 r[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] += p[(size_t)(s + u * SL) * stride4 + i];
+            for (int u = 0; u < 8; ++u) r[u] = p[(size_t)(s + u * SL) * stride4 + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u & 3] += r[u];
+        }
+        for (; s + 3 * SL < sk; s += 4 * SL) {
+            f32x4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = p[(size_t)(s + u * SL) * stride4 + i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += r[u];
         }
         for (; s < sk; s += SL) acc[0] += p[(size_t)s * stride4 + i];
     }
