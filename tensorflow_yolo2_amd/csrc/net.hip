@@ -259,8 +259,9 @@ static void plan(y2_ctx* c) {
         // round 4, 16-bit types: the linear form keeps NO conv output of the first layer, only 3 index bits per element
         // (kernels.h Conv1PoolArgs::idx3); Y2_CONV1_YSEL=1 (and the f32 parity mode) keep ysel + 2 index bits
         static const bool keep_ysel = getenv("Y2_CONV1_YSEL") != nullptr;
-        // (f16x2: the layer runs the f32 kernels, which are bound by their fp32 matrix instructions -- the 3-bit form was tried
-        //  there and changes nothing: 401 / 1155 us forward / backward either way)
+        // (f16x2: the layer's fp32-operand kernels form split products in registers -- conv1.hip / conv1_wgrad.hip XS forms -- and
+        //  take the 3-bit form too: 241 -> 210 us forward, 657 -> 617 us backward on one box; on the exact-fp32 matrix
+        //  instructions, Y2_CONV1_NO_XS=1, it had changed nothing.  Y2_CONV1_XS_YSEL=1 keeps ysel there for A/B)
         static const bool xs_off = getenv("Y2_CONV1_NO_XS") != nullptr;
         static const bool xs_sel = getenv("Y2_CONV1_XS_YSEL") != nullptr;
         const bool nosel = lin1 && (dtype_plain(c->dtype) != 0 || (dtype_split(c->dtype) && !xs_off && !xs_sel)) && !keep_ysel;
