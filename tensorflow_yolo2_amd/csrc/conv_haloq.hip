@@ -34,6 +34,7 @@
 // between the MFMAs (mfma_interleave), k-group g of a fragment row is address ^ (g * 64) instead of a second swizzle,
 // and the filter fragments are loaded by inline asm with hand-counted vmcnt (frag_load) -- together -3 % on the
 // 13x13 / 26x26 layers against the round-2 kernel on the same box.
+#include <stdlib.h>
 #include "common.h"
 #include "conv_epilogue.h"
 #include "kernels.h"
@@ -413,7 +414,12 @@ __global__ __launch_bounds__(256) void conv_ks_stats_kernel(ConvArgs a) {
 //   [cout tile of 16][tap][k-group of 64 bytes][lane = (16-byte chunk)*16 + cout%16][16 B].
 // TP / TC still count 32-wide units, so tiles, LDS image and epilogue patch are those of the kernel above.
 // ---------------------------------------------------------------------------
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT, int TAPS>
+// PL2 (f16x2 mode, round 5): BOTH operand planes of a K chunk are staged together -- an LDS image row is [64 B of the hi
+// plane | 64 B of the lo plane], the two 64-byte k-groups of a row ARE the two planes -- and a tap step runs the three
+// plane products of its 32 channels on them (w_hi x_hi, w_hi x_lo, w_lo x_hi) instead of the K loop running three plane
+// passes: the hi plane is staged, read from LDS and its filter fragments fetched ONCE instead of twice (2/3 of the LDS-DMA
+// bytes, fragment reads, filter loads, tap steps and barriers per matrix instruction).
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT, int TAPS, bool PL2 = false>
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, int arows) {
     static_assert(TAPS == 9 || (TAPS == 1 && CPT), "1x1 filters run on the compact image (no halo, no border taps)");
     typedef typename Elem<T>::frag frag_t;
@@ -423,6 +429,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
     constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB, KG = BKB / 64;   // k-groups of 64 bytes
     constexpr int TP16 = 2 * TP, TC16 = 2 * TC;
+    static_assert(!PL2 || (SPLIT && BKB == 128 && !CPT), "the two-plane form: split operands, 128-byte image rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem
     const int lrow = lane / LPR, lslot = lane % LPR;
     auto issueA = [&](int c, int ab) {
-        const char* xs = xg + lo * (long)rowbytes + (long)split_act_chunk<SPLIT>(c, npl) * BKB;
+        const char* xs = xg + lo * (long)rowbytes + (PL2 ? (long)c * 64 : (long)split_act_chunk<SPLIT>(c, npl) * BKB);
         char* dst = img0 + ab * abytes;
         if (CPT) {
             // eight table entries first, then their DMAs: an LDS-DMA is an LDS write to the compiler, so a table read
@@ -491,7 +498,10 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         } else {
             for (int i = w; i < npieces; i += NW) {
                 const int row = i * RPI + lrow;
-                const uint32_t off = (uint32_t)row * (uint32_t)rowbytes + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+                const uint32_t src = (uint32_t)(lslot ^ ((row / RPB) % LPR));     // 16-byte chunk of the row this slot holds
+                // PL2: chunks 0-3 come from the hi plane, 4-7 from the lo plane (a.C halves further on)
+                const uint32_t off = (uint32_t)row * (uint32_t)rowbytes +
+                                     (PL2 ? (src & 3u) * 16u + (src >> 2) * (uint32_t)(a.C * 2) : src * 16u);
                 glds16(xs + off, dst + i * 1024);
             }
         }
@@ -503,6 +513,16 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
         wbase[i] = (const char*)a.w + ((size_t)(n0 / 16 + wc * TC16 + i) * TAPS * kgrow * 64 + lane) * 16;
     static_assert(KG <= 4, "immediate offsets of the fragment loads");
     auto loadB = [&](int c, int t, u32x4 (&fb)[TC16][KG]) {
+        if constexpr (PL2) {      // k-group c of the hi plane and of the lo plane (kgrow / 2 groups further on)
+            const size_t off = (size_t)(t * kgrow + c) * 1024, lod = (size_t)(kgrow / 2) * 1024;
+#pragma unroll
+            for (int i = 0; i < TC16; ++i) {
+                const char* b = wbase[i] + off;
+                frag_load<0>(fb[i][0], b);
+                frag_load<0>(fb[i][1], b + lod);
+            }
+            return;
+        }
         const size_t off = (size_t)(t * kgrow + split_flt_chunk<SPLIT>(c, npl) * KG) * 1024;
 #pragma unroll
         for (int i = 0; i < TC16; ++i) {
@@ -554,7 +574,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
 #pragma unroll
         for (int j = 0; j < TP16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = SPLIT ? 3 * npl : npl;
+    const int nchunks = PL2 ? a.C * (int)sizeof(OT) / 64 : (SPLIT ? 3 * npl : npl);
     const int steps = nchunks * TAPS;
     u32x4 fbq[2][TC16][KG];
     int aoffq[2][TP16];                        // fragment-row addresses of the current / the next tap step
@@ -603,6 +623,24 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
             for (int g = 0; g < KG; ++g) frag_ready(fbq[P][i][g]);
         __builtin_amdgcn_sched_barrier(0);
         tap_addr(khn, kwn, cn, aoffq[P ^ 1]);   // next step's addresses beside this step's first MFMAs
+        if constexpr (PL2) {
+            // fp0 = this chunk's x_hi fragments, fp1 = x_lo; fbq[.][i][0] = w_hi, [1] = w_lo: hi hi, then the two small terms
+            load_frags(1, fp1);
+#pragma unroll
+            for (int i = 0; i < TC16; ++i)
+#pragma unroll
+                for (int j = 0; j < TP16; ++j) mma16(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][0]), fp0[j]);
+            mfma_interleave<TC16 * TP16, TP16>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TC16; ++i)
+#pragma unroll
+                for (int j = 0; j < TP16; ++j) {
+                    mma16(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][0]), fp1[j]);
+                    mma16(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][1]), fp0[j]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        } else
 #pragma unroll
         for (int g = 0; g < KG; g += 2) {
             if (g + 1 < KG) load_frags(g + 1, fp1);
@@ -696,13 +734,21 @@ static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
     if (lds < (size_t)Epi::LDS) lds = Epi::LDS;
     if (lds > 160 * 1024) return hipErrorOutOfMemory;
     void (*kern)(ConvArgs, int);
-    if constexpr (M16) kern = conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
-    else kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
-    static size_t attr = 0;
-    if (lds > attr) {
+    // f16x2 on the 16x16 tiles: both operand planes per K chunk (conv_haloq16_kernel PL2); Y2_NO_CONV_PL2=1: three plane passes
+    static const bool no_pl2 = getenv("Y2_NO_CONV_PL2") != nullptr;
+    constexpr bool kPL2 = Types<T>::kSplit && M16 && BKB == 128 && !CPT && TAPS == 9;
+    bool pl2 = false;
+    if constexpr (M16) {
+        kern = conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
+        if constexpr (kPL2) {
+            if (!no_pl2) { kern = conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS, true>; pl2 = true; }
+        }
+    } else kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
+    static size_t attr[2] = {0, 0};
+    if (lds > attr[pl2]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr = lds;
+        attr[pl2] = lds;
     }
     const int nPT = (a.M + BP - 1) / BP;
     const int nCT = (a.Cout + BC - 1) / BC;
