@@ -75,7 +75,9 @@ Y2_DEV u32x4 lds_read16(uint32_t lds_addr) {
 // tile in a.ks_scratch [split][M][ldy] and conv_ks_finish_kernel adds them in split order (bias, rounding, statistics
 // or the folded inference batch norm there): launches of a few hundred pixels are bound by the SERIAL K loop of their
 // few workgroups (~110 ns per tap step, 72 us for K = 9216 whatever the tile), not by anything a roofline names.
-template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT, int TAPS, bool KS = false>
+// PL2 (f16x2 mode): as conv_haloq16_kernel -- an LDS image row is [BKB/2 bytes of the hi plane | BKB/2 of the lo plane], the
+// first half of a row's 32-byte k-groups is x_hi, the second half x_lo, and a tap step runs the three plane products
+template <typename T, int WP, int WC, int TP, int TC, int BKB, bool ADB, bool CPT, int TAPS, bool KS = false, bool PL2 = false>
 __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int arows) {
     static_assert(TAPS == 9 || (TAPS == 1 && CPT), "1x1 filters run on the compact image (no halo, no border taps)");
     typedef typename Elem<T>::frag frag_t;
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     typedef typename Types<T>::out_t YT;
     constexpr bool SPLIT = Types<T>::kSplit;
     static_assert(!(SPLIT && KS), "the K split of small launches is not built for the split-operand mode");
+    static_assert(!PL2 || (SPLIT && !CPT && (BKB == 128 || BKB == 64)), "the two-plane form: split operands, bordered image");
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
     constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB, KG = BKB / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,8 +136,9 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 
     const int smem_lds = (int)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem
     const int lrow = lane / LPR, lslot = lane % LPR;
+    constexpr int KGH = KG / 2;                            // PL2: 32-byte k-groups per plane and chunk
     auto issueA = [&](int c, int ab) {
-        const char* xs = xg + lo * (long)rowbytes + (long)split_act_chunk<SPLIT>(c, npl) * BKB;
+        const char* xs = xg + lo * (long)rowbytes + (PL2 ? (long)c * (BKB / 2) : (long)split_act_chunk<SPLIT>(c, npl) * BKB);
         char* dst = img0 + ab * abytes;
         if (CPT) {
             // eight table entries first, then their DMAs: an LDS-DMA is an LDS write to the compiler, so a table read
@@ -159,7 +163,10 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         } else {
             for (int i = w; i < npieces; i += NW) {
                 const int row = i * RPI + lrow;
-                const uint32_t off = (uint32_t)row * (uint32_t)rowbytes + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+                const uint32_t src = (uint32_t)(lslot ^ ((row / RPB) % LPR));     // 16-byte chunk of the row this slot holds
+                // PL2: the first LPR / 2 chunks come from the hi plane, the others from the lo plane (a.C halves further on)
+                const uint32_t off = (uint32_t)row * (uint32_t)rowbytes +
+                                     (PL2 ? (src % (LPR / 2)) * 16u + (src / (LPR / 2)) * (uint32_t)(a.C * 2) : src * 16u);
                 glds16(xs + off, dst + i * 1024);
             }
         }
@@ -172,6 +179,18 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         wbase[i] = (const char*)a.w + ((size_t)(n0 / 32 + wc * TC + i) * TAPS * kgrow * 64 + lane) * 16;
     static_assert(KG <= 4, "immediate offsets of the fragment loads");
     auto loadB = [&](int c, int t, u32x4 (&fb)[TC][KG]) {
+        if constexpr (PL2) {      // k-groups c KGH .. of the hi plane, then the same of the lo plane (kgrow / 2 groups further on)
+            const size_t off = (size_t)(t * kgrow + c * KGH) * 1024, lod = (size_t)(kgrow / 2) * 1024;
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const char* b = wbase[i] + off;
+                frag_load<0>(fb[i][0], b);
+                if constexpr (KGH > 1) frag_load<1024>(fb[i][1], b);
+                frag_load<0>(fb[i][KGH], b + lod);
+                if constexpr (KGH > 1) frag_load<1024>(fb[i][KGH + 1], b + lod);
+            }
+            return;
+        }
         const size_t off = (size_t)(t * kgrow + split_flt_chunk<SPLIT>(c, npl) * KG) * 1024;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    int c_begin = 0, nchunks = SPLIT ? 3 * npl : npl;     // this workgroup's chunk range [c_begin, nchunks)
+    int c_begin = 0, nchunks = PL2 ? a.C * (int)sizeof(OT) / (BKB / 2) : (SPLIT ? 3 * npl : npl);     // this workgroup's chunk range [c_begin, nchunks)
     if constexpr (KS) {
         const int per = (nchunks + a.ks_splits - 1) / a.ks_splits;
         c_begin = split * per;
@@ -284,6 +303,32 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
         // the next step's addresses: VALU work that issues beside this step's first MFMAs instead of in front of
         // the next step's first LDS reads
         tap_addr(khn, kwn, cn, aoffq[P ^ 1]);
+        if constexpr (PL2) {
+            // fp0 = x_hi of k-group 0 (read above); per k-group q: w_hi x_hi, then w_hi x_lo and w_lo x_hi; the next group's
+            // x_hi goes to a third register set while the small terms run
+            frag_t fp2[TP];
+#pragma unroll
+            for (int q = 0; q < KGH; ++q) {
+                frag_t(&xh)[TP] = (q & 1) ? fp2 : fp0;
+                frag_t(&xn)[TP] = (q & 1) ? fp0 : fp2;
+                load_frags(KGH + q, fp1);                                        // x_lo of this k-group
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) mma32(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][q]), xh[j]);
+                if (q == 0) mfma_interleave<TC * TP, TP>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < KGH) load_frags(q + 1, xn);
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        mma32(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][q]), fp1[j]);
+                        mma32(acc[i][j], __builtin_bit_cast(frag_t, fbq[P][i][KGH + q]), xh[j]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int g = 0; g < KG; g += 2) {
             if (g + 1 < KG) load_frags(g + 1, fp1);
@@ -743,7 +788,13 @@ static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
         if constexpr (kPL2) {
             if (!no_pl2) { kern = conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS, true>; pl2 = true; }
         }
-    } else kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
+    } else {
+        kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
+        constexpr bool kPL2q = Types<T>::kSplit && !CPT && TAPS == 9 && (BKB == 128 || BKB == 64);
+        if constexpr (kPL2q) {
+            if (!no_pl2) { kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS, false, true>; pl2 = true; }
+        }
+    }
     static size_t attr[2] = {0, 0};
     if (lds > attr[pl2]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
