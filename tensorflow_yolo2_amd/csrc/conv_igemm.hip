@@ -20,6 +20,7 @@
 // Staging: global_load_lds 16 B/lane, double-buffered LDS, XOR swizzle applied
 // on the per-lane SOURCE address and on the ds_read (LDS image stays linear,
 // cdna guide rule 21), conflict-free for ds_read_b128.
+#include <stdlib.h>
 #include "common.h"
 #include "conv_epilogue.h"
 #include "kernels.h"
@@ -61,7 +62,9 @@ struct ConvCfg {
 
 // ABL: timing-only ablation bits (dev): 1 skip pixel-tile loads, 2 skip filter-tile loads,
 // 4 skip MFMAs, 8 skip LDS fragment reads.  0 in every product launch.
-template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0>
+// PL2 (f16x2 mode, round 5; as conv_haloq.hip): a staged row of either operand is [BKB/2 bytes of the hi plane | BKB/2 of the
+// lo plane] of the K chunk, and a K step runs the three plane products on it instead of the K loop running three plane passes
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0, bool PL2 = false>
 __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     typedef ConvCfg<T, WP, WC, TP, TC, BKB, NS> Cfg;
     typedef typename Elem<T>::frag frag_t;
@@ -70,6 +73,12 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool SPLIT = Types<T>::kSplit;
     constexpr int NW = Cfg::NW, BP = Cfg::BP, BC = Cfg::BC, SZ = Cfg::SZ;
     constexpr int LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB, IPW = Cfg::IPW, KG = Cfg::KG;
+    static_assert(!PL2 || (SPLIT && KG >= 2 && KG % 2 == 0), "the two-plane form: split operands, an even number of k-groups");
+    constexpr int KGH = KG / 2;
+    // 16-byte chunk `src` of a staged row -> byte offset in the operand's row (PL2: first half hi plane, second half lo plane)
+    auto chunk_off = [&](uint32_t src) -> uint32_t {
+        return PL2 ? (src % (LPR / 2)) * 16u + (src / (LPR / 2)) * (uint32_t)(a.C * 2) : src * 16u;
+    };
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -101,15 +110,15 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
                 // top-left tap of the 3x3 window (bordered layout, common.h)
                 base = (uint32_t)(bpix(n, h, ww, a.H, a.W) - (size_t)(a.W + 2)) * (uint32_t)(a.C * SZ);
             }
-            voff[i] = base + (uint32_t)((lslot ^ ((row / RPB) % LPR)) * 16);
+            voff[i] = base + chunk_off((uint32_t)(lslot ^ ((row / RPB) % LPR)));
         } else {
             const int r = row - BP;
-            voff[i] = (uint32_t)(n0 + r) * (uint32_t)(Ktot * SZ) + (uint32_t)((lslot ^ ((r / RPB) % LPR)) * 16);
+            voff[i] = (uint32_t)(n0 + r) * (uint32_t)(Ktot * SZ) + chunk_off((uint32_t)(lslot ^ ((r / RPB) % LPR)));
         }
     }
     // k-chunks per tap; f16x2: three passes over the planes, [x hi | x lo | x hi] against [w hi | w hi | w lo]
     const int npl = (a.C * (int)sizeof(OT)) / BKB;
-    const int cpt = SPLIT ? 3 * npl : npl;
+    const int cpt = PL2 ? (a.C * (int)sizeof(OT)) / (BKB / 2) : (SPLIT ? 3 * npl : npl);
     const int nK = a.taps * cpt;
     const int rowpitch = (a.W + 1) * a.C * SZ;
 
@@ -122,8 +131,8 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
         } else {
             tapoff = rowpitch + a.C * SZ;
         }
-        const char* xs = xg + tapoff + split_act_chunk<SPLIT>(c, npl) * BKB;
-        const char* ws = wg + (size_t)(t * a.C * SZ + split_flt_chunk<SPLIT>(c, npl) * BKB);
+        const char* xs = xg + tapoff + (PL2 ? c * (BKB / 2) : split_act_chunk<SPLIT>(c, npl) * BKB);
+        const char* ws = wg + (size_t)(t * a.C * SZ + (PL2 ? c * (BKB / 2) : split_flt_chunk<SPLIT>(c, npl) * BKB));
         char* lbase = smem + buf * Cfg::STAGE;
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
@@ -168,6 +177,30 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
         asm volatile("" ::: "memory");
         if (kk + NS - 1 < nK) stage(kk + NS - 1, ibuf);
         const char* lb = smem + cbuf * Cfg::STAGE;
+        if constexpr (PL2) {
+#pragma unroll
+            for (int q = 0; q < KGH; ++q) {
+                frag_t wh[TC], wl[TC], xh[TP], xl[TP];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    wh[i] = *(const frag_t*)(lb + cbase + i * 32 * BKB + foff[q]);
+                    wl[i] = *(const frag_t*)(lb + cbase + i * 32 * BKB + foff[KGH + q]);
+                }
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    xh[j] = *(const frag_t*)(lb + pbase + j * 32 * BKB + foff[q]);
+                    xl[j] = *(const frag_t*)(lb + pbase + j * 32 * BKB + foff[KGH + q]);
+                }
+#pragma unroll
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) {
+                        mma32(acc[i][j], wh[i], xh[j]);
+                        mma32(acc[i][j], wh[i], xl[j]);
+                        mma32(acc[i][j], wl[i], xh[j]);
+                    }
+            }
+        } else
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             frag_t fc[TC], fp[TP];
@@ -224,12 +257,18 @@ template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL =
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     typedef ConvCfg<T, WP, WC, TP, TC, BKB, NS> Cfg;
     static_assert(Cfg::LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_igemm_kernel<T, WP, WC, TP, TC, BKB, NS, ABL>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    void (*kern)(ConvArgs) = conv_igemm_kernel<T, WP, WC, TP, TC, BKB, NS, ABL>;
+    // f16x2: both operand planes per K chunk (PL2); Y2_NO_CONV_PL2=1: three plane passes
+    static const bool no_pl2 = getenv("Y2_NO_CONV_PL2") != nullptr;
+    int pl2 = 0;
+    if constexpr (Types<T>::kSplit && ABL == 0 && (BKB == 128 || BKB == 64)) {
+        if (!no_pl2) { kern = conv_igemm_kernel<T, WP, WC, TP, TC, BKB, NS, ABL, true>; pl2 = 1; }
+    }
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[pl2]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[pl2] = true;
     }
     const int nPT = (a.M + Cfg::BP - 1) / Cfg::BP;
     const int nCT = (a.Cout + Cfg::BC - 1) / Cfg::BC;
