@@ -219,6 +219,13 @@ Y2_DEV void pool_window(const BnActArgs& a, int n, int ho, int wo, int c0, const
                         Chunk<T>& ys) {
     constexpr int EPC = 16 / sizeof(T);
     const int hi0 = 2 * ho, wi0 = 2 * wo;
+    if (a.pool == 2) {       // subsample (kernels.h BnActArgs::pool): the window's position 0, nothing compared
+        const Chunk<T> v0 = ld_chunk<T>((const char*)a.y + (((size_t)(n * a.H + hi0) * a.W + wi0) * a.ldy + c0) * sizeof(T));
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) r[e] = leaky_s(Elem<T>::to_f32(v0.v[e]) * sc[e] + sh[e], a.slope);
+        ys = v0;
+        return;
+    }
     if (hi0 + 1 < a.H && wi0 + 1 < a.W) {
         const char* p = (const char*)a.y + (((size_t)(n * a.H + hi0) * a.W + wi0) * a.ldy + c0) * sizeof(T);
         const size_t pxB = (size_t)a.ldy * sizeof(T), rowB = (size_t)a.W * pxB;
@@ -647,6 +654,14 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                             }
                         }
                 }
+                const bool sub = a.pool == 2;     // subsample: position 0 carries the gradient, the others are not in the batch norm
+                if (sub) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        arg[e] = 0;
+                        yb[e] = Elem<T>::to_f32(yc[0].v[e]);
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yb[e], sc[e], sh[e]), a.slope);
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                         float o[EPC];
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) {
-                            const float t = fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
+                            const float t = (sub && d != 0) ? 0.f : fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
                             o[e] = (arg[e] == d) ? fmaf(sc[e], gz[e], t) : t;
                         }
                         st_act<T, SPLIT>((char*)a.dyp, bpix(n, hi, wi, a.H, a.W), a.ldy, c0, o);
@@ -767,7 +782,7 @@ __global__ __launch_bounds__(SLN * kFinCh) void bn_bwd_finalize_kernel(BnBwdArgs
             t[k] = fin_block_sum<kFinSl * kFinCh / 64>((v4[k][0] + v4[k][1]) + (v4[k][2] + v4[k][3]), red, sl, cl);
     }
     if (sl == 0 && cv) {
-        const double m = (double)a.N * a.H * a.W;
+        const double m = a.pool == 2 ? (double)a.N * ((a.H + 1) / 2) * ((a.W + 1) / 2) : (double)a.N * a.H * a.W;   // (subsampling layers: the kept positions)
         const double mu = a.mean[c], is = a.invstd[c], sc = a.scale[c];
         const double dgam = is * (t[1] - mu * t[0]);          // sum(dz * xhat)
         a.dbeta[c] = (float)(t[0] * a.inv_grad_scale);
@@ -823,7 +838,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { s0 += red[k][c][0]; s1 += red[k][c][1]; }
-            const double m = (double)a.N * a.H * a.W;
+            const double m = a.pool == 2 ? (double)a.N * ((a.H + 1) / 2) * ((a.W + 1) / 2) : (double)a.N * a.H * a.W;   // (subsampling layers: the kept positions)
             const double mu = a.mean[ci], is = a.invstd[ci], sc = a.scale[ci];
             const double dgam = is * (s1 - mu * s0);
             const float c1 = a.training ? (float)(s0 / m) : 0.f;
@@ -924,6 +939,14 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
                         }
                     }
             }
+            const bool sub = a.pool == 2;     // subsample: position 0 carries the gradient, the others are not in the batch norm
+            if (sub) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    arg[e] = 0;
+                    yb[e] = Elem<T>::to_f32(yc[0].v[e]);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) gz[e] = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yb[e], sc[e], sh[e]), a.slope);
 #pragma unroll
@@ -933,7 +956,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
                 float o[EPC];
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const float t = fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
+                    const float t = (sub && d != 0) ? 0.f : fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
                     o[e] = (arg[e] == d) ? fmaf(sc[e], gz[e], t) : t;
                 }
                 st_act<T, SPLIT>((char*)a.dyp, bpix(n, hi, wi, a.H, a.W), a.ldy, c0, o);
@@ -1016,6 +1039,62 @@ hipError_t launch_bn_bwd_finalize(const BnBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(bn_bwd_finalize_kernel<kBwdFinSl>, dim3((a.C + kFinCh - 1) / kFinCh), dim3(kBwdFinSl * kFinCh), 0, s, a, a.P);
     return hipGetLastError();
 }
+// ---------------------------------------------------------------------------
+// Subsampling layers (pool == 2): batch-norm partial records over the kept positions of y.  Block = 64 channels x 4
+// pixel slices of one record's kBnSubRec kept pixels; sums about the record's first kept value (shifted sums), the four
+// slices added in double in a fixed order.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_sub_kernel(const T* __restrict__ y, int N, int H, int W, int ldy,
+                                                           float* part_cnt, float* part_mean, float* part_m2) {
+    __shared__ float red[4][64][2];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int Ho = H / 2, Wo = W / 2, mout = N * Ho * Wo;
+    const int q0 = blockIdx.y * kBnSubRec;
+    const int q1 = q0 + kBnSubRec < mout ? q0 + kBnSubRec : mout;
+    const bool cv = c < ldy;
+    auto pixel = [&](int q) -> size_t {
+        const int wo = q % Wo, t = q / Wo, ho = t % Ho, n = t / Ho;
+        return ((size_t)(n * H + 2 * ho) * W + 2 * wo) * ldy;
+    };
+    const float piv = cv ? Elem<T>::to_f32(y[pixel(q0) + c]) : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (cv) {
+        for (int q = q0 + sl; q < q1; q += 4) {
+            const float d = Elem<T>::to_f32(y[pixel(q) + c]) - piv;
+            s1 += d;
+            s2 = fmaf(d, d, s2);
+        }
+    }
+    red[sl][threadIdx.x & 63][0] = s1;
+    red[sl][threadIdx.x & 63][1] = s2;
+    __syncthreads();
+    if (sl == 0 && cv) {
+        const int k = threadIdx.x & 63;
+        const double S1 = ((double)red[0][k][0] + red[1][k][0]) + ((double)red[2][k][0] + red[3][k][0]);
+        const double S2 = ((double)red[0][k][1] + red[1][k][1]) + ((double)red[2][k][1] + red[3][k][1]);
+        const double n = (double)(q1 - q0), md = S1 / n, m2 = S2 - S1 * md;
+        part_mean[(size_t)blockIdx.y * ldy + c] = (float)((double)piv + md);
+        part_m2[(size_t)blockIdx.y * ldy + c] = (float)(m2 > 0.0 ? m2 : 0.0);
+        if (c == 0) part_cnt[blockIdx.y] = (float)(q1 - q0);
+    }
+}
+hipError_t launch_bn_stats_sub(int dtype, const void* y, int N, int H, int W, int ldy, float* part_cnt, float* part_mean,
+                               float* part_m2, int* records, hipStream_t s) {
+    if ((H & 1) || (W & 1)) return hipErrorInvalidValue;
+    const int mout = N * (H / 2) * (W / 2);
+    const int rec = (mout + kBnSubRec - 1) / kBnSubRec;
+    const dim3 g((ldy + 63) / 64, rec), b(256);
+    switch (dtype) {
+        case 0: case 3: hipLaunchKernelGGL(bn_stats_sub_kernel<float>, g, b, 0, s, (const float*)y, N, H, W, ldy, part_cnt, part_mean, part_m2); break;
+        case 1: hipLaunchKernelGGL(bn_stats_sub_kernel<half_t>, g, b, 0, s, (const half_t*)y, N, H, W, ldy, part_cnt, part_mean, part_m2); break;
+        case 2: hipLaunchKernelGGL(bn_stats_sub_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)y, N, H, W, ldy, part_cnt, part_mean, part_m2); break;
+        default: return hipErrorInvalidValue;
+    }
+    if (records) *records = rec;
+    return hipGetLastError();
+}
+
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t s) {
     switch (dtype) {
         case 0: return bn_bwd_T<float, true>(a, s);

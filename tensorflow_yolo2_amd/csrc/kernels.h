@@ -400,7 +400,10 @@ struct BnActArgs {
     const float* shift;
     void* out;            // zero-bordered [N][Ho+2][Wo+2][C] of T, or (out_f32) float [M][C] compact
     int N, H, W, C, ldy;
-    int pool;             // 2x2/2 SAME max pool after the activation
+    int pool;             // 1: 2x2/2 SAME max pool after the activation.  2 (round 5, the ResNet swap's stride-2 3x3
+                          // convolutions, slim conv2d_same: resnet_utils.py:77-122): SUBSAMPLE -- the layer keeps window
+                          // position 0 (the stride-1 output at even rows / columns) and its batch norm runs over the kept
+                          // positions only; even H and W
     int out_f32;
     float slope = 0.1f;   // activation: max(slope * z, z)
     void* ysel = nullptr; // pooled layers, training: the conv output at the window's (first) arg-max, [Mout][ldy] of T --
@@ -414,6 +417,11 @@ hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t s);
 // merge of a short partial list (P <= 128) + apply in one launch (64-channel slabs); bn_fin_act_ok says whether it applies
 bool bn_fin_act_ok(const BnActArgs& a, const BnFinalizeArgs& f);
 hipError_t launch_bn_fin_act(int dtype, const BnActArgs& a, const BnFinalizeArgs& f, hipStream_t s);
+// subsampling layers (BnActArgs::pool == 2): (count, mean, M2) records of the conv output y [N*H*W][ldy] over the KEPT
+// positions (even rows and columns), one record per kBnSubRec kept pixels; *records = their number
+constexpr int kBnSubRec = 256;
+hipError_t launch_bn_stats_sub(int dtype, const void* y, int N, int H, int W, int ldy, float* part_cnt, float* part_mean,
+                               float* part_m2, int* records, hipStream_t s);
 
 struct BnBwdArgs {
     const void* dA;       // grad wrt layer output [M_out][ldd] of T (scaled by grad_scale)

@@ -332,6 +332,10 @@ int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers
     for (int l = 0; l < num_layers; ++l) {
         Layer y{};
         y.k = spec[l * 4 + 0]; y.cin = spec[l * 4 + 1]; y.cout = spec[l * 4 + 2]; y.pool = spec[l * 4 + 3];
+        if (y.pool < 0 || y.pool > 2 || (y.pool == 2 && ((h & 1) || (w & 1) || l == 0 || l + 1 == num_layers))) {
+            delete c;
+            return fail(Y2_ERR_ARG, "layer %d: pool is 0, 1 (2x2 max pool) or 2 (subsample: an inner layer on an even map)", l);
+        }
         if ((y.k != 1 && y.k != 3) || y.cin <= 0 || y.cout <= 0) {
             delete c;
             return fail(Y2_ERR_ARG, "layer %d: only 1x1 / 3x3 stride-1 SAME convolutions exist in this network", l);
@@ -731,7 +735,8 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             if (l == 0 && !c->ext_xin) HIPCHK(launch_pack_act(c->dtype, images, xin, c->N, y.H, y.W, y.cin, y.cin_s, s));
             ConvArgs a{};
             a.x = xin; a.w = c->ws + y.wf; a.y = c->ws + y.y; a.bias = c->params + y.pb;
-            if (training) { a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2; }
+            // (subsampling layers, pool == 2: their batch norm runs over the kept positions -- launch_bn_stats_sub below)
+            if (training && y.pool != 2) { a.part_cnt = part_cnt; a.part_mean = part_mean; a.part_m2 = part_m2; }
             a.N = c->N; a.H = y.H; a.W = y.W; a.C = y.cin_s; a.M = y.M; a.Cout = y.cout; a.ldy = y.ldy;
             a.taps = y.k * y.k;
             if (c->ks_floats) { a.ks_scratch = (float*)(c->ws + c->o_ks); a.ks_floats = c->ks_floats; }
@@ -741,14 +746,18 @@ static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8
             // bindings keep y: a later y2_backward of a frozen-core graph reads it.
             // (round 5: pooled layers on the conv_haloq kernels too -- window-major tiles, ConvArgs::aff_pool)
             if (!training && l + 1 < nl && !c->bound_training && y.ldy == c->L[l + 1].cin_s &&
-                (y.pool ? conv_affine_pool_ok(c->dtype, a) : conv_affine_ok(c->dtype, a))) {
+                (y.pool == 1 ? conv_affine_pool_ok(c->dtype, a) : (y.pool == 0 && conv_affine_ok(c->dtype, a)))) {
                 conv_set_affine(a, scale, shift, c->ws + c->L[l + 1].xin + c->in_geom(l + 1).base_off(sz));
                 a.aff_slope = y.slope;
-                a.aff_pool = y.pool ? 1 : 0;
+                a.aff_pool = y.pool == 1 ? 1 : 0;
                 folded = true;
             }
             { PROF(CAT_CONV_FWD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }
             P = rec;
+            if (training && y.pool == 2) {
+                PROF(CAT_BN_FWD);
+                HIPCHK(launch_bn_stats_sub(c->dtype, c->ws + y.y, c->N, y.H, y.W, y.ldy, part_cnt, part_mean, part_m2, &P, s));
+            }
         }
         c->fwd_folded[l] = folded ? 1 : 0;
         if (folded) continue;

@@ -57,6 +57,7 @@ def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, 
 
 
 _TWO_CALL_JOIN = bool(os.environ.get("Y2_RESNET_TWO_CALL_JOIN"))
+_NO_STRIDED_STACKS = bool(os.environ.get("Y2_RESNET_NO_STRIDED_STACKS"))   # A/B: the stride-2 units on fp32 operators
 _NO_LINK = bool(os.environ.get("Y2_RESNET_NO_LINK"))       # A/B: round 4's fp32 hand-over between the fused units
 
 
@@ -163,8 +164,10 @@ class ResNet50Yolo:
                 cin = depth
         return True
 
-    def _stack_for(self, scope, hw, cin, depth, db):
-        """(main stack, projection stack) of a stride-1 unit at hw x hw, created on first use"""
+    def _stack_for(self, scope, hw, cin, depth, db, stride=1):
+        """(main stack, projection stack) of a unit at hw x hw, created on first use.  stride 2 (round 5; the last unit of
+        blocks 1-3, identity shortcut): conv2 is a SUBSAMPLING layer of the executor (pool = 2: the stride-1 3x3 output at
+        even rows / columns, batch norm over the kept positions = slim's conv2d_same(stride=2), resnet_utils.py:77-122)"""
         key = (scope, hw)
         if key not in self._stacks:
             def make(first, last, spec, slopes):
@@ -177,7 +180,9 @@ class ResNet50Yolo:
                                 buffers=(self.params[p0:pe], self.grads[p0:pe], self.state[s0:se]))
                 net.set_layer_options(slopes, BN_EPS, BN_DECAY, zero_bias_grad=True)
                 return net
-            main = make("conv1", "conv3", [(1, cin, db, 0), (3, db, db, 0), (1, db, depth, 0)], [0.0, 0.0, 1.0])
+            main = make("conv1", "conv3", [(1, cin, db, 0), (3, db, db, 2 if stride == 2 else 0), (1, db, depth, 0)],
+                        [0.0, 0.0, 1.0])
+            assert stride == 1 or depth == cin, "a strided unit with a projection shortcut is not wired"
             proj = make("shortcut", "shortcut", [(1, cin, depth, 0)], [1.0]) if depth != cin else None
             self._stacks[key] = (main, proj)
         return self._stacks[key]
@@ -360,6 +365,16 @@ class ResNet50Yolo:
                     tape.append(("linked", u, out))
                     x = out
                     continue
+                if self.fused and stride == 2 and depth == x.shape[3] and x.shape[1] % 2 == 0 and not _NO_STRIDED_STACKS:
+                    # round 5: the strided unit on the stack executor too (conv2 a subsampling layer); the identity
+                    # shortcut subsample(x) (resnet_v1.py:99-101) joins in the main stack's last apply pass
+                    main, _ = self._stack_for(sc, int(x.shape[1]), int(x.shape[3]), depth, db, stride=2)
+                    xin = x.contiguous()
+                    short = E.subsample(xin, stride)
+                    out = main.forward(xin, is_training, is_training, update_moving=update_moving, join=short)
+                    tape.append(("fused_s", main, out, stride, tuple(xin.shape[1:3])))
+                    x = out
+                    continue
                 if self.fused and stride == 1:
                     main, proj = self._stack_for(sc, int(x.shape[1]), int(x.shape[3]), depth, db)
                     xin = x.contiguous()
@@ -424,7 +439,7 @@ class ResNet50Yolo:
         dx = dflat.reshape(feat.shape).contiguous()
         dx2 = None          # a fused unit leaves its input gradient as two addends (main branch, shortcut): the unit below
         for rec in reversed(self.tape[:-1]):    # folds their sum into its own join's backward, anything else adds them first
-            if rec[0] not in ("fused", "linked") and dx2 is not None:
+            if rec[0] not in ("fused", "fused_s", "linked") and dx2 is not None:
                 dx = E.accumulate(dx, dx2)
                 dx2 = None
             if rec[0] == "linked":
@@ -455,6 +470,11 @@ class ResNet50Yolo:
                         u["_short_grad"] = u["g"] if proj is None else u["dxp"]
                 if u["top"] and u["bottom"]:
                     raise AssertionError("unlinked units take the fused path")
+            elif rec[0] == "fused_s":
+                _k, main, out, stride, in_hw = rec
+                g = E.add_relu_backward(dx.contiguous(), out, dx2)     # at the unit's output resolution
+                dx = main.backward_input(g)                            # main branch, at the input resolution
+                dx2 = E.subsample(g, stride, out_hw=in_hw)             # identity shortcut: g back at the even positions
             elif rec[0] == "fused":
                 _k, main, proj, out = rec
                 g = E.add_relu_backward(dx.contiguous(), out, dx2)     # d(relu(r + s)) = dout * [out > 0], to both branches

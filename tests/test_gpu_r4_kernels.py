@@ -143,16 +143,20 @@ def test_small_launches_k_split_in_network(N, hw, cin, cout, pool):
     check_layer_in_network(N, "small-M", 3, cin, cout, hw, pool, "K-split")
 
 
+@pytest.mark.parametrize("stride", [1, 2])
 @pytest.mark.parametrize("dtype,tol", [("f32", 2e-4), ("f16", 2e-3)])
-def test_layer_options_relu_and_linear_stack_vs_torch(dtype, tol):
+def test_layer_options_relu_and_linear_stack_vs_torch(dtype, tol, stride):
     """y2_set_layer_options: a bottleneck-shaped stack (1x1 ReLU, 3x3 ReLU, 1x1 without activation; batch norm with slim's
     eps 1e-5 / decay 0.997; the conv-bias slots held at zero and given no gradient) against float64 autograd: output,
-    input gradient, every parameter gradient, moving statistics (src/slim_dir/nets/resnet_v1.py:99-112)."""
+    input gradient, every parameter gradient, moving statistics (src/slim_dir/nets/resnet_v1.py:99-112).
+    stride 2 (round 5): the 3x3 layer is a SUBSAMPLING layer of the executor (pool = 2) -- slim's conv2d_same(stride=2),
+    the stride-1 output at even rows / columns (src/slim_dir/nets/resnet_utils.py:77-122), its batch norm over the kept
+    positions: the bottleneck's conv2 in the last unit of blocks 1-3."""
     import torch.nn.functional as F
     from tensorflow_yolo2_amd import engine as E
     rng = np.random.default_rng(3)
     N, hw, cin, db, depth = 4, 12, 64, 32, 128
-    spec = [(1, cin, db, 0), (3, db, db, 0), (1, db, depth, 0)]
+    spec = [(1, cin, db, 0), (3, db, db, 2 if stride == 2 else 0), (1, db, depth, 0)]
     slopes = [0.0, 0.0, 1.0]
     net = E.Network(spec, N, hw, hw, dtype=dtype, training=True, grad_scale=1.0)
     net.set_layer_options(slopes, 1e-5, 0.997, zero_bias_grad=True)
@@ -183,6 +187,8 @@ def test_layer_options_relu_and_linear_stack_vs_torch(dtype, tol):
     flips = 0
     for l, ((k, _ci, _co, _p), p, s) in enumerate(zip(spec, tp, slopes)):
         h = F.conv2d(h, p["W"].permute(3, 2, 0, 1), padding=k // 2)
+        if _p == 2:
+            h = h[:, :, ::2, ::2]          # conv2d_same(stride=2) = the stride-1 output at even positions
         mean, var = h.mean((0, 2, 3)), h.var((0, 2, 3), unbiased=False)
         mv.append((0.003 * mean.detach().numpy(), 0.997 + 0.003 * var.detach().numpy()))
         z = (h - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + 1e-5) * p["gamma"][None, :, None, None] \
