@@ -58,7 +58,11 @@ int y2_version(void);
 int y2_darknet19_spec(int kind, int output_filter, int* spec, int max_layers);
 
 /* ---- network context (replaces the TF graph + variables built by
- *      conv_bn_layer, src/yolo2_nets/darknet.py:32-46) ------------------------ */
+ *      conv_bn_layer, src/yolo2_nets/darknet.py:32-46) ------------------------
+ * spec: 4 ints per layer (filter_size, in_chl, out_chl, after).  after = 0: nothing; 1: tf.nn.max_pool(2, 2, 'SAME')
+ * behind the activation (darknet.py:24-25,45); 2 (round 5, inner layers on even maps): SUBSAMPLE -- the layer is slim's
+ * conv2d_same(stride=2) / subsample (src/slim_dir/nets/resnet_utils.py:60-122): its stride-1 output at even rows and
+ * columns, batch norm over those positions only (the 3x3 convolution of a stride-2 bottleneck unit, resnet_v1.py:99-112) */
 int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers, int tail, int tail_k,
                   int batch, int height, int width, int dtype);
 void y2_ctx_destroy(y2_ctx* ctx);
