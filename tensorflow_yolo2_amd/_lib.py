@@ -92,6 +92,7 @@ SIGNATURES = {
     "y2_fully_connected": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_fully_connected_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_conv7x7s2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "y2_conv7x7s2_t": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_conv7x7s2_backward_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_bias_relu": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
     "y2_bias_relu_backward": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),

@@ -704,6 +704,115 @@ __global__ void rn_join_bwd_t_kernel(const T* __restrict__ outb, const T* __rest
         y2::st_chunk<T>(g + m * C + c, r);
     }
 }
+// ---------------------------------------------------------------------------
+// Round 5: the root convolution on the matrix pipe in the half-precision modes (y2_conv7x7s2_t).  The scalar kernel above
+// is bound by its LDS issue rate (147 wave-uniform reads per 147 FMAs: 0.40 ms at batch 32, 3.6 % of the ResNet step).
+// Here the seven input rows of an output row are staged as T with FOUR channels per pixel (8 bytes: the window of output
+// pixel wo starts at byte 16 wo, every fragment read is one aligned ds_read_b128), a filter row is 7 taps x 4 channels
+// + one zero tap = 32 k-slots = two 32x32x16 steps, D[cout][pixel], fp32 accumulation and output; the filters are packed
+// in fragment order by a one-block kernel in front ([cout tile][kh][k-group][lane][8]).  A wave takes 32 output pixels x
+// 64 filters (28 matrix instructions) and writes its tile through a [pixel][cout] patch as whole 256-byte rows.
+// ---------------------------------------------------------------------------
+constexpr int kC7mThreads = 256;
+template <typename T>
+__global__ void rn_conv7_pack_kernel(const float* __restrict__ w, T* __restrict__ wp, int Co, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = idx & 63, g = (idx >> 6) & 1, kh = (idx >> 7) % 7, ct = idx / (128 * 7);
+    const int co = ct * 32 + (lane & 31), hh = lane >> 5;
+    T o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * g + 8 * hh + j, kw = k >> 2, c = k & 3;
+        o[j] = Elem<T>::from_f32((kw < 7 && c < 3 && co < Co) ? w[(size_t)((kh * 7 + kw) * 3 + c) * Co + co] : 0.f);
+    }
+    *(u32x4*)(wp + (size_t)idx * 8) = *(const u32x4*)o;
+}
+template <typename T>
+__global__ __launch_bounds__(kC7mThreads) void rn_conv7_mfma_kernel(const float* __restrict__ x, const T* __restrict__ wp,
+                                                                    float* __restrict__ y, int N, int H, int W, int Co, int PW) {
+    typedef typename Elem<T>::frag frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PROW = 64 + 4;                     // floats per patch row (16-byte pad)
+    char* const rows = smem;                         // [7][PW] pixels of 4 T
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hh = lane >> 5;
+    float* const patch = (float*)(smem + (size_t)7 * PW * 8) + wave * 32 * PROW;
+    frag_t fw[2][7][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) fw[ct][kh][g] = *(const frag_t*)(wp + ((size_t)((ct * 7 + kh) * 2 + g) * 64 + lane) * 8);
+    for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+        const int n = row / Ho, ho = row - n * Ho;
+        __syncthreads();
+        for (int i = tid; i < 7 * PW; i += kC7mThreads) {
+            const int kh = i / PW, pc = i - kh * PW;
+            const int hi = 2 * ho + kh - 3, wi = pc - 3;
+            T o[4] = {Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f)};
+            if (hi >= 0 && hi < H && wi >= 0 && wi < W) {
+                const float* px = x + ((size_t)(n * H + hi) * W + wi) * 3;
+                o[0] = Elem<T>::from_f32(px[0]); o[1] = Elem<T>::from_f32(px[1]); o[2] = Elem<T>::from_f32(px[2]);
+            }
+            *(u32x2*)(rows + (size_t)i * 8) = *(const u32x2*)o;
+        }
+        __syncthreads();
+        for (int grp = wave; grp * 32 < Wo; grp += kC7mThreads / 64) {
+            const int wo = grp * 32 + r32;
+            f32x16 acc[2];
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
+            const char* win = rows + (size_t)wo * 16 + 16 * hh;        // the window's first pixel is input column 2 wo (padded)
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const frag_t fb = *(const frag_t*)(win + (size_t)kh * PW * 8 + 32 * g);
+                    mma32(acc[0], fw[0][kh][g], fb);
+                    mma32(acc[1], fw[1][kh][g], fb);
+                }
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    *(f32x4*)(patch + r32 * PROW + ct * 32 + 8 * q4 + 4 * hh) =
+                        f32x4{acc[ct][4 * q4], acc[ct][4 * q4 + 1], acc[ct][4 * q4 + 2], acc[ct][4 * q4 + 3]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int p = it * 4 + (lane >> 4), ch = lane & 15;
+                if (grp * 32 + p < Wo && ch * 4 < Co)
+                    *(f32x4*)(y + ((size_t)row * Wo + grp * 32 + p) * Co + ch * 4) = *(const f32x4*)(patch + p * PROW + ch * 4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+template <typename T>
+static int conv7_mfma_T(const float* x, const float* w, float* y, int N, int H, int W, int Cout, hipStream_t s) {
+    const int Wo = (W + 1) / 2, groups = (Wo + 31) / 32;
+    const int PW = 2 * groups * 32 + 8;               // every window of every group's 32 pixels stays inside the row
+    const size_t lds = (size_t)7 * PW * 8 + (size_t)(kC7mThreads / 64) * 32 * (64 + 4) * sizeof(float);
+    if (lds > 64 * 1024) return Y2_ERR_ARG;
+    const int total = 2 * 7 * 2 * 64;
+    T* wp = (T*)op_scratch(s, (size_t)total * 8 * sizeof(T));
+    if (!wp) return op_scratch_error();
+    hipLaunchKernelGGL(rn_conv7_pack_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, s, w, wp, Cout, total);
+    const int rows = N * ((H + 1) / 2);
+    hipLaunchKernelGGL(rn_conv7_mfma_kernel<T>, dim3(rows < 1024 ? rows : 1024), dim3(kC7mThreads), lds, s, x, (const T*)wp, y, N, H, W,
+                       Cout, PW);
+    RCHK(hipGetLastError());
+    return Y2_OK;
+}
+
 extern "C" {
 
 int y2_batch_norm_forward(const float* x, const float* residual, float* y, size_t rows, int channels, const float* gamma,
@@ -853,6 +962,15 @@ int y2_conv7x7s2(const float* x, const float* w, float* y, int N, int H, int W, 
                        y, N, H, W, Cout);
     RCHK(hipGetLastError());
     return Y2_OK;
+}
+int y2_conv7x7s2_t(const float* x, const float* w, float* y, int N, int H, int W, int Cout, int dtype, void* stream) {
+    if (!x || !w || !y || N < 1 || H < 1 || W < 1 || Cout < 1) return rfail(Y2_ERR_ARG, "bad arguments");
+    if ((dtype == 1 || dtype == 2) && Cout <= 64 && (Cout % 4) == 0) {
+        const int rc = dtype == 1 ? conv7_mfma_T<half_t>(x, w, y, N, H, W, Cout, (hipStream_t)stream)
+                                  : conv7_mfma_T<bf16_t>(x, w, y, N, H, W, Cout, (hipStream_t)stream);
+        if (rc != Y2_ERR_ARG) return rc;         // (rows too long for the staged window: the fp32 kernel decides)
+    }
+    return y2_conv7x7s2(x, w, y, N, H, W, Cout, stream);
 }
 int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* stream) {
     if (!x || !dy || !dw || N < 1 || H < 1 || W < 1) return rfail(Y2_ERR_ARG, "bad arguments");

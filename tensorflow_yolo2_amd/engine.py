@@ -965,13 +965,14 @@ def max_pool_3x3_s2_backward(x, dy):
     return dx
 
 
-def conv7x7_s2(x, w):
+def conv7x7_s2(x, w, dtype="f32"):
+    """the root block's conv2d_same(net, 64, 7, stride=2) (resnet_v1.py:197); dtype f16 / bf16: on the matrix pipe"""
     lib = _lib.load()
     _chk(x, w)
     n, h, wd, _ = x.shape
     co = w.shape[3]
     y = torch.empty((n, (h + 1) // 2, (wd + 1) // 2, co), dtype=torch.float32, device=x.device)
-    check(lib.y2_conv7x7s2(_ptr(x), _ptr(w), _ptr(y), n, h, wd, co, _stream()))
+    check(lib.y2_conv7x7s2_t(_ptr(x), _ptr(w), _ptr(y), n, h, wd, co, _lib.DTYPES[dtype], _stream()))
     return y
 
 

@@ -344,7 +344,7 @@ class ResNet50Yolo:
         assert tuple(images.shape) == (self.batch, self.size, self.size, 3) and images.is_cuda
         self._training, self._update_moving = bool(is_training), bool(update_moving)
         tape = []
-        x = E.conv7x7_s2(images.contiguous(), self.p["conv1/weights"])                     # resnet_v1.py:197
+        x = E.conv7x7_s2(images.contiguous(), self.p["conv1/weights"], self.dtype)         # resnet_v1.py:197
         tape.append(("conv7", images))
         x, r = self._bn(x, "conv1", True); tape.append(r)
         pooled = E.max_pool_3x3_s2(x); tape.append(("pool", x)); x = pooled                # resnet_v1.py:198

@@ -156,6 +156,36 @@ def test_root_convolution_at_224_vs_float64():
         assert torch.equal(dw, E.conv7x7_s2_backward_filter(dev(x), dev(dy)))
 
 
+@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("bf16", 8e-3)])
+def test_root_convolution_on_the_matrix_pipe(dtype, tol):
+    """y2_conv7x7s2_t (round 5): conv2d_same(64, 7, stride 2) of the root block (resnet_v1.py:197) with half-precision
+    operands on the matrix pipe -- against float64 on the operands as the kernel rounds them (1e-5: the arithmetic) and on
+    the fp32 operands (the type's tolerance), at the network's geometry, an odd size, few filters, and a filter count that
+    falls back to the fp32 kernel; the ordinary entry point's result is the fp32 one."""
+    from tensorflow_yolo2_amd import engine as E
+    rng = np.random.default_rng(21)
+    td = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype]
+    for (n, h, w, co) in ((8, 224, 224, 64), (2, 96, 96, 32), (1, 37, 51, 24), (3, 64, 64, 8), (1, 30, 30, 6)):
+        x = rng.uniform(-1, 1, (n, h, w, 3)).astype(np.float32)
+        wt = (rng.standard_normal((7, 7, 3, co)) * 0.1).astype(np.float32)
+        y = E.conv7x7_s2(dev(x), dev(wt), dtype)
+        ref = RR.conv2d_same(torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2), torch.tensor(wt, dtype=torch.float64), 2)
+        ref = ref.permute(0, 2, 3, 1).numpy()
+        assert tuple(y.shape) == ref.shape
+        e = rel(y.cpu().numpy(), ref)
+        if co % 4 == 0:
+            xq, wq = torch.tensor(x).to(td).double(), torch.tensor(wt).to(td).double()
+            refq = RR.conv2d_same(xq.permute(0, 3, 1, 2), wq, 2).permute(0, 2, 3, 1).numpy()
+            eq = rel(y.cpu().numpy(), refq)
+            print("root conv %s %dx%dx%d, %d filters: %.2e of the max (rounded operands: %.2e)" % (dtype, n, h, w, co, e, eq))
+            assert eq < 1e-5, (n, h, w, co, eq)
+            assert e < tol, (n, h, w, co, e)
+        else:       # not a multiple of 4 filters: the fp32 kernel
+            assert e < 1e-5, (n, h, w, co, e)
+    y32 = E.conv7x7_s2(dev(x), dev(wt))
+    assert rel(y32.cpu().numpy(), ref) < 1e-5
+
+
 @pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("f16", 1e-3), ("bf16", 8e-3)])
 @pytest.mark.parametrize("M,K,N", [(32, 25088, 1024), (4, 1024, 98), (70, 512, 200), (128, 4096, 1470), (1, 16, 3)])
 def test_fully_connected_forward_backward_vs_float64(M, K, N, dtype, tol):
