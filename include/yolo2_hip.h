@@ -210,6 +210,14 @@ int y2_link(y2_ctx* ctx, void* x_bordered, void* out_bordered, const void* join_
             void* dx_t);
 int y2_join_backward(int dtype, const void* out_bordered, const void* d1, const void* d2, int d2_f32, void* g, int N, int H,
                      int W, int C, void* stream);
+/* ... with a STRIDE-2 unit above (round 5: the last unit of blocks 1-3 inside a linked run).  y2_subsample_bordered:
+ * resnet_utils.subsample(x, 2) (resnet_utils.py:60-75) from a bordered tensor [N][H+1][W+1][C] of T into one of half the
+ * size -- that unit's identity shortcut, joined in its last apply pass (y2_link join_bordered).  y2_join_backward_s2: as
+ * y2_join_backward, but d2 -- the gradient of that shortcut -- lives on the upper unit's OUTPUT grid [N*H/2*W/2][C] and
+ * reaches the even rows / columns of this [N*H*W] grid only. */
+int y2_subsample_bordered(int dtype, const void* src_bordered, void* dst_bordered, int N, int H, int W, int C, void* stream);
+int y2_join_backward_s2(int dtype, const void* out_bordered, const void* d1, const void* d2, int d2_f32, void* g, int N, int H,
+                        int W, int C, void* stream);
 /* scores [rows][classes] -> best score and class index per row (the class choice in front of the NMS of the YOLOv2
  * detector; ties: smallest index, as np.argmax in net_utils.py:418) */
 int y2_class_argmax(const float* scores, float* best, int* cls, int rows, int classes, void* stream);

@@ -704,6 +704,52 @@ __global__ void rn_join_bwd_t_kernel(const T* __restrict__ outb, const T* __rest
         y2::st_chunk<T>(g + m * C + c, r);
     }
 }
+// The same join one level down a STRIDE-2 unit (y2_join_backward_s2): the second addend is the gradient of the unit's
+// identity shortcut subsample(x) (resnet_v1.py:99-101) and lives on the unit's OUTPUT grid [N][H/2][W/2][C]: it reaches
+// the even rows / columns of this [N][H][W] grid, the other positions take d1 alone.
+template <typename T>
+__global__ void rn_join_bwd_s2_kernel(const T* __restrict__ outb, const T* __restrict__ d1, const void* __restrict__ d2,
+                                      int d2_f32, T* __restrict__ g, int N, int H, int W, int C) {
+    const int cg = C / 8, Hs = H / 2, Ws = W / 2;
+    const size_t total = (size_t)N * H * W * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cg) * 8;
+        const size_t m = i / cg;
+        const int w = (int)(m % W), h = (int)((m / W) % H), n = (int)(m / ((size_t)W * H));
+        const y2::Chunk<T> o = y2::ld_chunk<T>(outb + y2::bpix(n, h, w, H, W) * C + c);
+        const y2::Chunk<T> a = y2::ld_chunk<T>(d1 + m * C + c);
+        float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!(h & 1) && !(w & 1)) {
+            const size_t ms = ((size_t)n * Hs + (h >> 1)) * Ws + (w >> 1);
+            if (d2_f32) {
+                const float4 b0 = *(const float4*)((const float*)d2 + ms * C + c), b1 = *(const float4*)((const float*)d2 + ms * C + c + 4);
+                b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+            } else {
+                const y2::Chunk<T> bt = y2::ld_chunk<T>((const T*)d2 + ms * C + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b[e] = y2::Elem<T>::to_f32(bt.v[e]);
+            }
+        }
+        y2::Chunk<T> r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            r.v[e] = y2::Elem<T>::from_f32(y2::Elem<T>::to_f32(o.v[e]) > 0.f ? y2::Elem<T>::to_f32(a.v[e]) + b[e] : 0.f);
+        y2::st_chunk<T>(g + m * C + c, r);
+    }
+}
+// resnet_utils.subsample(x, 2) between two bordered tensors of the arithmetic type (y2_subsample_bordered): the identity
+// shortcut of a stride-2 unit inside a linked run; 16-byte chunks (8 channels)
+template <typename T>
+__global__ void rn_subsample_bordered_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int H, int W, int C) {
+    const int cg = C / 8, Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo * cg;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cg) * 8;
+        const size_t m = i / cg;
+        const int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho), n = (int)(m / ((size_t)Wo * Ho));
+        y2::st_chunk<T>(dst + y2::bpix(n, ho, wo, Ho, Wo) * C + c, y2::ld_chunk<T>(src + y2::bpix(n, 2 * ho, 2 * wo, H, W) * C + c));
+    }
+}
 // ---------------------------------------------------------------------------
 // Round 5: the root convolution on the matrix pipe in the half-precision modes (y2_conv7x7s2_t).  The scalar kernel above
 // is bound by its LDS issue rate (147 wave-uniform reads per 147 FMAs: 0.40 ms at batch 32, 3.6 % of the ResNet step).
@@ -921,6 +967,38 @@ int y2_join_backward(int dtype, const void* out_bordered, const void* d1, const 
     else
         hipLaunchKernelGGL(rn_join_bwd_t_kernel<y2::bf16_t>, grid, block, 0, (hipStream_t)stream, (const y2::bf16_t*)out_bordered,
                            (const y2::bf16_t*)d1, d2, d2_f32, (y2::bf16_t*)g, N, H, W, C);
+    RCHK(hipGetLastError());
+    return Y2_OK;
+}
+
+int y2_join_backward_s2(int dtype, const void* out_bordered, const void* d1, const void* d2, int d2_f32, void* g, int N, int H,
+                        int W, int C, void* stream) {
+    if (!out_bordered || !d1 || !d2 || !g) return rfail(Y2_ERR_ARG, "y2_join_backward_s2: null tensor");
+    if (dtype != 1 && dtype != 2) return rfail(Y2_ERR_ARG, "y2_join_backward_s2: the 16-bit arithmetic types");
+    if (C % 8 != 0 || (H & 1) || (W & 1)) return rfail(Y2_ERR_ARG, "y2_join_backward_s2: channels in multiples of 8, an even map");
+    const size_t total = (size_t)N * H * W * (C / 8);
+    const dim3 grid(grid_for(total)), block(256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(rn_join_bwd_s2_kernel<y2::half_t>, grid, block, 0, (hipStream_t)stream, (const y2::half_t*)out_bordered,
+                           (const y2::half_t*)d1, d2, d2_f32, (y2::half_t*)g, N, H, W, C);
+    else
+        hipLaunchKernelGGL(rn_join_bwd_s2_kernel<y2::bf16_t>, grid, block, 0, (hipStream_t)stream, (const y2::bf16_t*)out_bordered,
+                           (const y2::bf16_t*)d1, d2, d2_f32, (y2::bf16_t*)g, N, H, W, C);
+    RCHK(hipGetLastError());
+    return Y2_OK;
+}
+int y2_subsample_bordered(int dtype, const void* src_bordered, void* dst_bordered, int N, int H, int W, int C, void* stream) {
+    if (!src_bordered || !dst_bordered) return rfail(Y2_ERR_ARG, "y2_subsample_bordered: null tensor");
+    if (dtype != 1 && dtype != 2) return rfail(Y2_ERR_ARG, "y2_subsample_bordered: the 16-bit arithmetic types");
+    if (C % 8 != 0 || (H & 1) || (W & 1)) return rfail(Y2_ERR_ARG, "y2_subsample_bordered: channels in multiples of 8, an even map");
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 8);
+    const dim3 grid(grid_for(total)), block(256);
+    if (dtype == 1)
+        hipLaunchKernelGGL(rn_subsample_bordered_kernel<y2::half_t>, grid, block, 0, (hipStream_t)stream,
+                           (const y2::half_t*)src_bordered, (y2::half_t*)dst_bordered, N, H, W, C);
+    else
+        hipLaunchKernelGGL(rn_subsample_bordered_kernel<y2::bf16_t>, grid, block, 0, (hipStream_t)stream,
+                           (const y2::bf16_t*)src_bordered, (y2::bf16_t*)dst_bordered, N, H, W, C);
     RCHK(hipGetLastError());
     return Y2_OK;
 }

@@ -412,14 +412,26 @@ class Bordered:
         return self._interior().float()
 
 
-def join_backward(dtype, out_bordered, d1, d2, g):
-    """g = (d1 + d2) * [out > 0] between linked stacks (y2_join_backward); d2 fp32 or of the arithmetic type"""
+def join_backward(dtype, out_bordered, d1, d2, g, stride=1):
+    """g = (d1 + d2) * [out > 0] between linked stacks (y2_join_backward); d2 fp32 or of the arithmetic type.
+    stride 2: the unit above is a stride-2 unit, d2 lives on ITS output grid (y2_join_backward_s2)"""
     lib = _lib.load()
     dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
     n, h, w, c = out_bordered.shape
-    check(lib.y2_join_backward(dt, C.c_void_p(out_bordered.cell0), C.c_void_p(d1.data_ptr()), C.c_void_p(d2.data_ptr()),
-                               int(d2.dtype == torch.float32), C.c_void_p(g.data_ptr()), n, h, w, c, _stream()))
+    fn = lib.y2_join_backward if stride == 1 else lib.y2_join_backward_s2
+    check(fn(dt, C.c_void_p(out_bordered.cell0), C.c_void_p(d1.data_ptr()), C.c_void_p(d2.data_ptr()),
+             int(d2.dtype == torch.float32), C.c_void_p(g.data_ptr()), n, h, w, c, _stream()))
     return g
+
+
+def subsample_bordered(dtype, src, dst):
+    """resnet_utils.subsample(x, 2) between two Bordered tensors of the arithmetic type (y2_subsample_bordered)"""
+    lib = _lib.load()
+    dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    n, h, w, c = src.shape
+    assert tuple(dst.shape) == (n, h // 2, w // 2, c)
+    check(lib.y2_subsample_bordered(dt, C.c_void_p(src.cell0), C.c_void_p(dst.cell0), n, h, w, c, _stream()))
+    return dst
 
 
 # ---------------------------------------------------------------------------

@@ -58,6 +58,7 @@ def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, 
 
 _TWO_CALL_JOIN = bool(os.environ.get("Y2_RESNET_TWO_CALL_JOIN"))
 _NO_STRIDED_STACKS = bool(os.environ.get("Y2_RESNET_NO_STRIDED_STACKS"))   # A/B: the stride-2 units on fp32 operators
+_NO_STRIDED_LINK = bool(os.environ.get("Y2_RESNET_NO_STRIDED_LINK"))       # A/B: ... on the executor, but outside the linked runs
 _NO_LINK = bool(os.environ.get("Y2_RESNET_NO_LINK"))       # A/B: round 4's fp32 hand-over between the fused units
 
 
@@ -207,8 +208,13 @@ class ResNet50Yolo:
         for bname, blk in self.blocks:
             for i, (depth, db, stride) in enumerate(blk):
                 sc = "%s/unit_%d/bottleneck_v1/" % (bname, i + 1)
-                if self.fused and stride == 1:
-                    u = {"scope": sc, "hw": hw, "cin": cin, "depth": depth, "db": db, "proj": depth != cin}
+                # (round 5: a stride-2 unit with an identity shortcut continues the run it sits on -- its shortcut is the typed
+                #  subsample of the run's activation, its shortcut gradient reaches the unit below through y2_join_backward_s2)
+                strided_ok = (stride == 2 and depth == cin and hw % 2 == 0 and bool(run) and not _NO_STRIDED_STACKS
+                              and not _NO_STRIDED_LINK)
+                if self.fused and (stride == 1 or strided_ok):
+                    u = {"scope": sc, "hw": hw, "cin": cin, "depth": depth, "db": db, "proj": depth != cin, "stride": stride,
+                         "hwo": (hw + stride - 1) // stride}
                     if not run and not u["proj"]:
                         close([u])                      # an identity unit cannot open a run: it stays on the fp32 interface
                     else:
@@ -225,15 +231,21 @@ class ResNet50Yolo:
                 u["below"] = u["above"] = None
         dev, dt, n = str(self.device), self.dtype, self.batch
         tdt = torch.float16 if dt == "f16" else torch.bfloat16
-        for u in units.values():
-            main, proj = self._stack_for(u["scope"], u["hw"], u["cin"], u["depth"], u["db"])
+        for u in list(units.values()):
+            if u["stride"] == 2 and u["bottom"] and u["top"]:
+                del units[u["scope"]]          # an unlinked strided unit: the fp32-interface path of forward() ("fused_s")
+                continue
+            main, proj = self._stack_for(u["scope"], u["hw"], u["cin"], u["depth"], u["db"], stride=u["stride"])
             u["main"], u["pstack"] = main, proj
             m = n * u["hw"] * u["hw"]
+            mo = n * u["hwo"] * u["hwo"]
             if not u["top"]:      # my output is the next unit's bordered input
-                u["out_b"] = E.Bordered(n, u["hw"], u["hw"], u["depth"], dt, dev)
-                u["g"] = torch.zeros((m, u["depth"]), dtype=tdt, device=dev)        # my join's gradient (T), made by join_backward
+                u["out_b"] = E.Bordered(n, u["hwo"], u["hwo"], u["depth"], dt, dev)
+                u["g"] = torch.zeros((mo, u["depth"]), dtype=tdt, device=dev)       # my join's gradient (T), made by join_backward
             if u["proj"] and not (u["bottom"] and u["top"]):
                 u["short_b"] = E.Bordered(n, u["hw"], u["hw"], u["depth"], dt, dev)  # the projection's output, joined in T
+            if u["stride"] == 2:
+                u["short_b"] = E.Bordered(n, u["hwo"], u["hwo"], u["depth"], dt, dev)   # subsample(x), joined in T
             if not u["bottom"]:
                 u["dxm"] = torch.zeros((m, u["cin"]), dtype=tdt, device=dev)
                 if u["proj"]:
@@ -246,6 +258,8 @@ class ResNet50Yolo:
             g_in = u.get("g")                               # None at the top: fp32 dout through the convert pass
             if u["proj"]:
                 u["pstack"].link(x=xin, out=u["short_b"], dout=g_in, dx=u.get("dxp"))
+                u["main"].link(x=xin, out=out_b, join=u["short_b"], dout=g_in, dx=u.get("dxm"))
+            elif u["stride"] == 2:
                 u["main"].link(x=xin, out=out_b, join=u["short_b"], dout=g_in, dx=u.get("dxm"))
             else:
                 u["main"].link(x=xin, out=out_b, join_self=True, dout=g_in, dx=u.get("dxm"))
@@ -352,20 +366,22 @@ class ResNet50Yolo:
         for bname, blk in self.blocks:
             for i, (depth, db, stride) in enumerate(blk):                                    # resnet_v1.py:99-112
                 sc = "%s/unit_%d/bottleneck_v1/" % (bname, i + 1)
-                if self.fused and stride == 1 and not (units[sc]["bottom"] and units[sc]["top"]):
+                if self.fused and sc in units and not (units[sc]["bottom"] and units[sc]["top"]):
                     # linked run: typed tensors between the units, fp32 only where the run meets the graph-level operators
                     u = units[sc]
                     xin = x.contiguous() if u["bottom"] else None
                     out = None
                     if u["top"]:
-                        out = torch.empty((self.batch, u["hw"], u["hw"], u["depth"]), dtype=torch.float32, device=self.device)
+                        out = torch.empty((self.batch, u["hwo"], u["hwo"], u["depth"]), dtype=torch.float32, device=self.device)
+                    if u["stride"] == 2:       # the identity shortcut subsample(x), in the arithmetic type
+                        E.subsample_bordered(self.dtype, u["below"]["out_b"], u["short_b"])
                     if u["proj"]:
                         u["pstack"].forward_linked(is_training, update_moving, images=xin)
                     u["main"].forward_linked(is_training, update_moving, out=out, images=xin)
                     tape.append(("linked", u, out))
                     x = out
                     continue
-                if self.fused and stride == 2 and depth == x.shape[3] and x.shape[1] % 2 == 0 and not _NO_STRIDED_STACKS:
+                if self.fused and stride == 2 and x is not None and depth == x.shape[3] and x.shape[1] % 2 == 0 and not _NO_STRIDED_STACKS:
                     # round 5: the strided unit on the stack executor too (conv2 a subsampling layer); the identity
                     # shortcut subsample(x) (resnet_v1.py:99-101) joins in the main stack's last apply pass
                     main, _ = self._stack_for(sc, int(x.shape[1]), int(x.shape[3]), depth, db, stride=2)
@@ -456,7 +472,7 @@ class ResNet50Yolo:
                 else:
                     a = u["above"]
                     # g = (main branch of the unit above + its shortcut branch) * [my output > 0], all in T
-                    E.join_backward(self.dtype, u["out_b"], a["dxm"], a["_short_grad"], u["g"])
+                    E.join_backward(self.dtype, u["out_b"], a["dxm"], a["_short_grad"], u["g"], stride=a["stride"])
                     if u["bottom"]:
                         # the run's bottom: the input gradient leaves as two fp32 addends (main branch, projection)
                         dx = torch.empty((self.batch, u["hw"], u["hw"], u["cin"]), dtype=torch.float32, device=self.device)

@@ -592,7 +592,8 @@ def test_resnet50_fused_stacks_match_the_operator_path_f16_and_train():
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", ["f16"])      # (bf16: the interface test below; its 8-bit joins differ by 8e-2 at the grid)
 def test_resnet_linked_runs_match_the_fp32_hand_over(dtype):
-    """Three runs of two stride-1 units (a projection at the bottom of each) between strided units on the fp32 operators, at
+    """Nine units -- three pairs of stride-1 units (a projection in front of each pair) and the three stride-2 units between
+    them, which continue the run since round 5 (typed subsample for their shortcut, y2_join_backward_s2 below them) -- at
     64 x 64 ... 8 x 8 maps / batch 8 -- hundreds to thousands of samples per batch-norm channel, so the
     comparison is not the chaos of the 2 x 2 maps of the full-depth toy models: the linked composition against the same
     model with round 4's fp32 hand-over between the units (link=False) on the same variables.  What differs is WHERE the
@@ -617,7 +618,9 @@ def test_resnet_linked_runs_match_the_fp32_hand_over(dtype):
     gb = b.forward(x, True, update_moving=True, dropout=False).clone()
     units = a._linked_units(64, 64)
     runs = [(u["scope"], u["bottom"], u["top"]) for u in units.values()]
-    assert sum(1 for _s, bo, to in runs if not (bo and to)) == 6, runs          # all six stride-1 units are linked
+    # all six stride-1 units are linked -- and, since the strided units moved onto the executor, the three stride-2 units
+    # between them too: one run from block1/unit_1 to block4/unit_2
+    assert sum(1 for _s, bo, to in runs if not (bo and to)) == 9, runs
     e = rel(ga.cpu().numpy(), gb.cpu().numpy().astype(np.float64))
     print("linked vs fp32 hand-over %s: grid %.2e of the max" % (dtype, e))
     assert e < 2e-2, e
@@ -645,6 +648,40 @@ def test_resnet_linked_runs_match_the_fp32_hand_over(dtype):
     # and the linked model trains
     losses = [float(a.step(x, lab)[0][4]) for _ in range(6)]
     assert all(np.isfinite(losses)) and min(losses[3:]) < losses[0], losses
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_strided_unit_link_kernels_against_their_formulas(dtype):
+    """y2_subsample_bordered (the identity shortcut of a stride-2 unit inside a linked run: resnet_utils.subsample between
+    two bordered tensors of the arithmetic type) and y2_join_backward_s2 (the join one level below it: the shortcut's
+    gradient lives on the strided unit's OUTPUT grid and reaches the even positions only), typed and fp32 second addend:
+    bit-identical to the formulas on values the type represents."""
+    from tensorflow_yolo2_amd import engine as E
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    rng = np.random.default_rng(11)
+    N, hw, c = 3, 12, 64
+    x = torch.as_tensor(rng.standard_normal((N, hw, hw, c)).astype(np.float32)).to(tdt).cuda()
+    src = E.Bordered(N, hw, hw, c, dtype, "cuda:0")
+    dst = E.Bordered(N, hw // 2, hw // 2, c, dtype, "cuda:0")
+    src.write(x.float())
+    E.subsample_bordered(dtype, src, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.read(), x[:, ::2, ::2, :].float())
+    raw = dst.buf.view(tdt) if dst.buf.numel() % 2 == 0 else None
+    # borders of the destination stay zero
+    assert float(dst.read().abs().sum()) > 0 and float(dst.buf.view(torch.uint8).float().sum()) > 0
+    out = torch.as_tensor(rng.standard_normal((N, hw, hw, c)).astype(np.float32)).to(tdt).cuda()
+    src.write(out.float())
+    d1 = torch.as_tensor(rng.standard_normal((N * hw * hw, c)).astype(np.float32)).to(tdt).cuda()
+    for d2 in (torch.as_tensor(rng.standard_normal((N * (hw // 2) ** 2, c)).astype(np.float32)).to(tdt).cuda(),
+               torch.as_tensor(rng.standard_normal((N * (hw // 2) ** 2, c)).astype(np.float32)).cuda()):
+        g = torch.empty_like(d1)
+        E.join_backward(dtype, src, d1, d2, g, stride=2)
+        torch.cuda.synchronize()
+        full = torch.zeros((N, hw, hw, c), dtype=torch.float32, device="cuda")
+        full[:, ::2, ::2, :] = d2.float().view(N, hw // 2, hw // 2, c)
+        want = torch.where(out.float() > 0, d1.float().view(N, hw, hw, c) + full, torch.zeros_like(full)).to(tdt)
+        assert torch.equal(g.view(N, hw, hw, c), want), str(d2.dtype)
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
