@@ -66,6 +66,13 @@ int y2_darknet19_spec(int kind, int output_filter, int* spec, int max_layers);
 int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers, int tail, int tail_k,
                   int batch, int height, int width, int dtype);
 void y2_ctx_destroy(y2_ctx* ctx);
+/* A GROUP of bound contexts on one flat parameter buffer (round 5: the 20 stacks of the ResNet swap) re-packs its filters
+ * in ONE launch instead of one per context.  y2_pack_group_table: once, outside any stream capture (a synchronous copy) --
+ * the concatenated pack tables into caller-owned device memory (table_bytes >= 128 * layers is ample); returns the layer
+ * and block counts.  y2_pack_group_run: the launch; afterwards the contexts' packed copies are current (the lazy pack of
+ * their next y2_forward is skipped).  Contexts with a 3-channel first layer pack on their own. */
+int y2_pack_group_table(y2_ctx** ctxs, int n, void* table_dev, size_t table_bytes, int* nlayers, int* blocks);
+int y2_pack_group_run(y2_ctx** ctxs, int n, const void* table_dev, int nlayers, int blocks, void* stream);
 int y2_num_layers(const y2_ctx* ctx);
 /* info: k, cin, cout, pool, H, W (conv input = output spatial size), Ho, Wo */
 int y2_layer_info(const y2_ctx* ctx, int layer, int info[8]);

@@ -78,6 +78,8 @@ SIGNATURES = {
     "y2_bordered_bytes": (_sz, [_i, _i, _i, _i, _i, _psz]),
     "y2_link": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "y2_join_backward": (_i, [_i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "y2_pack_group_table": (_i, [_vp, _i, _vp, _sz, _pi, _pi]),
+    "y2_pack_group_run": (_i, [_vp, _i, _vp, _i, _i, _vp]),
     "y2_join_backward_s2": (_i, [_i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "y2_subsample_bordered": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_scale": (_i, [_vp, _sz, _f, _vp]),

@@ -650,6 +650,40 @@ static int pack_all_weights(y2_ctx* c, hipStream_t s) {
     return Y2_OK;
 }
 
+// ONE filter-pack launch for a GROUP of contexts (round 5: the ResNet swap binds 20 small stacks to one flat parameter
+// buffer; after every optimizer step each of them used to re-pack its three filters in its own 10-us launch).
+// y2_pack_group_table: the concatenated pack tables of the contexts (first blocks re-based) into device memory the caller
+// owns -- a synchronous copy, once, outside any capture; returns layers / blocks of the group launch.
+// y2_pack_group_run: that launch; the contexts' packed copies are current afterwards (their own lazy pack is skipped).
+int y2_pack_group_table(y2_ctx** ctxs, int n, void* table_dev, size_t table_bytes, int* nlayers, int* blocks) {
+    if (!ctxs || n < 1 || !table_dev || !nlayers || !blocks) return fail(Y2_ERR_ARG, "y2_pack_group_table: bad arguments");
+    std::vector<PackLayer> all;
+    int nb = 0;
+    for (int i = 0; i < n; ++i) {
+        y2_ctx* c = ctxs[i];
+        if (!c || !c->ws) return fail(Y2_ERR_STATE, "y2_pack_group_table: context %d is not bound", i);
+        if (c->dtype != ctxs[0]->dtype) return fail(Y2_ERR_ARG, "y2_pack_group_table: one arithmetic type per group");
+        if (!c->L.empty() && c->L[0].first3) return fail(Y2_ERR_ARG, "y2_pack_group_table: a 3-channel first layer packs on its own");
+        for (PackLayer p : c->packtab) {
+            p.first_block += nb;
+            all.push_back(p);
+        }
+        nb += c->pack_blocks;
+    }
+    if (all.size() * sizeof(PackLayer) > table_bytes) return fail(Y2_ERR_ARG, "y2_pack_group_table: %zu bytes needed", all.size() * sizeof(PackLayer));
+    if (!all.empty()) HIPCHK(hipMemcpy(table_dev, all.data(), all.size() * sizeof(PackLayer), hipMemcpyHostToDevice));
+    *nlayers = (int)all.size();
+    *blocks = nb;
+    return Y2_OK;
+}
+int y2_pack_group_run(y2_ctx** ctxs, int n, const void* table_dev, int nlayers, int blocks, void* stream) {
+    if (!ctxs || n < 1 || !table_dev) return fail(Y2_ERR_ARG, "y2_pack_group_run: bad arguments");
+    if (nlayers > 0 && blocks > 0)
+        HIPCHK(launch_pack_all(ctxs[0]->dtype, (const PackLayer*)table_dev, nlayers, blocks, (hipStream_t)stream));
+    for (int i = 0; i < n; ++i) ctxs[i]->weights_dirty = false;
+    return Y2_OK;
+}
+
 static int forward_impl(y2_ctx* c, const float* images, const uint8_t* images_u8, int train_core, int train_head,
                         int update_moving, float* out, void* stream, const float* join = nullptr);
 int y2_forward(y2_ctx* c, const float* images, int train_core, int train_head, int update_moving, float* out,

@@ -58,6 +58,7 @@ def variable_list(blocks=BLOCKS_50, root_depth=64, fc_hidden=4096, fc_out=1470, 
 
 _TWO_CALL_JOIN = bool(os.environ.get("Y2_RESNET_TWO_CALL_JOIN"))
 _NO_STRIDED_STACKS = bool(os.environ.get("Y2_RESNET_NO_STRIDED_STACKS"))   # A/B: the stride-2 units on fp32 operators
+_NO_PACK_GROUP = bool(os.environ.get("Y2_RESNET_NO_PACK_GROUP"))           # A/B: every stack re-packs its filters itself
 _NO_STRIDED_LINK = bool(os.environ.get("Y2_RESNET_NO_STRIDED_LINK"))       # A/B: ... on the executor, but outside the linked runs
 _NO_LINK = bool(os.environ.get("Y2_RESNET_NO_LINK"))       # A/B: round 4's fp32 hand-over between the fused units
 
@@ -272,6 +273,28 @@ class ResNet50Yolo:
             main.params_changed()
             if proj is not None:
                 proj.params_changed()
+        self._packs_dirty = True
+
+    def _pack_group(self):
+        """round 5: ONE filter-pack launch for all stacks (y2_pack_group_run) instead of one per stack at its next forward
+        (20 launches of ~10 us per step); the table is built once the stacks exist (after the first forward)"""
+        if not getattr(self, "pack_group", not _NO_PACK_GROUP) or not self._stacks or not getattr(self, "_packs_dirty", True):
+            return
+        import ctypes as C
+        nets = [n for pair in self._stacks.values() for n in pair if n is not None]
+        key = tuple(id(n) for n in nets)
+        lib = E._lib.load()
+        if getattr(self, "_pack_key", None) != key:
+            if torch.cuda.is_current_stream_capturing():
+                return                                   # (built outside captures; this step packs per stack)
+            arr = (C.c_void_p * len(nets))(*[n.h.value for n in nets])
+            tab = torch.zeros(256 * 3 * len(nets), dtype=torch.uint8, device=self.device)
+            nl, nb = C.c_int(0), C.c_int(0)
+            E.check(lib.y2_pack_group_table(arr, len(nets), E._ptr(tab), tab.numel(), C.byref(nl), C.byref(nb)))
+            self._pack_key, self._pack_arr, self._pack_tab, self._pack_counts = key, arr, tab, (nl.value, nb.value)
+        E.check(lib.y2_pack_group_run(self._pack_arr, len(nets), E._ptr(self._pack_tab), self._pack_counts[0],
+                                      self._pack_counts[1], E._stream()))
+        self._packs_dirty = False
 
     # ---- variables ---------------------------------------------------------
     def init_params(self, seed=0):
@@ -357,6 +380,7 @@ class ResNet50Yolo:
         """images [N,size,size,3] fp32 -> grid_net [N,S,S,5B+C] (pascal_train_resnet.py:37-50)"""
         assert tuple(images.shape) == (self.batch, self.size, self.size, 3) and images.is_cuda
         self._training, self._update_moving = bool(is_training), bool(update_moving)
+        self._pack_group()
         tape = []
         x = E.conv7x7_s2(images.contiguous(), self.p["conv1/weights"], self.dtype)         # resnet_v1.py:197
         tape.append(("conv7", images))

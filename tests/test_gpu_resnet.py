@@ -780,6 +780,27 @@ def test_resnet_fc1_update_fused_with_its_gradient_is_bit_identical():
     assert int(a.ctrl[1]) >= 1 and int(a.ctrl[2]) >= 1          # steps applied and steps skipped were both exercised
 
 
+def test_resnet_group_pack_equals_the_per_stack_packs():
+    """y2_pack_group_table / y2_pack_group_run (round 5): ONE filter-pack launch for all stacks of the model against every
+    stack re-packing its own filters at its next forward -- the same bits in parameters, Adam slots and loss after steps
+    that move every filter (eager and replayed from the HIP graph)."""
+    from tensorflow_yolo2_amd import synthetic
+    n, size, S = 8, 96, 3
+    x, lab = dev(synthetic.images(n, size, 9)), dev(synthetic.det_labels(n, size, S, 10))
+    for graph in (False, True):
+        a, _, _ = _build("f16", div=2, size=size, n=n, fused=True, seed=4, graph=graph, loss_scale=16.0)
+        b, _, _ = _build("f16", div=2, size=size, n=n, fused=True, seed=4, graph=graph, loss_scale=16.0)
+        b.pack_group = False
+        for it in range(5):
+            la, lb = a.step(x, lab), b.step(x, lab)
+            torch.cuda.synchronize()
+            assert torch.equal(la[0], lb[0]), (graph, it)
+        assert getattr(a, "_pack_key", None) is not None and getattr(b, "_pack_key", None) is None
+        assert int(a.ctrl[1]) >= 2, a.ctrl[:3].tolist()          # steps were applied: the filters moved
+        assert torch.equal(a.params, b.params) and torch.equal(a.m, b.m) and torch.equal(a.v, b.v), graph
+        del a, b
+
+
 def tf_hidden():
     from tensorflow_yolo2_amd.yolo2_nets import tf_resnet
     return tf_resnet.HIDDEN
