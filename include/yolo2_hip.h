@@ -276,6 +276,8 @@ int y2_conv7x7s2(const float* x, const float* w, float* y, int N, int H, int W, 
 /* the same with the arithmetic type of the model (round 5): Y2_F16 / Y2_BF16 run it on the matrix pipe (operands rounded to
  * the type, fp32 accumulation and output; Cout <= 64, a multiple of 4), any other dtype is y2_conv7x7s2 */
 int y2_conv7x7s2_t(const float* x, const float* w, float* y, int N, int H, int W, int Cout, int dtype, void* stream);
+int y2_conv7x7s2_backward_filter_t(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, int dtype,
+                                   void* stream);
 int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* stream);
 /* slim.fully_connected (pascal_train_resnet.py:41-46; the flattened 7x7x2048 features -> 4096 -> S*S*(5B+C)) for a
  * batch of 1..128 rows: y [rows][out] = act(x [rows][in] * w [in][out] + bias), bias may be NULL, in_features a multiple

@@ -98,6 +98,7 @@ SIGNATURES = {
     "y2_conv7x7s2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "y2_conv7x7s2_t": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_conv7x7s2_backward_filter": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "y2_conv7x7s2_backward_filter_t": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "y2_bias_relu": (_i, [_vp, _vp, _sz, _i, _i, _vp]),
     "y2_bias_relu_backward": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "y2_dropout": (_i, [_vp, _vp, _sz, _f, _u64, _vp]),

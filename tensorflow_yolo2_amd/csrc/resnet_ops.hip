@@ -842,6 +842,94 @@ __global__ __launch_bounds__(kC7mThreads) void rn_conv7_mfma_kernel(const float*
         }
     }
 }
+// The root's filter gradient on the matrix pipe (y2_conv7x7s2_backward_filter_t): dW[co][kh][slot] = sum over the output
+// pixels of dy[p][co] * window_kh(p)[slot], slot = 4 kw + c -- K of the matrix products is the output pixel.  Per output
+// row the seven input rows are staged as in the forward kernel and the dy row as [wo][64] of T; wave kh reads BOTH operands
+// with hardware-transposed LDS reads (k = 16 output pixels per step: dy^T rows = filters, window columns = slots; the
+// window of pixel wo starts 16 bytes behind that of wo - 1) into two 32x32 accumulators (64 filters x 32 slots).  Block
+// partials in the scalar kernel's format, summed in a fixed order by rn_sum_partials_kernel.
+template <typename T>
+__global__ __launch_bounds__(kC7Threads) void rn_conv7_wgrad_mfma_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                         float* __restrict__ part, int N, int H, int W, int Co,
+                                                                         int PW, int WoP) {
+    typedef typename Elem<T>::frag frag_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const rows = smem;                                 // [7][PW] pixels of 4 T
+    char* const dyl = smem + (size_t)7 * PW * 8;             // [WoP][64] T
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, kh = tid >> 6;
+    const int r32 = lane & 31, hh = lane >> 5;
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1;
+    f32x16 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
+    for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+        const int n = row / Ho, ho = row - n * Ho;
+        __syncthreads();
+        for (int i = tid; i < 7 * PW; i += kC7Threads) {
+            const int r = i / PW, pc = i - r * PW;
+            const int hi = 2 * ho + r - 3, wi = pc - 3;
+            T o[4] = {Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f)};
+            if (hi >= 0 && hi < H && wi >= 0 && wi < W) {
+                const float* px = x + ((size_t)(n * H + hi) * W + wi) * 3;
+                o[0] = Elem<T>::from_f32(px[0]); o[1] = Elem<T>::from_f32(px[1]); o[2] = Elem<T>::from_f32(px[2]);
+            }
+            *(u32x2*)(rows + (size_t)i * 8) = *(const u32x2*)o;
+        }
+        for (int i = tid; i < WoP * 16; i += kC7Threads) {      // 4 filters per thread and pixel
+            const int wo = i >> 4, c4 = (i & 15) * 4;
+            T o[4] = {Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f), Elem<T>::from_f32(0.f)};
+            if (wo < Wo && c4 < Co) {
+                const f32x4 v = *(const f32x4*)(dy + ((size_t)row * Wo + wo) * Co + c4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = Elem<T>::from_f32(v[e]);
+            }
+            *(u32x2*)(dyl + (size_t)wo * 128 + c4 * 2) = *(const u32x2*)o;
+        }
+        __syncthreads();
+        const char* xr = rows + (size_t)kh * PW * 8;
+        for (int w0 = 0; w0 < WoP; w0 += 16) {
+            const int k = w0 + 8 * hh + qq;
+            const char* pb = xr + (size_t)k * 16 + (16 * g1 + 4 * pp) * 2;
+            const frag_t fb = tr_frag<T>(pb, pb + 4 * 16);
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+                const char* pa = dyl + (size_t)k * 128 + (ct * 32 + 16 * g1 + 4 * pp) * 2;
+                const frag_t fa = tr_frag<T>(pa, pa + 4 * 128);
+                mma32(acc[ct], fa, fb);
+            }
+        }
+    }
+    // D[filter (registers)][slot (lane)]: slot = 4 kw + c
+    float* o = part + (size_t)blockIdx.x * 147 * Co;
+    const int kw = r32 >> 2, c = r32 & 3;
+    if (kw < 7 && c < 3) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = ct * 32 + acc_row(q, hh);
+                if (co < Co) o[(size_t)(kh * 21 + kw * 3 + c) * Co + co] = acc[ct][q];
+            }
+    }
+}
+template <typename T>
+static int conv7_wgrad_mfma_T(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, hipStream_t s) {
+    const int Wo = (W + 1) / 2, groups = (Wo + 31) / 32, WoP = (Wo + 15) / 16 * 16;
+    const int PW = 2 * groups * 32 + 8;
+    const size_t lds = (size_t)7 * PW * 8 + (size_t)WoP * 128;
+    if (lds > 64 * 1024) return Y2_ERR_ARG;
+    const int rows = N * ((H + 1) / 2);
+    const int blocks = rows < 512 ? rows : 512;
+    float* part = (float*)op_scratch(s, (size_t)blocks * 147 * Cout * sizeof(float));
+    if (!part) return op_scratch_error();
+    hipLaunchKernelGGL(rn_conv7_wgrad_mfma_kernel<T>, dim3(blocks), dim3(kC7Threads), lds, s, x, dy, part, N, H, W, Cout, PW, WoP);
+    hipLaunchKernelGGL(rn_sum_partials_kernel, dim3((147 * Cout + 63) / 64), dim3(256), 0, s, part, dw, blocks, 147 * Cout);
+    RCHK(hipGetLastError());
+    return Y2_OK;
+}
 template <typename T>
 static int conv7_mfma_T(const float* x, const float* w, float* y, int N, int H, int W, int Cout, hipStream_t s) {
     const int Wo = (W + 1) / 2, groups = (Wo + 31) / 32;
@@ -1049,6 +1137,17 @@ int y2_conv7x7s2_t(const float* x, const float* w, float* y, int N, int H, int W
         if (rc != Y2_ERR_ARG) return rc;         // (rows too long for the staged window: the fp32 kernel decides)
     }
     return y2_conv7x7s2(x, w, y, N, H, W, Cout, stream);
+}
+int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* stream);
+int y2_conv7x7s2_backward_filter_t(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, int dtype,
+                                   void* stream) {
+    if (!x || !dy || !dw || N < 1 || H < 1 || W < 1 || Cout < 1) return rfail(Y2_ERR_ARG, "bad arguments");
+    if ((dtype == 1 || dtype == 2) && Cout <= 64 && (Cout % 4) == 0) {
+        const int rc = dtype == 1 ? conv7_wgrad_mfma_T<half_t>(x, dy, dw, N, H, W, Cout, (hipStream_t)stream)
+                                  : conv7_wgrad_mfma_T<bf16_t>(x, dy, dw, N, H, W, Cout, (hipStream_t)stream);
+        if (rc != Y2_ERR_ARG) return rc;
+    }
+    return y2_conv7x7s2_backward_filter(x, dy, dw, N, H, W, Cout, stream);
 }
 int y2_conv7x7s2_backward_filter(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* stream) {
     if (!x || !dy || !dw || N < 1 || H < 1 || W < 1) return rfail(Y2_ERR_ARG, "bad arguments");

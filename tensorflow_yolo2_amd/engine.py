@@ -988,13 +988,13 @@ def conv7x7_s2(x, w, dtype="f32"):
     return y
 
 
-def conv7x7_s2_backward_filter(x, dy):
+def conv7x7_s2_backward_filter(x, dy, dtype="f32"):
     lib = _lib.load()
     _chk(x, dy)
     n, h, wd, _ = x.shape
     co = dy.shape[3]
     dw = torch.empty((7, 7, 3, co), dtype=torch.float32, device=x.device)
-    check(lib.y2_conv7x7s2_backward_filter(_ptr(x), _ptr(dy), _ptr(dw), n, h, wd, co, _stream()))
+    check(lib.y2_conv7x7s2_backward_filter_t(_ptr(x), _ptr(dy), _ptr(dw), n, h, wd, co, _lib.DTYPES[dtype], _stream()))
     return dw
 
 

@@ -541,7 +541,7 @@ class ResNet50Yolo:
             elif rec[0] == "bn":
                 dx, _ = self._bn_backward(rec, dx)
             elif rec[0] == "conv7":
-                dw = E.conv7x7_s2_backward_filter(rec[1].contiguous(), dx.contiguous())
+                dw = E.conv7x7_s2_backward_filter(rec[1].contiguous(), dx.contiguous(), self.dtype)
                 self.g["conv1/weights"].copy_(dw)
 
     def flops_per_step(self):

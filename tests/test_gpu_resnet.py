@@ -182,6 +182,23 @@ def test_root_convolution_on_the_matrix_pipe(dtype, tol):
             assert e < tol, (n, h, w, co, e)
         else:       # not a multiple of 4 filters: the fp32 kernel
             assert e < 1e-5, (n, h, w, co, e)
+        # the filter gradient (y2_conv7x7s2_backward_filter_t): K of its matrix products is the output pixel
+        dy = rng.standard_normal(ref.shape).astype(np.float32)
+        dw = E.conv7x7_s2_backward_filter(dev(x), dev(dy), dtype)
+        wtt = torch.tensor(wt, dtype=torch.float64, requires_grad=True)
+        RR.conv2d_same(torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2), wtt, 2).permute(0, 2, 3, 1).backward(
+            torch.tensor(dy, dtype=torch.float64))
+        eg = rel(dw.cpu().numpy(), wtt.grad.numpy())
+        if co % 4 == 0:
+            wq2 = torch.tensor(wt, dtype=torch.float64, requires_grad=True)
+            RR.conv2d_same(torch.tensor(x).to(td).double().permute(0, 3, 1, 2), wq2, 2).permute(0, 2, 3, 1).backward(
+                torch.tensor(dy).to(td).double())
+            egq = rel(dw.cpu().numpy(), wq2.grad.numpy())
+            print("   its filter gradient: %.2e of the max (rounded operands: %.2e)" % (eg, egq))
+            assert egq < 5e-5 and eg < tol, (n, h, w, co, eg, egq)
+            assert torch.equal(dw, E.conv7x7_s2_backward_filter(dev(x), dev(dy), dtype))
+        else:
+            assert eg < 2e-5, (n, h, w, co, eg)
     y32 = E.conv7x7_s2(dev(x), dev(wt))
     assert rel(y32.cpu().numpy(), ref) < 1e-5
 
