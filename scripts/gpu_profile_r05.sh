@@ -33,7 +33,7 @@ python3 scripts/summarize_profiles.py trace $O/${TAG}_trace_f16x2 $O/${TAG}_time
 python3 scripts/summarize_profiles.py stats $O/${TAG}_trace_c3 $O/${TAG}_stats_c3.csv 23        # 3 warm-up + 20 timed steps
 python3 scripts/summarize_profiles.py stats $O/${TAG}_trace_c2 $O/${TAG}_stats_c2_forward.csv $ALL
 # one APPLIED graph-replayed step (bench settles the loss scale first): the dispatches between the last two root convolutions
-python3 scripts/summarize_profiles.py step $O/${TAG}_trace_rn $O/${TAG}_resnet50_step.csv rn_conv7_fwd_kernel
+python3 scripts/summarize_profiles.py step $O/${TAG}_trace_rn $O/${TAG}_resnet50_step.csv rn_conv7_mfma_kernel
 python3 scripts/profile_layers.py > $O/${TAG}_layers_per_layer_us.txt 2>&1
 DTYPE=f16x2 python3 scripts/profile_layers.py > $O/${TAG}_layers_f16x2.txt 2>&1
 DTYPE=f32 python3 scripts/profile_layers.py > $O/${TAG}_layers_f32.txt 2>&1
