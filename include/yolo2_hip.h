@@ -39,6 +39,15 @@ typedef struct y2_ctx y2_ctx;
  * with respect to activations, statistics, batch norm, loss and optimizer are fp32 as in Y2_F32; the 3-channel image
  * layer runs in exact fp32.  Gradients ride on the f16 loss scale (y2_set_options) with the f16 mode's overflow guard. */
 #define Y2_F16X2 3
+/* Round 6: Y2_F16X2 forward, single-product backward.  Tensors, forward pass, batch norm, loss and optimizer are exactly
+ * Y2_F16X2's (so every forward DECISION -- leaky branch, pool arg-max, responsible box -- is the reference-precision one);
+ * the two backward contractions of tf.gradients (Conv2DBackpropInput / Conv2DBackpropFilter behind
+ * src/pascal/pascal_train_darknet.py:49-51) read the hi planes of dY, W and x only: one f16 MFMA per product with fp32
+ * accumulation.  With the decisions fixed the backward pass is linear in dY, so the f16 operand rounding (2^-11 relative
+ * per element, random) is not amplified: gradients stay within the 1e-3 tolerance of the whole-step gates
+ * (tests/test_gpu_f16x2f.py), at roughly a third of the backward cost of Y2_F16X2.  y2_ctx_create and the op-level
+ * y2_conv2d / y2_conv2d_backward accept it. */
+#define Y2_F16X2F 4
 
 #define Y2_TAIL_NONE 0    /* output = last layer activation [N,Ho,Wo,Cout]       */
 #define Y2_TAIL_AVGPOOL 1 /* + average_pooling2d(k,k) + reshape -> [N,Cout]      */

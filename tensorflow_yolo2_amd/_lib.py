@@ -16,13 +16,17 @@ if os.environ.get("Y2_DEV_LIB") == "1":
 if os.environ.get("Y2_LIB_PATH"):
     LIB_PATH = os.environ["Y2_LIB_PATH"]
 
-Y2_F32, Y2_F16, Y2_BF16, Y2_F16X2 = 0, 1, 2, 3
+Y2_F32, Y2_F16, Y2_BF16, Y2_F16X2, Y2_F16X2F = 0, 1, 2, 3, 4
+# modes whose gradients ride on the f16 loss scale (dY is stored in f16 planes)
+LOSS_SCALED = (Y2_F16, Y2_F16X2, Y2_F16X2F)
 Y2_TAIL_NONE, Y2_TAIL_AVGPOOL = 0, 1
 DTYPES = {"f32": Y2_F32, "fp32": Y2_F32, "float32": Y2_F32,
           "f16": Y2_F16, "fp16": Y2_F16, "float16": Y2_F16,
           "bf16": Y2_BF16, "bfloat16": Y2_BF16,
           # split-operand mode: (hi, lo) f16 pairs, three MFMAs per product, fp32-width storage (include/yolo2_hip.h)
-          "f16x2": Y2_F16X2}
+          "f16x2": Y2_F16X2,
+          # round 6: f16x2 forward, backward contractions on the hi planes only (one f16 MFMA per product)
+          "f16x2f": Y2_F16X2F}
 
 _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 _pi = C.POINTER(C.c_int)

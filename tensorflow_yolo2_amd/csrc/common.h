@@ -75,9 +75,21 @@ template <> struct Elem<hsplit_t> {
     static constexpr int kId = 3;
 };
 constexpr float kSplitWScale = 64.0f, kSplitWScaleInv = 1.0f / 64.0f;
-// operand type of the MFMA kernels / type of what their epilogues store
-template <typename T> struct Types { typedef T op_t; typedef T out_t; static constexpr bool kSplit = false; };
-template <> struct Types<hsplit_t> { typedef half_t op_t; typedef float out_t; static constexpr bool kSplit = true; };
+// Round 6 ("f16x2f", dtype 4 -- backward launches only): the SAME split tensors read through their HI planes alone, one
+// f16 MFMA per product.  With the forward decisions (leaky branches, pool arg-max, responsible boxes) fixed by the
+// split-operand forward pass, the backward pass is linear in dY: rounding dY, W and x to f16 per contraction is a relative
+// perturbation of ~3e-4 per layer that nothing amplifies chaotically.  A cell is still [C halves hi][C halves lo]
+// (4 bytes per element: the executor's byte counts do not change); a launch walks ONE plane pass of the K range.
+struct hsplith_t { uint32_t bits; };
+template <> struct Elem<hsplith_t> {
+    typedef f16x8 frag;
+    static constexpr int kPerFrag = 8;
+    static constexpr int kId = 4;
+};
+// operand type of the MFMA kernels / type of what their epilogues store; kPasses = plane passes of the K loop
+template <typename T> struct Types { typedef T op_t; typedef T out_t; static constexpr bool kSplit = false; static constexpr int kPasses = 1; };
+template <> struct Types<hsplit_t> { typedef half_t op_t; typedef float out_t; static constexpr bool kSplit = true; static constexpr int kPasses = 3; };
+template <> struct Types<hsplith_t> { typedef half_t op_t; typedef float out_t; static constexpr bool kSplit = true; static constexpr int kPasses = 1; };
 // K chunk c of a launch whose K range is [hi plane | lo plane | hi plane again] x [filter hi | filter hi | filter lo]:
 // n = chunks per plane.  Activation chunk: c mod 2n; filter chunk: c < n ? c : c - n (hi, hi, lo).
 template <bool SPLIT> Y2_DEV int split_act_chunk(int c, int n) { return SPLIT ? (c >= 2 * n ? c - 2 * n : c) : c; }

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
     typedef typename Types<T>::out_t YT;
     constexpr bool SPLIT = Types<T>::kSplit;
     static_assert(!(SPLIT && KS), "the K split of small launches is not built for the split-operand mode");
-    static_assert(!PL2 || (SPLIT && !CPT && (BKB == 128 || BKB == 64)), "the two-plane form: split operands, bordered image");
+    static_assert(!PL2 || (SPLIT && Types<T>::kPasses == 3 && !CPT && (BKB == 128 || BKB == 64)), "the two-plane form: split operands, bordered image");
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
     constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB, KG = BKB / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    int c_begin = 0, nchunks = PL2 ? a.C * (int)sizeof(OT) / (BKB / 2) : (SPLIT ? 3 * npl : npl);     // this workgroup's chunk range [c_begin, nchunks)
+    int c_begin = 0, nchunks = PL2 ? a.C * (int)sizeof(OT) / (BKB / 2) : Types<T>::kPasses * npl;     // this workgroup's chunk range [c_begin, nchunks)
     if constexpr (KS) {
         const int per = (nchunks + a.ks_splits - 1) / a.ks_splits;
         c_begin = split * per;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
     constexpr int NW = WP * WC, BP = WP * TP * 32, BC = WC * TC * 32, SZ = sizeof(T);
     constexpr int LPR = BKB / 16, RPI = 64 / LPR, RPB = 256 / BKB, KG = BKB / 64;   // k-groups of 64 bytes
     constexpr int TP16 = 2 * TP, TC16 = 2 * TC;
-    static_assert(!PL2 || (SPLIT && BKB == 128 && !CPT), "the two-plane form: split operands, 128-byte image rows");
+    static_assert(!PL2 || (SPLIT && Types<T>::kPasses == 3 && BKB == 128 && !CPT), "the two-plane form: split operands, 128-byte image rows");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
 #pragma unroll
         for (int j = 0; j < TP16; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = PL2 ? a.C * (int)sizeof(OT) / 64 : (SPLIT ? 3 * npl : npl);
+    const int nchunks = PL2 ? a.C * (int)sizeof(OT) / 64 : Types<T>::kPasses * npl;
     const int steps = nchunks * TAPS;
     u32x4 fbq[2][TC16][KG];
     int aoffq[2][TP16];                        // fragment-row addresses of the current / the next tap step
@@ -781,7 +781,7 @@ static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
     void (*kern)(ConvArgs, int);
     // f16x2 on the 16x16 tiles: both operand planes per K chunk (conv_haloq16_kernel PL2); Y2_NO_CONV_PL2=1: three plane passes
     static const bool no_pl2 = getenv("Y2_NO_CONV_PL2") != nullptr;
-    constexpr bool kPL2 = Types<T>::kSplit && M16 && BKB == 128 && !CPT && TAPS == 9;
+    constexpr bool kPL2 = Types<T>::kPasses == 3 && M16 && BKB == 128 && !CPT && TAPS == 9;
     bool pl2 = false;
     if constexpr (M16) {
         kern = conv_haloq16_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
@@ -790,7 +790,7 @@ static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
         }
     } else {
         kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS>;
-        constexpr bool kPL2q = Types<T>::kSplit && !CPT && TAPS == 9 && (BKB == 128 || BKB == 64);
+        constexpr bool kPL2q = Types<T>::kPasses == 3 && !CPT && TAPS == 9 && (BKB == 128 || BKB == 64);
         if constexpr (kPL2q) {
             if (!no_pl2) { kern = conv_haloq_kernel<T, WP, WC, TP, TC, BKB, ADB, CPT, TAPS, false, true>; pl2 = true; }
         }
@@ -810,7 +810,7 @@ static hipError_t haloq_launch(const ConvArgs& a, hipStream_t s) {
 template <typename T, int WP, int WC, int TP, int TC, int BKB, bool M16 = false>
 static hipError_t haloq_pick(const ConvArgs& a, hipStream_t s) {
     constexpr int BP = WP * TP * 32, RPI = 64 / (BKB / 16);
-    const int nchunks = a.C * (int)sizeof(typename Types<T>::op_t) / BKB * (Types<T>::kSplit ? 3 : 1);
+    const int nchunks = a.C * (int)sizeof(typename Types<T>::op_t) / BKB * Types<T>::kPasses;
     if (halo_compact()) {
         const int arows = haloq_rows_compact(a.W, BP);
         if (nchunks > 1 && haloq_lds<BKB>(arows, true, true) <= 150 * 1024)
@@ -1001,6 +1001,7 @@ hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* b
         case 1: return haloq_T<half_t>(a, s, bp);
         case 2: return haloq_T<bf16_t>(a, s, bp);
         case 3: return haloq_T<hsplit_t>(a, s, bp);
+        case 4: return haloq_T<hsplith_t>(a, s, bp);     // f16x2f backward launches: the hi planes of split tensors
     }
     return hipErrorInvalidValue;
 }

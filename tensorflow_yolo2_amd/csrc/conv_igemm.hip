@@ -73,7 +73,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     constexpr bool SPLIT = Types<T>::kSplit;
     constexpr int NW = Cfg::NW, BP = Cfg::BP, BC = Cfg::BC, SZ = Cfg::SZ;
     constexpr int LPR = Cfg::LPR, RPI = Cfg::RPI, RPB = Cfg::RPB, IPW = Cfg::IPW, KG = Cfg::KG;
-    static_assert(!PL2 || (SPLIT && KG >= 2 && KG % 2 == 0), "the two-plane form: split operands, an even number of k-groups");
+    static_assert(!PL2 || (SPLIT && Types<T>::kPasses == 3 && KG >= 2 && KG % 2 == 0), "the two-plane form: split operands, an even number of k-groups");
     constexpr int KGH = KG / 2;
     // 16-byte chunk `src` of a staged row -> byte offset in the operand's row (PL2: first half hi plane, second half lo plane)
     auto chunk_off = [&](uint32_t src) -> uint32_t {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     }
     // k-chunks per tap; f16x2: three passes over the planes, [x hi | x lo | x hi] against [w hi | w hi | w lo]
     const int npl = (a.C * (int)sizeof(OT)) / BKB;
-    const int cpt = PL2 ? (a.C * (int)sizeof(OT)) / (BKB / 2) : (SPLIT ? 3 * npl : npl);
+    const int cpt = PL2 ? (a.C * (int)sizeof(OT)) / (BKB / 2) : Types<T>::kPasses * npl;
     const int nK = a.taps * cpt;
     const int rowpitch = (a.W + 1) * a.C * SZ;
 
@@ -261,7 +261,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     // f16x2: both operand planes per K chunk (PL2); Y2_NO_CONV_PL2=1: three plane passes
     static const bool no_pl2 = getenv("Y2_NO_CONV_PL2") != nullptr;
     int pl2 = 0;
-    if constexpr (Types<T>::kSplit && ABL == 0 && (BKB == 128 || BKB == 64)) {
+    if constexpr (Types<T>::kPasses == 3 && ABL == 0 && (BKB == 128 || BKB == 64)) {
         if (!no_pl2) { kern = conv_igemm_kernel<T, WP, WC, TP, TC, BKB, NS, ABL, true>; pl2 = 1; }
     }
     static bool attr_set[2] = {false, false};
@@ -302,6 +302,7 @@ hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
         case 1: return launch_T<half_t>(a, s);
         case 2: return launch_T<bf16_t>(a, s);
         case 3: return launch_T<hsplit_t>(a, s);
+        case 4: return launch_T<hsplith_t>(a, s);        // f16x2f backward launches: the hi planes of split tensors
     }
     return hipErrorInvalidValue;
 }

@@ -9,11 +9,13 @@
 
 namespace y2 {
 
-inline size_t dtype_size(int dtype) { return (dtype == 0 || dtype == 3) ? 4 : 2; }   // bytes per stored element
+//   4 = f16x2f (round 6): LAUNCH dtype of the backward contractions of a split-mode context created with Y2_F16X2F -- the
+//       same split tensors, hi planes only, one f16 MFMA per product (common.h hsplith_t).  A context's own dtype is 3.
+inline size_t dtype_size(int dtype) { return (dtype == 0 || dtype >= 3) ? 4 : 2; }   // bytes per stored element
 inline int dtype_kbytes(int dtype) { return dtype == 0 ? 4 : 2; }                  // bytes per element of ONE K plane (MFMA operand)
-inline bool dtype_split(int dtype) { return dtype == 3; }
+inline bool dtype_split(int dtype) { return dtype >= 3; }
 // dtype of the kernels whose arithmetic is elementwise fp32 in the split mode (first layer, casts): f32
-inline int dtype_plain(int dtype) { return dtype == 3 ? 0 : dtype; }
+inline int dtype_plain(int dtype) { return dtype >= 3 ? 0 : dtype; }
 
 struct ConvArgs {
     const void* x;      // zero-bordered NHWC [N][H+2][W+2][C]
@@ -290,7 +292,8 @@ inline int wgrad_split_args(int dtype, WgradArgs& a) {
     if (!a.xpitch) a.xpitch = a.Cin;
     if (!a.ypitch) a.ypitch = a.Cdy;
     if (!dtype_split(dtype)) return dtype;
-    a.xpitch = 2 * a.Cin; a.ypitch = 2 * a.Cdy; a.quads = 3;
+    a.xpitch = 2 * a.Cin; a.ypitch = 2 * a.Cdy;
+    a.quads = dtype == 4 ? 1 : 3;      // f16x2f: the hi-plane pair alone -- the f16 kernels on cells of twice the pitch
     return 1;
 }
 // one launch per operand-plane pair (WgradArgs::quads): hi hi, x lo, dy lo -- each with its own slab range

@@ -82,6 +82,9 @@ struct Layer {
 
 struct y2_ctx {
     int N, H, W, dtype, tail, tail_k, core_layers;
+    // Y2_F16X2F (round 6): dtype == 3 (split tensors, split-operand forward) and the backward contractions -- dgrad and
+    // weight gradients -- read the hi planes only (launch dtype 4, common.h hsplith_t): one f16 MFMA per product
+    int bwd_dtype = 0;
     std::vector<Layer> L;
     size_t nparams = 0, nstate = 0;
     int outN, outH, outW, outC;
@@ -322,10 +325,12 @@ int y2_darknet19_spec(int kind, int output_filter, int* spec, int max_layers) {
 int y2_ctx_create(y2_ctx** out, const int* spec, int num_layers, int core_layers, int tail, int tail_k, int batch,
                   int height, int width, int dtype) {
     if (!out || !spec || num_layers <= 0) return fail(Y2_ERR_ARG, "bad arguments");
-    if (dtype < 0 || dtype > 3) return fail(Y2_ERR_ARG, "dtype must be 0 (f32), 1 (f16), 2 (bf16) or 3 (f16x2)");
+    if (dtype < 0 || dtype > 4) return fail(Y2_ERR_ARG, "dtype must be 0 (f32), 1 (f16), 2 (bf16), 3 (f16x2) or 4 (f16x2f)");
     if (batch <= 0 || height <= 0 || width <= 0) return fail(Y2_ERR_ARG, "bad input shape");
     y2_ctx* c = new y2_ctx();
-    c->N = batch; c->H = height; c->W = width; c->dtype = dtype;
+    c->N = batch; c->H = height; c->W = width;
+    c->bwd_dtype = dtype;                       // what the dgrad / weight-gradient launches run in
+    c->dtype = dtype = (dtype == 4 ? 3 : dtype);   // tensors, forward pass, batch norm, optimizer: the split-operand mode's
     c->tail = tail; c->tail_k = tail_k; c->core_layers = core_layers;
     int h = height, w = width, cprev = 3;
     size_t po = 0, so = 0;
@@ -1076,7 +1081,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 ws_ = c->side;
                 forked = true;
             }
-            { ProfScope _p(c, ws_, CAT_WGRAD); HIPCHK(launch_wgrad_auto(c->dtype, g, ws_)); }
+            { ProfScope _p(c, ws_, CAT_WGRAD); HIPCHK(launch_wgrad_auto(c->bwd_dtype, g, ws_)); }
             if (l > 0 || c->dinput || c->ext_dx) {
                 ConvArgs a{};
                 a.x = dyp; a.w = c->ws + y.wd; a.y = (l == 0 && c->ext_dx) ? (char*)c->ext_dx : dA[c->dA_cur ^ 1];
@@ -1102,7 +1107,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                     a.bw_slope = z.slope;
                 }
                 int rec = 0;
-                { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->dtype, a, s, &bp, &rec)); }
+                { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->bwd_dtype, a, s, &bp, &rec)); }
                 if (fuse) fused_P = rec;
                 c->dA_cur ^= 1;
                 if (l == 0 && c->dinput)   // the stack's input gradient leaves in fp32 NHWC, loss scale divided out
@@ -1473,7 +1478,8 @@ int y2_conv2d(const float* x, const float* w, const float* bias, float* y, int N
               int k, int dtype, void* workspace, void* stream) {
     if (!x || !w || !y || !workspace) return fail(Y2_ERR_ARG, "null tensor");
     if (k != 1 && k != 3) return fail(Y2_ERR_ARG, "filter size must be 1 or 3");
-    if (dtype < 0 || dtype > 3) return fail(Y2_ERR_ARG, "bad dtype");
+    if (dtype < 0 || dtype > 4) return fail(Y2_ERR_ARG, "bad dtype");
+    if (dtype == 4) dtype = 3;      // f16x2f: the forward pass is the split-operand mode's
     hipStream_t s = (hipStream_t)stream;
     const size_t sz = dtype_size(dtype);
     OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
@@ -1495,7 +1501,9 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
                        int Cin, int Cout, int k, int dtype, void* workspace, void* stream) {
     if (!x || !w || !dy || !workspace) return fail(Y2_ERR_ARG, "null tensor");
     if (k != 1 && k != 3) return fail(Y2_ERR_ARG, "filter size must be 1 or 3");
-    if (dtype < 0 || dtype > 3) return fail(Y2_ERR_ARG, "bad dtype");
+    if (dtype < 0 || dtype > 4) return fail(Y2_ERR_ARG, "bad dtype");
+    const int ldt = dtype;          // launch dtype of the two contractions (4: hi planes of the split tensors)
+    if (dtype == 4) dtype = 3;      // tensors and packs: the split-operand mode's
     hipStream_t s = (hipStream_t)stream;
     const size_t sz = dtype_size(dtype);
     OpPlan p = op_plan(N, H, W, Cin, Cout, k, dtype);
@@ -1513,7 +1521,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
         a.N = N; a.H = H; a.W = W; a.C = p.Cdy; a.M = N * H * W; a.Cout = p.Cin_p; a.ldy = p.Cin_p; a.taps = k * k;
         a.is_dgrad = 1;
         if (p.ks_floats) { a.ks_scratch = (float*)(ws + p.ks); a.ks_floats = p.ks_floats; }
-        HIPCHK(launch_conv(dtype, a, s));
+        HIPCHK(launch_conv(ldt, a, s));
         HIPCHK(launch_cast_to_f32(dtype, ws + p.dx, dx, (size_t)N * H * W, Cin, p.Cin_p, s));
     }
     if (dw) {
@@ -1524,7 +1532,7 @@ int y2_conv2d_backward(const float* x, const float* w, const float* dy, float* d
         g.taps = k * k; g.splitk = 0; g.scale = 1.f;
         g.slab = (float*)(ws + p.slab); g.slab_floats = op_slab_floats(dtype);
         g.tile_cnt = op_counters(s, kWgCntInts); g.cnt_ints = g.tile_cnt ? kWgCntInts : 0;
-        HIPCHK(launch_wgrad_auto(dtype, g, s));
+        HIPCHK(launch_wgrad_auto(ldt, g, s));
         for (int t = 0; t < k * k && !direct; ++t)
             HIPCHK(hipMemcpyAsync(dw + (size_t)t * Cin * Cout, (float*)(ws + p.dw) + (size_t)t * p.Cin_p * Cout,
                                   (size_t)Cin * Cout * sizeof(float), hipMemcpyDeviceToDevice, s));

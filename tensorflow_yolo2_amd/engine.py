@@ -137,7 +137,7 @@ class Network:
         self.scale_owner = share_with.scale_owner if share_with is not None else self
         if grad_scale is None:
             # f16 and the split-operand mode (f16 planes): gradients ride on a loss scale, dY's exponent range is f16's
-            grad_scale = 1024.0 if self.dtype in (_lib.Y2_F16, _lib.Y2_F16X2) else 1.0
+            grad_scale = 1024.0 if self.dtype in _lib.LOSS_SCALED else 1.0
         self.grad_scale = float(grad_scale)
         self.bn_eps, self.bn_momentum, self.zero_bias_grad = 1e-3, 0.99, False     # y2_ctx defaults (darknet.py:39-44)
         self._bessel = bool(bessel)
@@ -452,7 +452,7 @@ class LossScaler:
         self._host = torch.zeros(8, dtype=torch.int32).pin_memory()
         self._event = None
         self.growth_interval, self.max_scale, self.min_scale = growth_interval, max_scale, min_scale
-        self.enabled = net.dtype in (_lib.Y2_F16, _lib.Y2_F16X2)
+        self.enabled = net.dtype in _lib.LOSS_SCALED
         self._clean = 0
         self.overflows = 0
 
@@ -518,7 +518,7 @@ class AdamOptimizer:
         self.m = torch.zeros_like(net.params)
         self.v = torch.zeros_like(net.params)
         self.t = 0
-        self.guard = (net.dtype in (_lib.Y2_F16, _lib.Y2_F16X2)) if guard is None else bool(guard)
+        self.guard = (net.dtype in _lib.LOSS_SCALED) if guard is None else bool(guard)
         self.scaler = LossScaler(net) if self.guard else None
 
     def step(self, grad_mult=1.0, full_check=False, joint=None):
@@ -592,7 +592,7 @@ class MomentumOptimizer:
         self.net, self.lr, self.mom = net, learning_rate, momentum
         self.fused_pack = bool(fused_pack)
         self.accum = torch.zeros_like(net.params)
-        self.guard = (net.dtype in (_lib.Y2_F16, _lib.Y2_F16X2)) if guard is None else bool(guard)
+        self.guard = (net.dtype in _lib.LOSS_SCALED) if guard is None else bool(guard)
         self.scaler = LossScaler(net) if self.guard else None
 
     def step(self, grad_mult=1.0, full_check=False):
