@@ -111,10 +111,16 @@ class pascal_voc(object):
     get() returns the reference's (images [B,size,size,3] float32 in [-1,1], labels [B,S,S,25]); get_u8() returns
     the same batch with the images still uint8 BGR (resized, before / 255 * 2 - 1) for y2_forward_u8, which
     applies that conversion on the device.  Decoded + resized images are kept in host memory after their first
-    use (cache_images; 520 KB per 416x416 image) -- the reference re-decodes every time."""
+    use (cache_images; 520 KB per 416x416 image) -- the reference re-decodes every time.
+
+    Data parallelism (round 6; not in the reference): `rank` / `world` shard every epoch by stride.
+    All ranks hold the SAME shuffled list (same seed, same number of shuffles: the generator streams stay in lockstep);
+    rank r reads positions r, r + world, r + 2 world, ... of it, len // world positions per epoch on every rank (the
+    < world entries at the tail of an epoch's order are skipped that epoch -- another order the next one), then all
+    reshuffle together.  world = 1 is the reference's cursor, entry for entry."""
 
     def __init__(self, image_set, batch_size=None, rebuild=False, devkit_path=None, image_size=None, cell_size=None,
-                 flipped=None, seed=0, cache_images=True):
+                 flipped=None, seed=0, cache_images=True, rank=0, world=1):
         import os
         from .. import config as cfg
         self.name = 'voc_2007'
@@ -129,11 +135,15 @@ class pascal_voc(object):
         self.flipped = bool(getattr(cfg, "FLIPPED", False)) if flipped is None else bool(flipped)
         self.image_set = image_set
         self.cursor = 0
+        assert world >= 1 and 0 <= rank < world, (rank, world)
+        self.rank, self.world = int(rank), int(world)
         self.rng = np.random.default_rng(seed)
         self.cache_images = cache_images
         self._cache = {}
         assert os.path.exists(self.data_path), 'Path does not exist: {}'.format(self.data_path)
         self.gt_labels = self.prepare()
+        self.per_rank = len(self.gt_labels) // self.world      # positions of one epoch on every rank
+        assert self.per_rank >= 1, "fewer images (%d) than ranks (%d)" % (len(self.gt_labels), self.world)
 
     # ---- pascal_voc.py:69-124
     def load_labels(self):
@@ -179,9 +189,9 @@ class pascal_voc(object):
 
     # ---- pascal_voc.py:42-58
     def _next(self):
-        g = self.gt_labels[self.cursor]
+        g = self.gt_labels[self.cursor * self.world + self.rank]
         self.cursor += 1
-        if self.cursor >= len(self.gt_labels):
+        if self.cursor >= self.per_rank:
             self.rng.shuffle(self.gt_labels)
             self.cursor = 0
         return g

@@ -32,9 +32,10 @@ _NETWORKS = {}    # (scope chain, shape, dtype, training, tail) -> Network
 
 
 def set_default_dtype(dtype):
-    """'f32' (exact-f32 MFMA parity mode), 'f16' (default) or 'bf16'."""
+    """'f32' (exact-f32 MFMA parity mode), 'f16' (default), 'bf16', 'f16x2' (reference tolerance on the f16 matrix pipe,
+    split operands) or 'f16x2f' (f16x2 forward, single-product backward contractions)."""
     global _DEFAULT_DTYPE
-    assert dtype in ("f32", "f16", "bf16")
+    assert dtype in ("f32", "f16", "bf16", "f16x2", "f16x2f")
     _DEFAULT_DTYPE = dtype
 
 

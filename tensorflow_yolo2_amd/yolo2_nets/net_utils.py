@@ -55,6 +55,15 @@ class _Optimizer:
     def __init__(self, *args):
         self.args = args
         self._opt = {}
+        self._reducers = {}
+
+    def _reducer(self, net):
+        """data parallelism (trainer.GradReducer): the sliced, overlapped SUM all-reduce of `net`'s gradient buffer"""
+        from ..trainer import GradReducer
+        r = self._reducers.get(id(net))
+        if r is None:
+            r = self._reducers[id(net)] = GradReducer(net)
+        return r
 
     def slots(self, net):
         """the engine optimizer (slot tensors) that train ops of this object apply to `net`'s variables"""
@@ -82,8 +91,16 @@ class _Optimizer:
                 raise RuntimeError("loss was not produced by a training-mode NetTensor")
             net = src.network
             net.update_moving_stats()          # tf.control_dependencies(update_ops)
-            net.backward(loss.dnet.contiguous())
-            self._slots(net).step()
+            from ..trainer import _dist
+            if _dist() is None:
+                net.backward(loss.dnet.contiguous())
+                self._slots(net).step()
+            else:
+                # one process per GPU under torch.distributed (pascal_train_darknet.py under torchrun): the replicas'
+                # gradients are summed slice by slice behind the backward pass and the update divides by the world
+                # size -- slim's clone semantics (src/slim_dir/deployment/model_deploy.py:222-225,436-446)
+                world = self._reducer(net).backward_and_reduce(loss.dnet.contiguous())
+                self._slots(net).step(grad_mult=1.0 / world)
             store = getattr(net, "store", None)
             if store is not None:
                 store.version += 1
