@@ -344,25 +344,31 @@ def c5_resnet50_leg(args, device):
     from tensorflow_yolo2_amd import synthetic
     from tensorflow_yolo2_amd.yolo2_nets.tf_resnet import ResNet50Yolo
     bs, size = 32, 224
-    m = ResNet50Yolo(bs, size, dtype=args.dtype, device=device, seed=0, graph=True)
+    # (the ResNet swap has no split-operand form: under --dtype f16x2 / f16x2f this leg runs its f16 arithmetic)
+    rdtype = "f16" if args.dtype in ("f16x2", "f16x2f") else args.dtype
+    m = ResNet50Yolo(bs, size, dtype=rdtype, device=device, seed=0, graph=True)
     x = torch.as_tensor(synthetic.images(bs, size, 1234)).to(device)
     lab = torch.as_tensor(synthetic.det_labels(bs, size, size // 32, 4321)).to(device)
     for _ in range(4):                      # two eager steps, the capture, one replay
         m.step(x, lab)
     torch.cuda.synchronize()
-    settled = _resnet_settle(m, x, lab)     # the loss scale has adapted: the timed steps are APPLIED steps
+    # the loss scale has adapted: the timed steps are APPLIED steps.  (An unguarded f32 model has no control block to
+    # follow -- the host counts its steps -- so there is nothing to settle and every step is applied: ADVICE r5)
+    settled = _resnet_settle(m, x, lab) if m.guard else True
     n = 10
     ms, applied, skipped = _resnet_timed(m, x, lab, n)
+    if not m.guard:
+        applied, skipped = n, 0
     if skipped:                             # an overflow inside the timed region: settle again, time again
         settled = _resnet_settle(m, x, lab)
         ms, applied, skipped = _resnet_timed(m, x, lab, n)
     flops = m.flops_per_step()
-    return {"workload": "configs[4]: ResNet-50 backbone swap train step 224x224 batch 32 (HIP-graph replay)", "dtype": args.dtype,
+    return {"workload": "configs[4]: ResNet-50 backbone swap train step 224x224 batch 32 (HIP-graph replay)", "dtype": rdtype,
             "batch": bs, "image_size": size, "steps": n, "warmup": 4, "ms_per_step": ms, "images_per_s": bs / (ms * 1e-3),
             "steps_applied": applied, "steps_skipped_by_overflow_guard": skipped, "loss_scale": m.loss_scale,
             "loss_scale_settled": bool(settled),
             "whole_step_tflops": flops / (ms * 1e-3) / 1e12,
-            "whole_step_frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], "fused_stacks": bool(m.fused)}
+            "whole_step_frac": flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[rdtype], "fused_stacks": bool(m.fused)}
 
 
 def fed_input(args, tr, device, resident_ms):
@@ -496,28 +502,55 @@ def bench_resnet(args, device, rank, world, dist):
         m.step(x, lab)
     torch.cuda.synchronize()
     settled = _resnet_settle(m, x, lab) if m.guard else True
-    ms, applied, skipped = _resnet_timed(m, x, lab, args.steps)
-    if skipped:
+
+    def timed():
+        # replicas: barrier + synchronize on both sides, the slowest rank's clock (the contract of the headline line)
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+        ms_, applied_, skipped_ = _resnet_timed(m, x, lab, args.steps)
+        if dist is not None:
+            t = torch.tensor([ms_], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ms_ = float(t.item())
+        return ms_, applied_, skipped_
+
+    ms, applied, skipped = timed()
+    if not m.guard:
+        applied, skipped = args.steps, 0
+    if skipped:                 # (the control block is identical on every replica: all of them take this branch or none)
         settled = _resnet_settle(m, x, lab)
-        ms, applied, skipped = _resnet_timed(m, x, lab, args.steps)
-    flops = m.flops_per_step()
-    peak = MFMA_PEAK_TFLOPS[dtype]
-    out = {"metric": "images/sec fwd+bwd ResNet-50 (slim resnet_v1_50 + YOLO FC head) 224x224", "value": bs / (ms * 1e-3),
-           "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        ms, applied, skipped = timed()
+    flops = m.flops_per_step() * world
+    peak = MFMA_PEAK_TFLOPS[dtype] * world
+    out = {"metric": "images/sec fwd+bwd ResNet-50 (slim resnet_v1_50 + YOLO FC head) 224x224", "value": world * bs / (ms * 1e-3),
+           "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
            "config": {"workload": "ResNet-50 backbone swap train step: resnet_v1_50 (16 bottleneck units) + FC 4096 + dropout "
                                   "+ FC 1470 + get_loss + backward + Adam(0.0005)", "image_size": size, "batch_per_gpu": bs,
-                      "global_batch": bs, "S": 7, "B": 2, "parallelism": "dp1",
-                      "launch": "one HIP graph replay per step" if args.graph else "per-operator launches from Python",
-                      "note": "operator-level composition (fp32 tensors between operators, per-operator launches); "
-                              "replicas only for N > 1"},
+                      "global_batch": bs * world, "S": 7, "B": 2, "parallelism": "dp%d" % world,
+                      "launch": "one HIP graph replay per step" if (args.graph and world == 1) else "per-operator launches from Python",
+                      "grad_exchange": None if world == 1 else
+                      {"flat_buffer": "SUM all-reduce of every gradient in front of yolo_fc1/weights (%.1f MB), strategy %s"
+                                      % (m.offset["yolo_fc1/weights"][0] * 4 / 1e6 if m._fc1_fused_now() else m.params.numel() * 4 / 1e6,
+                                         m.dp_strategy),
+                       "yolo_fc1": ("all-gather of its operands x [%d, %d] and dz [%d, %d] per rank; every rank runs the fused "
+                                    "product + guarded Adam over the %d gathered rows -- the %.2f GB gradient is never formed"
+                                    % (bs, m.p["yolo_fc1/weights"].shape[0], bs, m.p["yolo_fc1/weights"].shape[1], bs * world,
+                                       m.p["yolo_fc1/weights"].numel() * 4 / 1e9)) if m._fc1_fused_now() else
+                                   "stored gradient inside the flat all-reduce (gathered batch beyond the fused kernel's 256 rows, or f32)"},
+                      "note": "the stride-1 / stride-2 bottleneck units on the native stack executor; batch-norm statistics per replica"},
            "steps_applied": applied, "steps_skipped_by_overflow_guard": skipped, "loss_scale": m.loss_scale,
            "loss_scale_settled": bool(settled),
            "whole_step_tflops": flops / (ms * 1e-3) / 1e12,
            "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                         "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None,
                         "kernel": "whole step (convolution + FC FLOPs as defined / wall time): launch-bound at batch %d" % bs}}
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return out
 
 
@@ -593,7 +626,8 @@ def main():
     if args.model == "yolov2":
         return bench_yolov2(args, images, labels, device, rank, world, dist)
     if args.model == "resnet50":
-        assert world == 1, "the ResNet swap is a single-GPU functional path (replicas only)"
+        if args.dtype in ("f16x2", "f16x2f"):
+            sys.exit("--model resnet50: --dtype f32 | f16 | bf16 (the split-operand modes exist for the Darknet-19 stacks only)")
         return bench_resnet(args, device, rank, world, dist)
     if args.model == "classifier":      # configs[2] on its own (what profiles/r04_*_c3* trace)
         assert world == 1

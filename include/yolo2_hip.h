@@ -337,6 +337,11 @@ int y2_grad_check(y2_ctx* ctx, void* ctrl, void* stream);
  * the control block the first stack's y2_grad_check cleared -- the step is then all-or-nothing over the whole graph */
 int y2_grad_check_more(y2_ctx* ctx, void* ctrl, void* stream);
 int y2_grad_check_full(const float* grads, size_t n, void* ctrl, void* stream);
+/* Round 6.  ctrl.found_inf |= any x[i] that is non-finite or beyond +-limit; the flag is NOT cleared first (call it between
+ * y2_grad_check_full and the guarded update).  For operands that a fused update rounds to a narrower type without ever
+ * storing the gradient: y2_fc_adam_apply_guarded rounds dz to f16 / bf16 inside the kernel, so a |dz| above 65504 is finite in
+ * every stored fp32 gradient it feeds and inf in the weight's (src/pascal/pascal_train_resnet.py:41-50, yolo_fc1). */
+int y2_range_check(const float* x, size_t n, float limit, void* ctrl, void* stream);
 int y2_adam_step_guarded(float* params, float* m, float* v, const float* grads, size_t n, void* ctrl, float lr,
                          float beta1, float beta2, float eps, float grad_mult, void* stream);
 int y2_momentum_step_guarded(float* params, float* accum, const float* grads, size_t n, void* ctrl, float lr,

@@ -78,6 +78,7 @@ SIGNATURES = {
     "y2_accumulate": (_i, [_vp, _vp, _sz, _vp]),
     "y2_add_relu": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "y2_add_relu_backward": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "y2_range_check": (_i, [_vp, _sz, _f, _vp, _vp]),
     "y2_fc_adam_apply_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _f, _f, _f, _f, _vp]),
     "y2_bordered_bytes": (_sz, [_i, _i, _i, _i, _i, _psz]),
     "y2_link": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),

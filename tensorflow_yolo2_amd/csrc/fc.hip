@@ -451,7 +451,10 @@ int y2_fc_adam_apply_guarded(const float* x, const float* dz, float* w, float* m
                              int out_features, int dtype, const void* ctrl, float beta1, float beta2, float eps,
                              float grad_mult, void* stream) {
     if (!x || !dz || !w || !m || !v || !ctrl) return fc_fail(Y2_ERR_ARG, "fully connected: null tensor");
-    if (rows < 1 || rows > 128) return fc_fail(Y2_ERR_ARG, "fully connected: 1..128 rows (the batch) per call");
+    // rows: the batch -- or, data parallel (round 6), the batches of every replica gathered (tf_resnet.py): the kernel keeps up
+    // to 16 row fragments of x in registers, 16 rows each in the 16-bit types, 8 in fp32
+    const int max_rows = dtype == 0 ? 128 : 256;
+    if (rows < 1 || rows > max_rows) return fc_fail(Y2_ERR_ARG, "fully connected: 1..256 rows per call (128 in fp32)");
     if (in_features < 1 || out_features < 1) return fc_fail(Y2_ERR_ARG, "fully connected: bad shape");
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {

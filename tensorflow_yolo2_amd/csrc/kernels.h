@@ -488,6 +488,7 @@ hipError_t launch_momentum(float* p, float* acc, const float* g, size_t n, float
 hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, hipStream_t s);
 hipError_t launch_grad_check_ranges(const float* g, const void* ranges_dev, int nranges, void* ctrl, hipStream_t s,
                                     unsigned* flag = nullptr, bool keep = false);   // keep: do not clear found_inf first
+hipError_t launch_range_check(const float* x, size_t n, float limit, void* ctrl, hipStream_t s);   // found_inf |= !(|x| <= limit)
 hipError_t launch_opt_ctrl_advance(void* ctrl, float lr, float b1, float b2, hipStream_t s);
 hipError_t launch_adam_guarded(float* p, float* m, float* v, const float* g, size_t n, const void* ctrl, float b1,
                                float b2, float eps, float gscale, hipStream_t s);

@@ -1322,6 +1322,11 @@ int y2_grad_check_full(const float* grads, size_t n, void* ctrl, void* stream) {
     HIPCHK(launch_grad_check(grads, n, ctrl, (hipStream_t)stream));
     return Y2_OK;
 }
+int y2_range_check(const float* x, size_t n, float limit, void* ctrl, void* stream) {
+    if (!x || !ctrl || !(limit > 0.f)) return fail(Y2_ERR_ARG, "bad arguments");
+    if (n) HIPCHK(launch_range_check(x, n, limit, ctrl, (hipStream_t)stream));
+    return Y2_OK;
+}
 int y2_adam_step_guarded(float* params, float* m, float* v, const float* grads, size_t n, void* ctrl, float lr,
                          float beta1, float beta2, float eps, float grad_mult, void* stream) {
     if (!params || !m || !v || !grads || !ctrl) return fail(Y2_ERR_ARG, "bad arguments");

@@ -96,6 +96,24 @@ hipError_t launch_grad_check(const float* g, size_t n, void* ctrl, hipStream_t s
     return hipGetLastError();
 }
 
+// Range scan (y2_range_check; round 6): found_inf |= any element that is non-finite or beyond +-limit.  The fused FC update
+// (fc.hip fc_dw_adam_kernel) rounds dz and x to the arithmetic type inside the kernel and never stores dW: a |dz| above the
+// type's largest finite value is finite in fp32 -- so every stored gradient it feeds stays finite -- but inf in the product.
+// Does NOT clear the flag: it runs between the scan of the stored gradients and the guarded update.
+__global__ __launch_bounds__(256) void range_check_kernel(const float* x, size_t n, float limit, OptCtrl* ctrl) {
+    unsigned bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        bad |= !(fabsf(x[i]) <= limit);          // NaN compares false: flagged
+    if (__any(bad != 0) && (threadIdx.x & 63) == 0) atomicOr(&ctrl->found_inf, 1);
+}
+hipError_t launch_range_check(const float* x, size_t n, float limit, void* ctrl, hipStream_t s) {
+    size_t nb = (n + 2047) / 2048;
+    if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(range_check_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, n, limit, (OptCtrl*)ctrl);
+    return hipGetLastError();
+}
+
 // Sentinel scan (y2_grad_check): a non-finite value anywhere in the backward pass reaches the checked ranges.
 //   * an inf / NaN in dA of layer l makes S1 = sum(dz) of its channel non-finite -> dbeta_l (checked), and through
 //     ka = f(S1) every dy of that channel -> dW_l, and through the dgrad every layer below;

@@ -75,6 +75,11 @@ class ResNet50Yolo:
         the optimizer, and the update is the overflow-guarded Adam (an inf / NaN anywhere skips the step on the
         device and halves the scale) -- the policy of the Darknet path (engine.LossScaler)."""
         assert image_size % 32 == 0
+        if dtype not in ("f32", "f16", "bf16"):
+            # (ADVICE r5: the FC head and the root convolution have no split-operand form; "f16x2" used to die at the head
+            #  with 'bad dtype')
+            raise ValueError("ResNet50Yolo: dtype must be 'f32', 'f16' or 'bf16' (got %r); the split-operand modes "
+                             "'f16x2' / 'f16x2f' exist for the Darknet-19 stacks only" % (dtype,))
         self.batch, self.size, self.S, self.B, self.num_class = batch, image_size, image_size // 32, B, num_class
         self.dtype, self.device, self.keep_prob = dtype, torch.device(device), keep_prob
         self.blocks = blocks or BLOCKS_50
@@ -135,7 +140,11 @@ class ResNet50Yolo:
         self.v = torch.zeros_like(self.params)
         self.t = 0
         self.lr = learning_rate
-        self.drop_seed = seed * 7919 + 1
+        # data parallelism (round 6): replicas share `seed` (identical parameters) and draw different dropout masks
+        from ..trainer import _dist
+        d = _dist()
+        self.drop_seed = seed * 7919 + 1 + (d.get_rank() * 104729 if d is not None else 0)
+        self.dp_strategy = os.environ.get("Y2_DP_STRATEGY", "allreduce")
         self.init_params(seed)
         self.tape = None
         self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if dtype == "f16" else 1.0)
@@ -329,7 +338,12 @@ class ResNet50Yolo:
         return {k: v.detach().cpu().numpy().copy() for k, v in self.p.items()}
 
     def export_grads(self):
-        return {k: v.detach().cpu().numpy().copy() for k, v in self.g.items()}
+        """gradients of the last backward pass.  After a train step of a fuse_fc1 model (backward(skip_fc1_dw=True)) the
+        gradient of yolo_fc1/weights was never formed -- the fused update consumed x and dz -- so that key is LEFT OUT rather
+        than returned stale; its slot in `grads` stays allocated because backward() without the skip (tests, the
+        f32 mode, gathered batches beyond the fused kernel's 256 rows) stores it there."""
+        skip = {"yolo_fc1/weights"} if getattr(self, "_fc1_dw_skipped", False) else set()
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.g.items() if k not in skip}
 
     # ---- building blocks ---------------------------------------------------
     def _conv(self, x, name, stride=1):
@@ -470,6 +484,7 @@ class ResNet50Yolo:
                                            dw_out=self.g["yolo_fc2/weights"])
         dfc1 = E.dropout(dh, self.keep_prob, seed) if use_drop else dh                      # same mask, same 1/keep scale
         dz1, _ = E.bias_relu_backward(dfc1, fc1, True, dbias_out=self.g["yolo_fc1/biases"])
+        self._fc1_dw_skipped = bool(skip_fc1_dw)
         if skip_fc1_dw:
             dflat, _ = E.fully_connected_backward(flat, self.p["yolo_fc1/weights"], dz1, self.dtype, want_dw=False)
             self._fc1_operands = (flat, dz1)
@@ -578,25 +593,62 @@ class ResNet50Yolo:
         self.tape = None
         return loss, ious, mask
 
+    # ---- data parallelism (round 6; SURVEY section 8e, slim's clone semantics: model_deploy.py:222-225,436-446) ----------
+    # One process per GPU, identically seeded replicas, batch-norm statistics per replica.  Everything in FRONT of
+    # yolo_fc1/weights in the flat gradient buffer (25.6 M floats at full width) is SUM all-reduced as one range and divided
+    # by the world size inside the optimizer kernel.  yolo_fc1/weights itself (1.64 GB) is designed for xGMI's point-to-point
+    # links instead: its gradient is never materialised -- the replicas ALL-GATHER the two operands of dW = x^T dz, the layer's
+    # input x [batch, 100352] (12.8 MB per rank at batch 32) and dz [batch, 4096] (0.5 MB), and every rank runs the fused
+    # product + guarded Adam update (y2_fc_adam_apply_guarded) over the batch * world gathered rows with grad_mult / world:
+    # 107 MB on the wire at 8 GPUs instead of a 1.64 GB all-reduce, the replicas stay bit-identical (same rows, same order,
+    # same kernel) and the update keeps its fused form.  The overflow guard sees the reduced gradients (an inf on one rank
+    # reaches every rank through the sum) and the gathered dz (identical on every rank): all replicas skip or none.
+    def _dp(self):
+        from ..trainer import _dist
+        d = _dist()
+        return (d, d.get_world_size()) if d is not None else (None, 1)
+
+    def _fc1_fused_now(self):
+        """the fused yolo_fc1 update applies when the gathered batch fits the kernel's row fragments (256 rows in the 16-bit
+        types); beyond that the gradient is stored and all-reduced with the rest"""
+        _d, world = self._dp()
+        return self.fuse_fc1 and self.batch * world <= 256
+
     def _guarded_update(self, lib, dnet):
         """overflow scan + guarded Adam of one step (dnet: run the backward pass first).  fuse_fc1: everything in front of
-        yolo_fc1/weights is scanned and updated from the stored gradients (its bias gradient, the column sum of dz, stands
-        guard for the weight's own), then the weight is updated from the layer's input and dz without its gradient ever
-        being stored"""
-        fused = self.fuse_fc1
+        yolo_fc1/weights is scanned and updated from the stored gradients, then the weight is updated from the layer's input
+        and dz without its gradient ever being stored; dz is range-checked against the arithmetic type's largest finite
+        value first (the kernel rounds it to that type: ADVICE r5 -- a |dz| above 65504 is finite in the fp32 bias gradient
+        that used to stand guard alone)"""
+        fused = self._fc1_fused_now()
         if dnet is not None:
             self.backward(dnet, skip_fc1_dw=fused)
+        dist, world = self._dp()
         n = self.offset["yolo_fc1/weights"][0] if fused else self.params.numel()
+        if dist is not None:
+            from ..trainer import reduce_flat
+            reduce_flat(self.grads, [(0, n)], dist, self.dp_strategy)
+        gmult = 1.0 / (self.loss_scale * world)
         E.check(lib.y2_grad_check_full(E._ptr(self.grads), n, E._ptr(self.ctrl), E._stream()))
-        E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
-                                         E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
         if fused:
             flat, dz1 = self._fc1_operands
+            if dist is not None:
+                flat_all = torch.empty((world * flat.shape[0], flat.shape[1]), dtype=flat.dtype, device=flat.device)
+                dz_all = torch.empty((world * dz1.shape[0], dz1.shape[1]), dtype=dz1.dtype, device=dz1.device)
+                dist.all_gather_into_tensor(flat_all, flat.contiguous())
+                dist.all_gather_into_tensor(dz_all, dz1.contiguous())
+                flat, dz1 = flat_all, dz_all
+            limit = 65504.0 if self.dtype == "f16" else 3.0e38
+            E.check(lib.y2_range_check(E._ptr(dz1), dz1.numel(), limit, E._ptr(self.ctrl), E._stream()))
+            E.check(lib.y2_range_check(E._ptr(flat), flat.numel(), limit, E._ptr(self.ctrl), E._stream()))
+        E.check(lib.y2_adam_step_guarded(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n,
+                                         E._ptr(self.ctrl), self.lr, 0.9, 0.999, 1e-8, gmult, E._stream()))
+        if fused:
             o, cnt = self.offset["yolo_fc1/weights"]
             E.check(lib.y2_fc_adam_apply_guarded(E._ptr(flat), E._ptr(dz1), E._ptr(self.params[o:o + cnt]), E._ptr(self.m[o:o + cnt]),
                                                  E._ptr(self.v[o:o + cnt]), flat.shape[0], flat.shape[1], dz1.shape[1],
                                                  E._lib.DTYPES[self.dtype], E._ptr(self.ctrl), 0.9, 0.999, 1e-8,
-                                                 1.0 / self.loss_scale, E._stream()))
+                                                 gmult, E._stream()))
             self._fc1_operands = None
 
     def _follow_ctrl(self):
@@ -653,19 +705,23 @@ class ResNet50Yolo:
 
     def step(self, images, labels):
         """one iteration of pascal_train_resnet.py:49-62: get_loss + AdamOptimizer(0.0005).minimize"""
-        if self.graph:
+        if self.graph and self._dp()[0] is None:      # (replicas: the collectives are issued from the host, step by step)
             return self._step_graph(images, labels)
         grid = self.forward(images, True, update_moving=True)
         loss, ious, mask, dnet = E.yolo_loss(grid, labels, self.num_class, self.batch, self.size, self.S, self.B)
         lib = E._lib.load()
         if self.loss_scale != 1.0:
             E.check(lib.y2_scale(E._ptr(dnet), dnet.numel(), self.loss_scale, E._stream()))
-        self.backward(dnet, skip_fc1_dw=self.guard and self.fuse_fc1)
+        self.backward(dnet, skip_fc1_dw=self.guard and self._fc1_fused_now())
         n = self.params.numel()
         if not self.guard:
+            dist, world = self._dp()
+            if dist is not None:                         # f32: every gradient is stored; one SUM over the flat buffer
+                from ..trainer import reduce_flat
+                reduce_flat(self.grads, [(0, n)], dist, self.dp_strategy)
             self.t += 1
             E.check(lib.y2_adam_step(E._ptr(self.params), E._ptr(self.m), E._ptr(self.v), E._ptr(self.grads), n, self.t,
-                                     self.lr, 0.9, 0.999, 1e-8, 1.0 / self.loss_scale, E._stream()))
+                                     self.lr, 0.9, 0.999, 1e-8, 1.0 / (self.loss_scale * world), E._stream()))
             self.params_changed()
             return loss, ious, mask
         # half precision: full overflow scan, then the guarded update (skipped as a whole on the device when any

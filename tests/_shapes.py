@@ -148,7 +148,10 @@ def check_layer_in_network(N, name, k, cin, cout, hw, pool, tag="C4", dtype="f16
     batch statistics, BN + leaky (+ pool) forward, BN backward (dy, dgamma, dbeta) and the in-network weight
     gradient -- each against float64 arithmetic on the values the device stored.
     dtype "f16x2" (split-operand mode): general fp32 inputs and parameters, nothing the device stores is rounded to
-    f16 (conv output, dA and dy are fp32 wide), tolerance TOL as passed."""
+    f16 (conv output, dA and dy are fp32 wide), tolerance TOL as passed.
+    dtype "f16x2f" (round 6): the forward pass is f16x2's; the two backward contractions read the HI planes of their
+    operands, so their float64 references are formed from f16(dy), f16(W), f16(x) -- what the device multiplies, exactly --
+    and the same TOL holds (the operand rounding itself is gated against unrounded float64 in check_layer_shape)."""
     from oracle import nn_ref as R
     from tensorflow_yolo2_amd import engine as E
     rng = np.random.default_rng(k * 1000003 + cin * 1009 + cout * 31 + hw + 17 * pool + 5 + 7 * abs(N - 64))
@@ -185,8 +188,9 @@ def check_layer_in_network(N, name, k, cin, cout, hw, pool, tag="C4", dtype="f16
     dy = net.debug_read(0, 2).cpu().numpy().astype(np.float64)   # d loss / d y as stored
     # what dy must be, from the stored dA (= dgrad of layer 1, checked at op level above) ...
     # recompute dA from layer 1's own stored dy and filter in float64 (1x1 conv: a plain matmul)
-    dy1 = net.debug_read(1, 2).cpu().numpy().astype(np.float64)
-    dA = (dy1.reshape(-1, 32) @ params[1]["W"].reshape(cout, 32).astype(np.float64).T)
+    hi = globals()["f16_representable"] if dtype == "f16x2f" else (lambda a: a)     # hi plane = f16(v)
+    dy1 = hi(net.debug_read(1, 2).cpu().numpy()).astype(np.float64)
+    dA = (dy1.reshape(-1, 32) @ hi(params[1]["W"]).reshape(cout, 32).astype(np.float64).T)
     Ho = hw // 2 if pool else hw
     dA = f16_representable(dA.astype(np.float32)).astype(np.float64).reshape(N, Ho, Ho, cout)   # stored as f16
     if pool:
@@ -223,7 +227,7 @@ def check_layer_in_network(N, name, k, cin, cout, hw, pool, tag="C4", dtype="f16
     # in-network weight gradient from the stored x and stored dy, sampled (ci, co) pairs over all pixels
     ci_s = np.unique(np.r_[0, cin - 1, rng.integers(0, cin, 4)])
     co_s = np.unique(np.r_[0, cout - 1, rng.integers(0, cout, 4)])
-    ref = wgrad_reference(x, dy, k, ci_s, co_s)
+    ref = wgrad_reference(hi(x), hi(dy.astype(np.float32)), k, ci_s, co_s)
     e_dw = rel_to_max(g[0]["W"][:, :, ci_s][:, :, :, co_s], ref)
     if e_dw > TOL:
         got = g[0]["W"][:, :, ci_s][:, :, :, co_s]

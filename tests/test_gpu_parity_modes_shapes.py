@@ -35,7 +35,7 @@ def test_c3_layer_shape_parity_modes(name, k, cin, cout, hw, dtype, tol):
     check_layer_shape(C3_N, name, k, cin, cout, hw, "C3", dtype=dtype, tol=tol, representable=False)
 
 
-@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("f16x2", 1e-4), ("f16x2f", 1e-3)], ids=["f32", "f16x2", "f16x2f"])
+@pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("f16x2", 1e-4), ("f16x2f", 1e-4)], ids=["f32", "f16x2", "f16x2f"])
 @pytest.mark.parametrize("name,k,cin,cout,hw,pool", C3_NET_SHAPES, ids=[s[0] for s in C3_NET_SHAPES])
 def test_c3_layer_in_network_parity_modes(name, k, cin, cout, hw, pool, dtype, tol):
     check_layer_in_network(C3_N, name, k, cin, cout, hw, pool, "C3", dtype=dtype, TOL=tol)
