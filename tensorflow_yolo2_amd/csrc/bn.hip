@@ -193,10 +193,16 @@ hipError_t launch_bn_infer_prepare_all(const BnInferLayer* tab, int nlayers, int
 
 // one 16-byte chunk of channels c0.. of cell `cell` of a bordered tensor with C channels per cell.  SPLIT (f16x2 mode,
 // T = float: four channels): the cell is [C halves hi][C halves lo] (common.h hsplit_t), 8 bytes go to each plane
+// hi_only (f16x2f, backward passes: BnBwdArgs::hi_only): the consumers of this dY -- the dgrad and the weight gradient -- read
+// its hi plane alone, so the lo plane is not written (2 of the 4 bytes per element)
 template <typename T, bool SPLIT>
-Y2_DEV void st_act(char* base, size_t cell, int C, int c0, const float* r) {
+Y2_DEV void st_act(char* base, size_t cell, int C, int c0, const float* r, int hi_only = 0) {
     if constexpr (SPLIT) {
         static_assert(sizeof(T) == 4, "the split store takes fp32 chunks");
+        if (hi_only) {
+            *(u32x2*)(base + cell * (size_t)C * 4 + (size_t)c0 * 2) = u32x2{pack2<half_t>(r[0], r[1]), pack2<half_t>(r[2], r[3])};
+            return;
+        }
         st_split4(base + cell * (size_t)C * 4, C, c0, r);
     } else {
         constexpr int EPC = 16 / sizeof(T);
@@ -681,7 +687,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                             const float t = (sub && d != 0) ? 0.f : fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
                             o[e] = (arg[e] == d) ? fmaf(sc[e], gz[e], t) : t;
                         }
-                        st_act<T, SPLIT>((char*)a.dyp, bpix(n, hi, wi, a.H, a.W), a.ldy, c0, o);
+                        st_act<T, SPLIT>((char*)a.dyp, bpix(n, hi, wi, a.H, a.W), a.ldy, c0, o, a.hi_only);
                     }
                 }
             } else {
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
                         s2[e] = fmaf(gz, yv, s2[e]);
                     }
                 }
-                if (APPLY) st_act<T, SPLIT>((char*)a.dyp, bpix(n, ho, wo, a.H, a.W), a.ldy, c0, o);
+                if (APPLY) st_act<T, SPLIT>((char*)a.dyp, bpix(n, ho, wo, a.H, a.W), a.ldy, c0, o, a.hi_only);
             }
         }
     }
@@ -959,7 +965,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
                     const float t = (sub && d != 0) ? 0.f : fmaf(nkb[e], Elem<T>::to_f32(yc[d].v[e]), nka[e]);
                     o[e] = (arg[e] == d) ? fmaf(sc[e], gz[e], t) : t;
                 }
-                st_act<T, SPLIT>((char*)a.dyp, bpix(n, hi, wi, a.H, a.W), a.ldy, c0, o);
+                st_act<T, SPLIT>((char*)a.dyp, bpix(n, hi, wi, a.H, a.W), a.ldy, c0, o, a.hi_only);
             }
         } else {
             Chunk<T> v = ld_chunk<T>((const char*)a.y + ((size_t)po * a.ldy + c0) * sizeof(T));
@@ -970,7 +976,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
                 const float gz = Elem<T>::to_f32(dav.v[e]) * leaky_slope_s(fmaf(yv, sc[e], sh[e]), a.slope);
                 o[e] = fmaf(sc[e], gz, fmaf(nkb[e], yv, nka[e]));
             }
-            st_act<T, SPLIT>((char*)a.dyp, bpix(n, ho, wo, a.H, a.W), a.ldy, c0, o);
+            st_act<T, SPLIT>((char*)a.dyp, bpix(n, ho, wo, a.H, a.W), a.ldy, c0, o, a.hi_only);
         }
     }
 }

@@ -445,6 +445,7 @@ struct BnBwdArgs {
     float inv_grad_scale;
     int P;                // number of partial blocks (set by launcher)
     float slope = 0.1f;   // activation slope of the forward pass
+    int hi_only = 0;      // f16x2f (split dyp): the consumers read the hi plane of dY alone -- the lo plane is not written
 };
 int bn_bwd_partials(const BnBwdArgs& a);
 hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s);

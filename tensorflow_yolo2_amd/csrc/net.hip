@@ -980,6 +980,8 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         b.ldd = y.ldy;
         b.pool = y.pool; b.training = c->fwd_training[l]; b.inv_grad_scale = inv_gs;
         b.slope = y.slope;
+        // f16x2f: dgrad and weight gradient read the hi plane of this dY alone (the 3-channel layer's own dy goes to fp32 kernels)
+        b.hi_only = (c->bwd_dtype == 4 && !y.first3) ? 1 : 0;
         if (c->zero_bias_grad) b.dbias = nullptr;      // stays zero from y2_bind: the bias is not a variable of this graph
         const bool fused1 = y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz());
         const bool rec1 = y.first3 && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&

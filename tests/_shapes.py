@@ -216,7 +216,9 @@ def check_layer_in_network(N, name, k, cin, cout, hw, pool, tag="C4", dtype="f16
         tie = (zz_sorted[:, :, :, 3, :] - zz_sorted[:, :, :, 2, :]) < 1e-4
         near_w = near.reshape(N, Ho, 2, Ho, 2, cout).any((2, 4)) | tie
         near = np.repeat(np.repeat(near_w, 2, axis=1), 2, axis=2)
-    bad = np.abs(dy - dy_ref) > TOL * np.abs(dy_ref).max()
+    # f16x2f stores the hi plane of dy alone (what its consumers read): the stored value is f16(dy), 2^-11 of each value
+    tol_dy = max(TOL, 6e-4) if dtype == "f16x2f" else TOL
+    bad = np.abs(dy - dy_ref) > tol_dy * np.abs(dy_ref).max()
     nbad = int(bad.sum())
     assert nbad <= 8 + 2e-7 * dy.size, ("too many dy entries off", nbad)
     assert not (bad & ~near).any(), "a dy entry is off away from any decision boundary"
@@ -238,7 +240,7 @@ def check_layer_in_network(N, name, k, cin, cout, hw, pool, tag="C4", dtype="f16
     assert e_conv < TOL and e_act < TOL, (e_conv, e_act)
     # dy / dgamma / dbeta / dW are functions of the f16-stored dA and dy: their own storage rounding (2^-11 of
     # each value) stays inside 1e-3 of the max
-    assert e_dy < TOL and e_dg < TOL and e_db < TOL and e_dw < TOL, (e_dy, e_dg, e_db, e_dw)
+    assert e_dy < tol_dy and e_dg < TOL and e_db < TOL and e_dw < TOL, (e_dy, e_dg, e_db, e_dw)
 
 
 def check_first_layer(N, hw, backward=True, tag="C4", chunk=8, direct=False):
