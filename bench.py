@@ -163,7 +163,7 @@ def f32_mode(args, images, labels, device, total_flops, igemm_flops, dtype="f32"
     if dtype == "f16x2":
         out["mfma_issued_frac"] = 3.0 * out["roofline"]["frac"] if "roofline" in out else None
         out["note"] = ("reference-tolerance mode on the fast matrix pipe: end to end within 1e-3 of the fp32 reference "
-                       "(tests/test_gpu_r5_f16x2.py); frac = algorithmic FLOPs / 2.5 PF, the pipe issues three times that")
+                       "(tests/test_gpu_f16x2.py); frac = algorithmic FLOPs / 2.5 PF, the pipe issues three times that")
     if dtype == "f16x2f":
         # forward: three products per MAC; dgrad and weight gradients: one (hi planes) -- 5/3 of the algorithmic FLOPs issued
         out["mfma_issued_frac"] = 5.0 / 3.0 * out["roofline"]["frac"] if "roofline" in out else None

@@ -228,7 +228,7 @@ def conv_bn_layer(x, p, is_training, pool, dtype=np.float32, bessel=False, quant
     being formed here.  The GPU tests hand over what the device normalised with (Network.layer_statistics) where the
     device forms its moments in another way than from the stored conv output -- the HIP path's pooled 3-channel first
     layer takes them from the Gram matrix of the input patches, csrc/conv1_wgrad.hip -- and gate those moments
-    separately against float64 (tests/test_gpu_r4_kernels.py); the oracle itself knows nothing about that form."""
+    separately against float64 (tests/test_gpu_kernel_policies.py); the oracle itself knows nothing about that form."""
     W = p["W"].astype(dtype)
     if quant is not None:
         W = quant(W).astype(dtype)

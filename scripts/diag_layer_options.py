@@ -1,4 +1,4 @@
-"""Dev tool (GPU): the bottleneck-shaped stack of tests/test_gpu_r4_kernels.py, every gradient's error printed."""
+"""Dev tool (GPU): the bottleneck-shaped stack of tests/test_gpu_kernel_policies.py, every gradient's error printed."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

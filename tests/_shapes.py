@@ -1,5 +1,5 @@
 """Shared float64 checks of the GPU shape tests (test_gpu_c4_shapes.py: BASELINE.json configs[3];
-test_gpu_r3_shapes.py: configs[1], [2] and [4]).  Everything here is test infrastructure: numpy / torch-CPU
+test_gpu_shapes_c2_c3_c5.py: configs[1], [2] and [4]).  Everything here is test infrastructure: numpy / torch-CPU
 float64 restatements of tf.nn.conv2d 'SAME' + bias (src/yolo2_nets/darknet.py:20-21,32-36),
 tf.layers.batch_normalization + tf.maximum(0.1 h, h) + max_pool 2x2 (darknet.py:24-25,39-46) and the
 autodiff of those, evaluated on the values the device stored.

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_r2_host.py::test_grad_reducer_two_ranks_on_one_gpu (started by
+"""Worker of tests/test_gpu_data_parallel.py::test_grad_reducer_two_ranks_on_one_gpu (started by
 torch.distributed.run, one process per rank, both on cuda:0).
 
 Drives trainer.GradReducer.backward_and_reduce -- y2_backward_marks, the per-slice event pairs, the

@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_r4_host.py::test_rccl_backend_runs_the_sliced_allreduce_path (a fresh child process: RCCL
+"""Worker of tests/test_gpu_data_parallel.py::test_rccl_backend_runs_the_sliced_allreduce_path (a fresh child process: RCCL
 and the package's streams are initialised here and nowhere else).
 
 The only RCCL coverage one GPU allows (RCCL refuses two ranks on one device): init_process_group("nccl", world_size=1)

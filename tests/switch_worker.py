@@ -1,4 +1,4 @@
-"""Helper of tests/test_gpu_r2_host.py::test_ab_switches_select_equivalent_paths (not a test): one detector train
+"""Helper of tests/test_gpu_callers_and_snapshots.py::test_ab_switches_select_equivalent_paths (not a test): one detector train
 step at batch 16 under whatever Y2_* switches the parent set; saves loss, gradient buffer, updated parameters and the
 loss's index work (ious, object_mask).  argv[2] (optional): a .npy file with the labels to use instead of the synthetic
 ones (the parent drops the object cells whose two IoUs are near-tied in the default run)."""

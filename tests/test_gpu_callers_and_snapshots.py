@@ -1,0 +1,261 @@
+"""GPU tests (-m gpu): the callers either side of the hot path -- the detect / train scripts
+run through their main() (src/pascal/pascal_detect_darknet.py, src/pascal/pascal_train_darknet.py:83-114), snapshots with
+optimizer slots under the reference's variable names (src/yolo2_nets/net_utils.py:14-110), the A/B environment switches
+selecting equivalent kernel paths, and the detection forward replayed from one HIP graph."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_ref as R, loss_ref as L, optim_ref as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def l2err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+# ---------------------------------------------------------------- a-15: the caller scripts through main()
+def test_detect_and_train_scripts_run_their_main(tmp_path, capsys):
+    """pascal_train_darknet.main(): trains, saves `train_iter_<n>.npz` (variables + Adam slots), a second
+    invocation RESUMES at last_iter_num + 1 (pascal_train_darknet.py:83,93-114).
+    pascal_detect_darknet.main() on the reference's test image restores that snapshot before running
+    (pascal_detect_darknet.py:54-62) and its output equals a forward of the restored variables."""
+    from tensorflow_yolo2_amd import engine as E
+    from tensorflow_yolo2_amd.pascal import pascal_detect_darknet, pascal_train_darknet
+    from tensorflow_yolo2_amd.yolo2_nets import darknet, net_utils
+    from tensorflow_yolo2_amd.img_dataset import pascal_voc
+    ck = str(tmp_path / "ckpts")
+    darknet.reset_default_graph()
+    try:
+        r1 = pascal_train_darknet.main(["--iters", "3", "--batch", "2", "--size", "64", "--dtype", "f32",
+                                        "--ckpt-dir", ck])
+        assert r1["first_iter"] == 1 and r1["last_iter"] == 3 and len(r1["losses"]) == 3
+        assert all(np.isfinite(r1["losses"]))
+        assert os.path.exists(os.path.join(ck, "train_iter_3.npz"))
+        trained = r1["network"].export_params()
+        darknet.reset_default_graph()
+        r2 = pascal_train_darknet.main(["--iters", "2", "--batch", "2", "--size", "64", "--dtype", "f32",
+                                        "--ckpt-dir", ck])
+        assert r2["first_iter"] == 4 and r2["last_iter"] == 5
+        assert os.path.exists(os.path.join(ck, "train_iter_5.npz"))
+        out = capsys.readouterr().out
+        assert "Model saved in file" in out
+        darknet.reset_default_graph()
+        img = os.path.join(ROOT, "tests", "golden", "testImg1.jpg")
+        d = pascal_detect_darknet.main([img, "--size", "224", "--dtype", "f32", "--ckpt-dir", ck, "--no-show"])
+        assert d["restored"] == 5 and tuple(d["predicts"].shape) == (1, 7, 7, 30)
+        # the same forward by hand from the snapshot
+        net = E.Network(list(E.CORE_SPEC) + E.det_head_spec(30), 1, 224, 224, dtype="f32", core_layers=18,
+                        training=False)
+        net.init_params(123)
+        net_utils.restore_variables(net, os.path.join(ck, "train_iter_5.npz"))
+        from PIL import Image
+        rgb = np.array(Image.open(img).convert("RGB"), dtype=np.uint8)
+        x = pascal_voc.image_read(rgb[:, :, ::-1], 224).reshape((1, 224, 224, 3))
+        want = net.forward(dev(x), False, True)
+        np.testing.assert_array_equal(d["predicts"].cpu().numpy().reshape(-1), want.cpu().numpy().reshape(-1))
+        # and without any snapshot the script still runs (initial values: the C1 plumbing case)
+        darknet.reset_default_graph()
+        d0 = pascal_detect_darknet.main([img, "--size", "224", "--dtype", "f32", "--no-show"])
+        assert d0["restored"] == 0 and torch.isfinite(d0["predicts"]).all()
+    finally:
+        darknet.reset_default_graph()
+        darknet.set_default_dtype("f16")
+
+
+# ---------------------------------------------------------------- snapshots with optimizer slots
+def test_snapshot_restores_adam_slots_and_rejects_shape_mismatch(tmp_path):
+    from tensorflow_yolo2_amd import engine as E
+    from tensorflow_yolo2_amd.yolo2_nets import net_utils as NU
+    spec = list(E.CORE_SPEC) + E.det_head_spec(30)
+    net = E.Network(spec, 1, 64, 64, dtype="f32", core_layers=18, training=True)
+    net.init_params(3)
+    opt = E.AdamOptimizer(net)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        net.grads.copy_(torch.as_tensor(rng.standard_normal(net.n_params).astype(np.float32) * 1e-3))
+        opt.step()
+    path = str(tmp_path / "train_iter_3.npz")
+    names = NU.save_variables(net, path, optimizer=opt)
+    assert "darknet19/Variable/Adam" in names and "darknet19_detection/output/Variable_1/Adam_1" in names
+    assert "beta1_power" in names and "beta2_power" in names
+    snap = np.load(path)
+    # TF1's Adam holds beta^(t+1) after t applies (it starts at beta and multiplies once per step): ADVICE r2
+    assert abs(float(snap["beta1_power"]) - 0.9 ** 4) < 1e-7 and abs(float(snap["beta2_power"]) - 0.999 ** 4) < 1e-7
+    # a snapshot converted from a TF checkpoint carries the powers only: the step is recovered from them
+    conv = {k: snap[k] for k in snap.files if k != "adam_step"}
+    np.savez(str(tmp_path / "train_iter_9.npz"), **conv)
+    opt_c = E.AdamOptimizer(net)
+    NU.restore_variables(net, str(tmp_path / "train_iter_9.npz"), optimizer=opt_c)
+    assert opt_c.t == 3
+    net2 = E.Network(spec, 1, 64, 64, dtype="f32", core_layers=18, training=True)
+    net2.init_params(4)
+    opt2 = E.AdamOptimizer(net2)
+    NU.restore_variables(net2, path, optimizer=opt2)
+    assert opt2.t == 3 and torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v)
+    assert torch.equal(net2.params, net.params)
+    # the resumed run takes the same 4th step as the uninterrupted one
+    g = torch.as_tensor(rng.standard_normal(net.n_params).astype(np.float32) * 1e-3)
+    net.grads.copy_(g); net2.grads.copy_(g)
+    opt.step(); opt2.step()
+    assert torch.equal(net2.params, net.params)
+    # another head width under the same names: error, not a silent skip
+    other = E.Network(list(E.CORE_SPEC) + E.det_head_spec(35), 1, 64, 64, dtype="f32", core_layers=18, training=False)
+    other.init_params(0)
+    with pytest.raises(ValueError):
+        NU.restore_variables(other, path)
+
+
+def test_ab_switches_select_equivalent_paths(tmp_path):
+    """Every Y2_* A/B switch of DESIGN section 5 selects between two implementations of the SAME arithmetic: one
+    detector train step (batch 16, f16) under each switch gives the loss of the default path to 1e-3 (f16 outputs of differently ordered sums) and its gradient
+    buffer / updated parameters to f16 round-off; the pure scheduling switches give the same bits (different tilings and summation orders move near-tie decisions)."""
+    import subprocess, sys
+    worker = os.path.join(ROOT, "tests", "switch_worker.py")
+
+    def run(env_extra, tag, labels=None):
+        env = dict(os.environ)
+        env.update(env_extra)
+        out = str(tmp_path / (tag + ".npz"))
+        subprocess.run([sys.executable, worker, out] + ([labels] if labels else []), check=True, env=env, timeout=600)
+        return np.load(out)
+
+    # The loss jumps by O(1 / batch) where a perturbation of the output moves a cell's responsible-box choice (the
+    # arg-max of two IoUs, net_utils.py:300-305).  Round 4 widened the loss bound to 3e-2 to live with that; instead the
+    # object cells whose two IoUs lie within 20 % of each other in the default run are now DROPPED from the labels (a
+    # cell's IoUs depend on its own label only, and the forward pass on none): a switch then cannot flip a responsible box
+    # (the 1e-2 output perturbation moves an IoU by about as much), object_mask must come out IDENTICAL and the loss is
+    # held to 1e-3 again.
+    from tensorflow_yolo2_amd import synthetic
+    probe = run({}, "probe")
+    labels = synthetic.det_labels(16, 416, 13, 8)
+    obj = probe["response"] > 0
+    margin = np.abs(probe["ious"][..., 0] - probe["ious"][..., 1])
+    big = np.maximum(probe["ious"][..., 0], probe["ious"][..., 1])
+    # (a randomly initialised head predicts boxes that barely overlap their ground truth: the IoUs are a few percent, so the
+    #  margin is taken relative to the larger one -- the perturbation is relative too)
+    # ... and absolute as well: a box that barely touches its ground truth (IoU 0.005) loses the overlap altogether
+    tied = obj & ((margin < 0.2 * big) | (margin < 0.02))
+    labels[tied] = 0.0
+    print("object cells %d, dropped as near-tied %d" % (int(obj.sum()), int(tied.sum())))
+    assert int((labels[..., 0] > 0).sum()) >= 4
+    run_seed = str(tmp_path / "labels.npy")
+    np.save(run_seed, labels)
+    base = run({}, "base", run_seed)
+    assert tuple(base["ctrl"]) == (0, 1, 0)
+    switches = [{"Y2_NO_CONV_RF": "1"}, {"Y2_NO_WGRAD_SLAB": "1"}, {"Y2_XCD_CONV": "0", "Y2_XCD_WGRAD": "0"},
+                {"Y2_NO_BN_FIN_FUSE": "1"}, {"Y2_NO_FUSED_TRAIN_OP": "1"}, {"Y2_NO_BNBWD_FUSE": "1"},
+                {"Y2_NO_WGRAD_OVERLAP": "1"}, {"Y2_HALO_COMPACT": "1"}, {"Y2_HALOQ_1X1": "1"}, {"Y2_NO_HALOQ_52": "1"},
+                {"Y2_NO_CONV1_GRAM": "1"}, {"Y2_LEGACY_TILES": "1"}, {"Y2_NO_KSPLIT": "1"},   # round 4: Gram-matrix statistics, tile cost model, K split of small launches
+                {"Y2_CONV1_YSEL": "1"}]     # first layer: arg-max conv outputs kept (ysel) instead of 3 index bits + the linear S2
+    for sw in switches:
+        r = run(sw, "_".join(sw), run_seed)
+        assert tuple(r["ctrl"]) == (0, 1, 0), sw
+        if not np.array_equal(r["mask"], base["mask"]):
+            for c in np.argwhere((r["mask"] != base["mask"]).any(-1)):
+                print("mask differs at", tuple(c), "ious base", base["ious"][tuple(c)], "switch", r["ious"][tuple(c)],
+                      "response", base["response"][tuple(c)])
+        assert np.array_equal(r["mask"], base["mask"]), sw        # index work: the same responsible boxes
+        el = abs(float(r["loss"][4]) - float(base["loss"][4])) / abs(float(base["loss"][4]))
+        eg, ep = l2err(r["grads"], base["grads"]), l2err(r["params"], base["params"])
+        print("switch", sw, "loss %.2e grads %.2e params %.2e" % (el, eg, ep))
+        # a different summation order moves f16 outputs by one ulp at layer 2; the randomly initialised 22-layer
+        # network amplifies that ~1.4x per layer (scripts/diag_switch_forward.py: 5e-6 -> 1.3e-2 at the output), so
+        # the implementation switches are held to the loss (1e-3: the responsible boxes are fixed, above) and to a loose
+        # gradient bound here -- their kernels are checked against the oracle one by one elsewhere; the scheduling
+        # switches below must give the same bits
+        assert el < 1e-3 and eg < 0.5 and ep < 2e-2, (sw, el, eg, ep)
+        # (Y2_HALO_COMPACT: the conflict-free LDS image of conv_haloq -- other addresses, the same products in the
+        #  same order)
+        if any(k in sw for k in ("Y2_NO_FUSED_TRAIN_OP", "Y2_XCD_CONV", "Y2_NO_WGRAD_OVERLAP", "Y2_NO_BN_FIN_FUSE")):
+            assert el == 0.0 and eg == 0.0 and ep == 0.0, sw      # scheduling / same-order switches: the same bits
+        if "Y2_HALO_COMPACT" in sw:
+            # the same products in the same order in every launch it touches -- but the compact image has no K-split form
+            # (round 4: the 13x13 dgrads of this batch-16 step split their K range and leave the BN-backward reduce to the
+            # standalone kernel): other partial sums in the backward pass, the forward pass bit-identical
+            assert el == 0.0 and eg < 1e-2, sw
+        if "Y2_CONV1_YSEL" in sw:
+            # the forward pass is the same arithmetic (the same window maximum); the first layer's sum of g * y is formed
+            # from un-rounded conv outputs (W . X(dz) + b sum dz) instead of the stored f16 ones: its dgamma moves by
+            # f16 round-off, everything above it not at all
+            assert el == 0.0 and eg < 1e-3, sw
+        if "Y2_NO_WGRAD_SLAB" in sw:
+            assert el == 0.0 and eg < 1e-5, sw                    # float atomics: summation order only (observed 2.6e-7)
+        if "Y2_NO_BNBWD_FUSE" in sw:
+            assert el == 0.0 and eg < 1e-2, sw                    # other partial sums of the same reduce (observed 1.4e-3)
+
+
+def test_forward_graph_replays_the_detection_forward():
+    """engine.ForwardGraph: pascal_detect_darknet.py's forward (core with moving statistics, head with batch statistics,
+    one image) captured into ONE HIP graph -- replays on changing inputs give the bits of the eager launches, float32
+    and uint8 inputs, and leave the moving statistics alone."""
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    core = [(k, ci, co, int(p)) for (k, ci, co, p) in R.scaled_spec(R.CORE_SPEC, 4)]
+    head = [(3, core[-1][2], 256, 0), (1, 256, 30, 0)]
+    size = 224
+    for dtype in ("f16", "f32"):
+        net = E.Network(core + head, 1, size, size, dtype=dtype, core_layers=len(core), training=False)
+        net.init_params(3)
+        state0 = net.state.clone()
+        g = net.forward_graph(False, True)
+        gu = net.forward_graph(False, True, uint8=True)
+        rng = np.random.default_rng(0)
+        for i in range(3):
+            x = torch.as_tensor(synthetic.images(1, size, 50 + i)).cuda()
+            want = net.forward(x, False, True).clone()
+            got = g(x)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), (dtype, i)
+            u = torch.as_tensor(rng.integers(0, 256, (1, size, size, 3), dtype=np.uint8)).cuda()
+            want_u = net.forward(u, False, True).clone()
+            got_u = gu(u)
+            torch.cuda.synchronize()
+            assert torch.equal(got_u, want_u), (dtype, i, "uint8")
+        assert torch.equal(net.state, state0)
+
+
+def test_forward_graph_follows_a_parameter_reload():
+    """a ForwardGraph replays the filter packs of its capture; load_params / init_params re-pack only at the
+    next eager forward.  The replay now refreshes the packs first: a graph captured on one set of parameters gives the
+    eager bits of ANOTHER set loaded afterwards, with no eager forward in between."""
+    from oracle import nn_ref as R
+    from tensorflow_yolo2_amd import engine as E, synthetic
+    core = [(k, ci, co, int(p)) for (k, ci, co, p) in R.scaled_spec(R.CORE_SPEC, 4)]
+    head = [(3, core[-1][2], 256, 0), (1, 256, 30, 0)]
+    size = 224
+    net = E.Network(core + head, 1, size, size, dtype="f16", core_layers=len(core), training=False)
+    net.init_params(3)
+    g = net.forward_graph(False, True)
+    x = torch.as_tensor(synthetic.images(1, size, 60)).cuda()
+    first = g(x).clone()
+    torch.cuda.synchronize()
+    other = E.Network(core + head, 1, size, size, dtype="f16", core_layers=len(core), training=False)
+    other.init_params(4)
+    net.load_params(other.export_params())
+    got = g(x).clone()                       # no eager forward since the reload
+    torch.cuda.synchronize()
+    want = other.forward(x, False, True)
+    torch.cuda.synchronize()
+    assert not torch.equal(first, want)
+    assert torch.equal(got, want)
+    got2 = g(x).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(got2, want)

@@ -1,0 +1,113 @@
+"""GPU tests (-m gpu): data parallelism of the detector (slim's clone semantics,
+src/slim_dir/deployment/model_deploy.py:222-225,436-446) -- trainer.GradReducer at world size 2 on one GPU (two rank
+processes, gloo on the device tensors) in f32 / f16 / f16x2 including a one-rank overflow, `bench.py --gpus 2` as the driver
+starts it, the real RCCL backend at world size 1, and the event marks of y2_backward_marks.  The ResNet swap's data
+parallelism: tests/test_gpu_resnet_dp.py; the data-parallel train script: tests/test_dp_train_entry.py; CPU gloo:
+tests/test_dp_gloo.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn_ref as R, loss_ref as L, optim_ref as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def l2err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+# ---------------------------------------------------------------- e: GradReducer at world size 2 on the GPU
+@pytest.mark.parametrize("strategy,dtype", [("allreduce", "f32"), ("rs_ag", "f32"), ("allreduce", "f16"), ("rs_ag", "f16"),
+                                            ("allreduce", "f16x2")])
+def test_grad_reducer_two_ranks_on_one_gpu(strategy, dtype):
+    """VERDICT r1 weak #8 / ADVICE: backward_marks + comm stream + collective at world > 1, on device tensors.
+    Two rank processes share cuda:0 (gloo moves the device tensors; RCCL refuses two ranks on one device).
+    f16: the headline type with its loss scaler, including a step that overflows on ONE rank;
+    f16x2 (round 5): the split-operand mode through the same sequence (its gradients are fp32, its dY rides the scale)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, Y2_DP_STRATEGY=strategy, Y2_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="2", Y2_TEST_DTYPE=dtype)
+    env.pop("Y2_FORCE_DIST", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dp_gpu_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert "dp2 ok" in r.stdout
+
+
+def test_bench_two_ranks_child_tree_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver starts it: the parent spawns the torch.distributed.run
+    child tree BEFORE any GPU call (bench.spawn_ranks; a GPU-initialised process is never re-executed), both ranks run the
+    sharded detector step with the sliced gradient all-reduce and rank 0 prints the one JSON line.  Two ranks share
+    cuda:0 here, so the collective goes through gloo on the device tensors (--dist-backend gloo); everything else of the
+    world > 1 branch is the code the 8-GPU run takes."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "Y2_FORCE_DIST"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--all-ranks-on-gpu0", "--dist-backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-f32-mode", "--no-fast-parity-mode",
+           "--sustain-steps", "0", "--fed-steps", "0", "--no-extra-legs"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["grad_allreduce"]["slices"] == 7
+    assert np.isfinite(d["value"]) and d["value"] > 0 and np.isfinite(d["ms_per_step"])
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # whole-job rate over all ranks
+
+
+def test_rccl_backend_runs_the_sliced_allreduce_path():
+    """torch.distributed backend "nccl" (= RCCL) at world size 1 in a fresh child process, Y2_FORCE_DIST=1: the
+    multi-GPU call sequence (backward marks, communication stream, both collective strategies, optimizer with
+    grad_mult = 1 / world) gives the same bits as the single-process fused train_op (tests/rccl_worker.py).
+    The world-size-2 semantics run under gloo (tests/test_dp_gloo.py, test_grad_reducer_two_ranks_on_one_gpu)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    for k in ("Y2_FORCE_DIST", "Y2_DP_STRATEGY", "Y2_DP_CUTS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    assert "rccl world-1 ok" in r.stdout
+
+
+def test_backward_marks_rejects_out_of_range_layers():
+    from tensorflow_yolo2_amd import engine as E, _lib
+    net = E.Network([(3, 32, 32, 0), (1, 32, 30, 0)], 1, 8, 8, dtype="f32", training=True)
+    net.init_params(0)
+    x = torch.zeros((1, 8, 8, 32), device="cuda")
+    out = net.forward(x, True, True)
+    with pytest.raises(_lib.Y2Error):
+        net.backward_marks(torch.ones_like(out), [0, 2])
+    net.backward_marks(torch.ones_like(out), [1, 0])

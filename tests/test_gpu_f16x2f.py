@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 
 from _shapes import check_layer_shape, rel_to_max   # noqa: E402
 from test_gpu_c4_shapes import C4_SHAPES, _full_detector_step_f32_vs_torch_oracle   # noqa: E402
-from test_gpu_r5_f16x2 import EDGE_SHAPES, STACKS, _stack_vs_f32   # noqa: E402
+from test_gpu_f16x2 import EDGE_SHAPES, STACKS, _stack_vs_f32   # noqa: E402
 
 TOL = 1e-3      # north_star's tolerance, rel. to the tensor's max (tests/_shapes.py)
 
@@ -62,7 +62,7 @@ def test_f16x2f_stack_vs_exact_f32_mode(name, spec, n, hw, tail):
     _stack_vs_f32(spec, n, hw, tail, dtype="f16x2f", tol_b=3e-3)
 
 
-from test_gpu_r5_f16x2 import NET_SHAPES   # noqa: E402
+from test_gpu_f16x2 import NET_SHAPES   # noqa: E402
 
 
 @pytest.mark.parametrize("name,k,cin,cout,hw,pool", NET_SHAPES, ids=[s[0] for s in NET_SHAPES])

@@ -87,7 +87,7 @@ def test_tile_choice_shapes_in_network_inference_fold(N, hw, cin, cout, k):
     512 x 64, 256 x 64: configs[2] at batch 128, the 320 / 608 maps of configs[4]) as LAYERS: a two-layer stack in
     inference mode folds scale / shift / leaky into the first layer's epilogue (bordered output addressing for every
     tile shape); the same stack on a training binding runs conv -> y -> bn_act: the same bits.  The per-shape float64
-    gates of these tiles are in test_gpu_r3_shapes.py (C3) and test_gpu_resnet.py."""
+    gates of these tiles are in test_gpu_shapes_c2_c3_c5.py (C3) and test_gpu_resnet.py."""
     from tensorflow_yolo2_amd import engine as E
     rng = np.random.default_rng(hw * 7 + cin)
     spec = [(k, cin, cout, 0), (1, cout, 32, 0)]

@@ -336,7 +336,7 @@ def test_first_layer_paths_odd_and_wide(shape, dtype):
     q = R.quantizer(dtype)
     # even sizes: the linear-form path, whose batch moments come from the Gram matrix (un-rounded conv output); odd sizes:
     # conv1 + bn_act with the moments of the stored values.  Either way the oracle gets the moments the device normalised
-    # layer 0 with as inputs (test_stack_backward above; the moments themselves are gated in test_gpu_r4_kernels.py)
+    # layer 0 with as inputs (test_stack_backward above; the moments themselves are gated in test_gpu_kernel_policies.py)
     gram = shape[1] % 2 == 0 and shape[2] % 2 == 0
     if q is None:
         ref, caches, _ = R.run_stack(x, params, spec, True, np.float64)

@@ -9,13 +9,13 @@
     (224x224, BATCH 128: 112 / 56 / 28 / 14 / 7 maps -- other tile choices than configs[3]; round 2's f32 mode was wrong
     from batch 24 up for exactly that reason; src/yolo2_nets/darknet.py:61-123) and configs[4] (320 / 608: 10 ... 160 and
     19 ... 304 maps).  The configs[1] inference fold (416x416, batch 32; src/pascal/pascal_detect_darknet.py:41-43) is
-    parametrised over the modes in tests/test_gpu_r3_shapes.py.
+    parametrised over the modes in tests/test_gpu_shapes_c2_c3_c5.py.
 Tolerances (rel. to the tensor's max, tests/_shapes.py): f32 1e-5, f16x2 3e-5, f16x2f forward 3e-5 / backward 1e-3."""
 import pytest
 
 from _shapes import check_layer_in_network, check_layer_shape
 from test_gpu_c4_shapes import C4_SHAPES
-from test_gpu_r3_shapes import C3_N, C3_NET_SHAPES, C3_SHAPES, C5_N, C5_SHAPES
+from test_gpu_shapes_c2_c3_c5 import C3_N, C3_NET_SHAPES, C3_SHAPES, C5_N, C5_SHAPES
 
 pytestmark = pytest.mark.gpu
 
