@@ -99,6 +99,8 @@ struct y2_ctx {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     int bound_training = 0;
+    int bind_gen = 0;              // incremented by every y2_bind: a pack-group table (absolute pointers) is valid for ONE binding
+    int group_gen = -1;            // bind_gen recorded by y2_pack_group_table
     bool weights_dirty = true;
     bool fwd_saved = false;
     bool moving_pending = false;   // last forward ran with update_moving = 0
@@ -517,6 +519,7 @@ int y2_bind(y2_ctx* c, float* params, float* grads, float* state, void* workspac
     c->params = params; c->grads = grads; c->state = state;
     c->ws = (char*)workspace; c->ws_bytes = workspace_bytes; c->bound_training = training;
     c->weights_dirty = true; c->fwd_saved = false;
+    ++c->bind_gen;
     // borders, guard bands and channel padding must be (and then stay) zero
     HIPCHK(hipMemsetAsync(workspace, 0, need, (hipStream_t)stream));
     // filter re-pack job table (one launch per step for all layers)
@@ -674,6 +677,7 @@ int y2_pack_group_table(y2_ctx** ctxs, int n, void* table_dev, size_t table_byte
             all.push_back(p);
         }
         nb += c->pack_blocks;
+        c->group_gen = c->bind_gen;
     }
     if (all.size() * sizeof(PackLayer) > table_bytes) return fail(Y2_ERR_ARG, "y2_pack_group_table: %zu bytes needed", all.size() * sizeof(PackLayer));
     if (!all.empty()) HIPCHK(hipMemcpy(table_dev, all.data(), all.size() * sizeof(PackLayer), hipMemcpyHostToDevice));
@@ -683,6 +687,13 @@ int y2_pack_group_table(y2_ctx** ctxs, int n, void* table_dev, size_t table_byte
 }
 int y2_pack_group_run(y2_ctx** ctxs, int n, const void* table_dev, int nlayers, int blocks, void* stream) {
     if (!ctxs || n < 1 || !table_dev) return fail(Y2_ERR_ARG, "y2_pack_group_run: bad arguments");
+    // the table holds absolute pointers copied at y2_pack_group_table time: a member re-bound since then (y2_bind /
+    // Network.rebind) would silently run on stale packed filters -- refuse instead
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !ctxs[i]->ws) return fail(Y2_ERR_STATE, "y2_pack_group_run: context %d is not bound", i);
+        if (ctxs[i]->group_gen != ctxs[i]->bind_gen)
+            return fail(Y2_ERR_STATE, "y2_pack_group_run: context %d was re-bound after y2_pack_group_table: build the table again", i);
+    }
     if (nlayers > 0 && blocks > 0)
         HIPCHK(launch_pack_all(ctxs[0]->dtype, (const PackLayer*)table_dev, nlayers, blocks, (hipStream_t)stream));
     for (int i = 0; i < n; ++i) ctxs[i]->weights_dirty = false;
@@ -1177,13 +1188,17 @@ size_t y2_bordered_bytes(int N, int H, int W, int C, int dtype, size_t* cell0_of
 }
 int y2_link(y2_ctx* c, void* x_bordered, void* out_bordered, const void* join_bordered, int join_self, const void* dout_t,
             void* dx_t) {
+    if (!c || c->L.empty()) return fail(Y2_ERR_ARG, "y2_link: null or empty context");
     if (dtype_split(c->dtype) && (x_bordered || out_bordered || join_bordered || join_self || dout_t || dx_t))
         return fail(Y2_ERR_ARG, "y2_link: not built for the split-operand mode");
     const Layer& first = c->L.front();
     const Layer& last = c->L.back();
     if ((x_bordered || dx_t) && first.first3) return fail(Y2_ERR_ARG, "y2_link: the 3-channel image layer takes fp32 / uint8 images");
-    if ((out_bordered || join_bordered || join_self) && (c->tail == Y2_TAIL_AVGPOOL || last.cout != last.ldy || (last.cout % 8) != 0))
-        return fail(Y2_ERR_ARG, "y2_link: the linked output needs out_chl in multiples of 32 and no average-pool tail");
+    // (ldy = out_chl rounded up to 32: the linked tensors have no padding channels)
+    if ((out_bordered || join_bordered || join_self || dout_t) && (c->tail == Y2_TAIL_AVGPOOL || last.cout != last.ldy))
+        return fail(Y2_ERR_ARG, "y2_link: the linked output / its gradient need out_chl in multiples of 32 and no average-pool tail");
+    if ((x_bordered || dx_t) && first.cin_s != first.cin)
+        return fail(Y2_ERR_ARG, "y2_link: the linked input / its gradient need in_chl equal to the tensor's channel stride");
     if (join_self && (first.cin != last.cout || first.H != last.Ho || first.W != last.Wo))
         return fail(Y2_ERR_ARG, "y2_link: an identity shortcut needs input and output of one shape");
     if (join_self && join_bordered) return fail(Y2_ERR_ARG, "y2_link: one join");
