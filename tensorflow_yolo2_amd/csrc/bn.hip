@@ -213,6 +213,23 @@ Y2_DEV void st_act(char* base, size_t cell, int C, int c0, const float* r, int h
     }
 }
 
+// one chunk of dA (BnBwdArgs): EPC elements of T -- or, in the fp32-wide kernels of the f16x2f mode, four halves widened
+// (dA_half: the dgrad above stored its output in f16, common.h hsplithh_t)
+template <typename T>
+Y2_DEV Chunk<T> ld_dA(const BnBwdArgs& a, size_t po, int c0) {
+    if constexpr (sizeof(T) == 4) {
+        if (a.dA_half) {
+            half_t h[4];
+            *(u32x2*)h = *(const u32x2*)((const char*)a.dA + (po * a.ldd + c0) * 2);
+            Chunk<T> c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c.v[e] = (float)h[e];
+            return c;
+        }
+    }
+    return ld_chunk<T>((const char*)a.dA + (po * a.ldd + c0) * sizeof(T));
+}
+
 // ---------------------------------------------------------------------------
 // forward: out = maxpool2x2?( leaky( y*scale + shift ) )
 // One 2x2 window of a pooled layer's apply pass: r = the activation's maximum, ys = the conv output at its first
@@ -605,7 +622,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(BnBwdArgs a) {
         for (uint32_t po = p_begin + row; po < p_end; po += g.rows, wo += dcol, ho += drow) {
             if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
             while (ho >= g.Ho) { ho -= g.Ho; ++n; }
-            Chunk<T> dav = ld_chunk<T>((const char*)a.dA + ((size_t)po * a.ldd + c0) * sizeof(T));
+            Chunk<T> dav = ld_dA<T>(a, po, c0);
             if (POOL) {
                 Chunk<T> yc[4];
                 bool valid[4];
@@ -893,7 +910,7 @@ __global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(BnBwdArgs a) {
     for (uint32_t po = p_begin + row; po < p_end; po += rows, wo += dcol, ho += drow) {
         if (wo >= Wo) { wo -= Wo; ++ho; }
         while (ho >= Ho) { ho -= Ho; ++n; }
-        Chunk<T> dav = ld_chunk<T>((const char*)a.dA + ((size_t)po * a.ldd + c0) * sizeof(T));
+        Chunk<T> dav = ld_dA<T>(a, po, c0);
         if (POOL) {
             Chunk<T> yc[4];
             bool valid[4];

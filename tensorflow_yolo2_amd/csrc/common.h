@@ -86,10 +86,23 @@ template <> struct Elem<hsplith_t> {
     static constexpr int kPerFrag = 8;
     static constexpr int kId = 4;
 };
-// operand type of the MFMA kernels / type of what their epilogues store; kPasses = plane passes of the K loop
-template <typename T> struct Types { typedef T op_t; typedef T out_t; static constexpr bool kSplit = false; static constexpr int kPasses = 1; };
-template <> struct Types<hsplit_t> { typedef half_t op_t; typedef float out_t; static constexpr bool kSplit = true; static constexpr int kPasses = 3; };
-template <> struct Types<hsplith_t> { typedef half_t op_t; typedef float out_t; static constexpr bool kSplit = true; static constexpr int kPasses = 1; };
+// ... and (launch dtype 5, dgrad launches of the f16x2f mode above the second layer) the same contraction with its OUTPUT
+// stored in f16 as well: dA, the gradient with respect to a layer's input, is consumed once, by the batch-norm backward
+// pass of the layer below, which rounds its own result (dY) to f16 for the next contraction anyway -- 2 of 4 bytes per element
+// on the write and on the read; the batch-norm backward reduce fused into this epilogue still reads that layer's fp32 conv
+// output (kBwF32)
+struct hsplithh_t { uint32_t bits; };
+template <> struct Elem<hsplithh_t> {
+    typedef f16x8 frag;
+    static constexpr int kPerFrag = 8;
+    static constexpr int kId = 5;
+};
+// operand type of the MFMA kernels / type of what their epilogues store; kPasses = plane passes of the K loop; kBwF32: the
+// conv output the fused batch-norm backward reduce reads (ConvArgs::bw_y) is fp32 although the epilogue stores 16-bit values
+template <typename T> struct Types { typedef T op_t; typedef T out_t; static constexpr bool kSplit = false; static constexpr int kPasses = 1; static constexpr bool kBwF32 = false; };
+template <> struct Types<hsplit_t> { typedef half_t op_t; typedef float out_t; static constexpr bool kSplit = true; static constexpr int kPasses = 3; static constexpr bool kBwF32 = false; };
+template <> struct Types<hsplith_t> { typedef half_t op_t; typedef float out_t; static constexpr bool kSplit = true; static constexpr int kPasses = 1; static constexpr bool kBwF32 = false; };
+template <> struct Types<hsplithh_t> { typedef half_t op_t; typedef half_t out_t; static constexpr bool kSplit = true; static constexpr int kPasses = 1; static constexpr bool kBwF32 = true; };
 // K chunk c of a launch whose K range is [hi plane | lo plane | hi plane again] x [filter hi | filter hi | filter lo]:
 // n = chunks per plane.  Activation chunk: c mod 2n; filter chunk: c < n ? c : c - n (hi, hi, lo).
 template <bool SPLIT> Y2_DEV int split_act_chunk(int c, int n) { return SPLIT ? (c >= 2 * n ? c - 2 * n : c) : c; }

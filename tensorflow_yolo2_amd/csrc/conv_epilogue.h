@@ -27,13 +27,14 @@ struct EpiCfg {
 // phases 2 and 3 (after the wave's patch has been written)
 // cstride / coff (conv_epilogue16 callers that run the epilogue in TWO passes over halves of a wave's couts, because the
 // fp32 patch of the whole tile does not fit LDS): the couts of wave column wc start at n0 + wc * cstride + coff
-template <typename T, int WP, int WC, int TP, int TC, int EABL = 0>
+// BWF32 (16-bit T only; f16x2f dgrad launches, common.h hsplithh_t): ConvArgs::bw_y is fp32 [M][ldy]
+template <typename T, int WP, int WC, int TP, int TC, int EABL = 0, bool BWF32 = false>
 Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane, int m0, int n0, int pt, int ct,
                                  int cstride = TC * 32, int coff = 0);
 
 // must be entered by ALL threads of the block, after a barrier that retires every read
 // of the staging buffers (the patch aliases them)
-template <typename T, int WP, int WC, int TP, int TC, int EABL = 0>
+template <typename T, int WP, int WC, int TP, int TC, int EABL = 0, bool BWF32 = false>
 Y2_DEV void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TC][TP], char* smem, int w, int lane, int m0, int n0,
                           int pt, int ct) {
     typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
@@ -63,7 +64,7 @@ Y2_DEV void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TC][TP], char* smem, 
             }
         }
     }
-    conv_epilogue_finish<T, WP, WC, TP, TC, EABL>(a, smem, w, lane, m0, n0, pt, ct);
+    conv_epilogue_finish<T, WP, WC, TP, TC, EABL, BWF32>(a, smem, w, lane, m0, n0, pt, ct);
 }
 
 // same, accumulators of 16x16 MFMA tiles: acc[i16][j16][r] = D[cout i16*16 + 4*(lane>>4) + r][pixel j16*16 + (lane&15)]
@@ -73,7 +74,7 @@ Y2_DEV void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[TC][TP], char* smem, 
 Y2_DEV int perm16(int c) { return c < 4 ? 2 * c : (c >= 12 ? 2 * (c - 8) : 2 * (c - 4) + 1); }
 
 // PERM: the accumulator columns are dealt by perm16 (the patch is written in pixel order either way)
-template <typename T, int WP, int WC, int TP, int TC, bool PERM = false>
+template <typename T, int WP, int WC, int TP, int TC, bool PERM = false, bool BWF32 = false>
 Y2_DEV void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[2 * TC][2 * TP], char* smem, int w, int lane, int m0,
                             int n0, int pt, int ct, int cstride = TC * 32, int coff = 0) {
     typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
@@ -100,12 +101,13 @@ Y2_DEV void conv_epilogue16(const ConvArgs& a, f32x4 (&acc)[2 * TC][2 * TP], cha
             else *(u32x4*)dst = *(const u32x4*)o;
         }
     }
-    conv_epilogue_finish<T, WP, WC, TP, TC, 0>(a, smem, w, lane, m0, n0, pt, ct, cstride, coff);
+    conv_epilogue_finish<T, WP, WC, TP, TC, 0, BWF32>(a, smem, w, lane, m0, n0, pt, ct, cstride, coff);
 }
 
-template <typename T, int WP, int WC, int TP, int TC, int EABL>
+template <typename T, int WP, int WC, int TP, int TC, int EABL, bool BWF32>
 Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane, int m0, int n0, int pt, int ct,
                                  int cstride, int coff) {
+    static_assert(!BWF32 || sizeof(T) == 2, "BWF32: a 16-bit output beside an fp32 conv output of the layer below");
     typedef EpiCfg<T, WP, WC, TP, TC> Cfg;
     constexpr int NW = Cfg::NW, SZ = Cfg::SZ, BP = Cfg::BP, EROW = Cfg::EROW;
     const int wp = w / WC, wc = w % WC;
@@ -238,17 +240,21 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
             sc[e] = cv ? a.bw_scale[cch + e] : 0.f;
             sh[e] = cv ? a.bw_shift[cch + e] : 0.f;
         }
-        const char* yb = (const char*)a.bw_y + (size_t)cch * SZ;
-        const size_t rowB = (size_t)a.ldy * SZ;
+        constexpr int YSZ = BWF32 ? 4 : SZ;          // element size of the conv output the reduce reads
+        const char* yb = (const char*)a.bw_y + (size_t)cch * YSZ;
+        const size_t rowB = (size_t)a.ldy * YSZ;
         // every y chunk of the sweep is requested before the first one is used (the accumulators are dead: the
         // registers are free, and one HBM latency is paid per tile instead of one per row group)
-        Chunk<T> yv[NIT];
+        struct YChunk { typename std::conditional<BWF32, float, T>::type v[EPC]; };
+        YChunk yv[NIT];
         if (cv) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 int p = mw0 + it * RPIe + prow0;
                 if (p > a.M - 1) p = a.M - 1;
-                yv[it] = ld_chunk<T>(yb + (size_t)p * rowB);
+#pragma unroll
+                for (int k = 0; k < (int)sizeof(YChunk) / 16; ++k)
+                    *((u32x4*)yv[it].v + k) = *((const u32x4*)(yb + (size_t)p * rowB) + k);
             }
         }
 #pragma unroll
@@ -260,7 +266,7 @@ Y2_DEV void conv_epilogue_finish(const ConvArgs& a, char* smem, int w, int lane,
                 st_chunk<T>((char*)a.y + ((size_t)(mw0 + prow) * a.ldy + cch) * SZ, c);
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
-                    const float yf = Elem<T>::to_f32(yv[it].v[e]);
+                    const float yf = (float)yv[it].v[e];
                     const float g = Elem<T>::to_f32(c.v[e]) * leaky_slope_s(fmaf(yf, sc[e], sh[e]), a.bw_slope);
                     s1[e] += g;
                     s2[e] = fmaf(g, yf, s2[e]);

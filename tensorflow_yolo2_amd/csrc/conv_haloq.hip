@@ -379,7 +379,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq_kernel(ConvArgs a, int
 #pragma unroll
                 for (int j = 0; j < TP; ++j) acc[i][j] *= kSplitWScaleInv;
         }
-        conv_epilogue<YT, WP, WC, TP, TC>(a, acc, smem, w, lane, m0, n0, pt, ct);
+        conv_epilogue<YT, WP, WC, TP, TC, 0, Types<T>::kBwF32>(a, acc, smem, w, lane, m0, n0, pt, ct);
     }
 }
 
@@ -730,10 +730,10 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_haloq16_kernel(ConvArgs a, i
 #pragma unroll
                 for (int j = 0; j < TP16; ++j) acch[i][j] = acc[h * (TC16 / 2) + i][j];
             if (h) __syncthreads();      // pass 0's patch and the statistics scratch that aliases it are dead
-            conv_epilogue16<YT, WP, WC, TP, TC / 2, CPT>(a, acch, smem, w, lane, m0, n0, pt, ct, TC * 32, h * (TC / 2) * 32);
+            conv_epilogue16<YT, WP, WC, TP, TC / 2, CPT, Types<T>::kBwF32>(a, acch, smem, w, lane, m0, n0, pt, ct, TC * 32, h * (TC / 2) * 32);
         }
     } else {
-        conv_epilogue16<YT, WP, WC, TP, TC, CPT>(a, acc, smem, w, lane, m0, n0, pt, ct);
+        conv_epilogue16<YT, WP, WC, TP, TC, CPT, Types<T>::kBwF32>(a, acc, smem, w, lane, m0, n0, pt, ct);
     }
 }
 
@@ -1002,6 +1002,7 @@ hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* b
         case 2: return haloq_T<bf16_t>(a, s, bp);
         case 3: return haloq_T<hsplit_t>(a, s, bp);
         case 4: return haloq_T<hsplith_t>(a, s, bp);     // f16x2f backward launches: the hi planes of split tensors
+        case 5: return haloq_T<hsplithh_t>(a, s, bp);    // ... with dA stored in f16 (common.h hsplithh_t)
     }
     return hipErrorInvalidValue;
 }

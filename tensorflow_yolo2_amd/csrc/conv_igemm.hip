@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < TP; ++j) acc[i][j] *= kSplitWScaleInv;
     }
-    conv_epilogue<YT, WP, WC, TP, TC, (ABL >> 6)>(a, acc, smem, w, lane, m0, n0, pt, ct);
+    conv_epilogue<YT, WP, WC, TP, TC, (ABL >> 6), Types<T>::kBwF32>(a, acc, smem, w, lane, m0, n0, pt, ct);
 }
 
 template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0>
@@ -303,6 +303,7 @@ hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
         case 2: return launch_T<bf16_t>(a, s);
         case 3: return launch_T<hsplit_t>(a, s);
         case 4: return launch_T<hsplith_t>(a, s);        // f16x2f backward launches: the hi planes of split tensors
+        case 5: return launch_T<hsplithh_t>(a, s);       // ... with dA stored in f16 (common.h hsplithh_t)
     }
     return hipErrorInvalidValue;
 }

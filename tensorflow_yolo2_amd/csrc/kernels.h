@@ -11,6 +11,7 @@ namespace y2 {
 
 //   4 = f16x2f (round 6): LAUNCH dtype of the backward contractions of a split-mode context created with Y2_F16X2F -- the
 //       same split tensors, hi planes only, one f16 MFMA per product (common.h hsplith_t).  A context's own dtype is 3.
+//   5 = the same contraction (dgrad launches only) with its output dA stored in f16 instead of fp32 (common.h hsplithh_t)
 inline size_t dtype_size(int dtype) { return (dtype == 0 || dtype >= 3) ? 4 : 2; }   // bytes per stored element
 inline int dtype_kbytes(int dtype) { return dtype == 0 ? 4 : 2; }                  // bytes per element of ONE K plane (MFMA operand)
 inline bool dtype_split(int dtype) { return dtype >= 3; }
@@ -293,7 +294,7 @@ inline int wgrad_split_args(int dtype, WgradArgs& a) {
     if (!a.ypitch) a.ypitch = a.Cdy;
     if (!dtype_split(dtype)) return dtype;
     a.xpitch = 2 * a.Cin; a.ypitch = 2 * a.Cdy;
-    a.quads = dtype == 4 ? 1 : 3;      // f16x2f: the hi-plane pair alone -- the f16 kernels on cells of twice the pitch
+    a.quads = dtype >= 4 ? 1 : 3;      // f16x2f: the hi-plane pair alone -- the f16 kernels on cells of twice the pitch
     return 1;
 }
 // one launch per operand-plane pair (WgradArgs::quads): hi hi, x lo, dy lo -- each with its own slab range
@@ -446,6 +447,7 @@ struct BnBwdArgs {
     int P;                // number of partial blocks (set by launcher)
     float slope = 0.1f;   // activation slope of the forward pass
     int hi_only = 0;      // f16x2f (split dyp): the consumers read the hi plane of dY alone -- the lo plane is not written
+    int dA_half = 0;      // f16x2f (T = float kernels): dA [M_out][ldd] is f16 (written by a launch-dtype-5 dgrad, common.h hsplithh_t)
 };
 int bn_bwd_partials(const BnBwdArgs& a);
 hipError_t launch_bn_bwd_reduce(int dtype, BnBwdArgs& a, hipStream_t s);

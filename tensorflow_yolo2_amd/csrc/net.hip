@@ -112,6 +112,7 @@ struct y2_ctx {
     size_t part_rows, part_ld;
     size_t total_infer = 0, total_train = 0;
     int dA_cur = 0;
+    int dA_half = 0;            // f16x2f: the dA buffer in use holds f16 values (written by a launch-dtype-5 dgrad)
     // pooled 3-channel first layer, training: the linear form of its backward pass (conv1_wgrad.hip) -- its conv
     // output is never stored
     bool lin1() const { return bound_training && !L.empty() && L[0].idx0 != 0; }
@@ -921,6 +922,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
     const float inv_gs = 1.0f / c->grad_scale;
     char* dA[2] = {c->ws + c->o_dA0, c->ws + c->o_dA1};
     const bool ext_top = layer_hi == nl && c->ext_dout != nullptr;
+    if (layer_hi == nl) c->dA_half = 0;        // the top layer's dA is the fp32 output gradient (times grad_scale)
     if (ext_top) {
         c->dA_cur = 0;
         if (layer_lo > 0 && c->grads) HIPCHK(hipMemsetAsync(c->grads, 0, c->L[layer_lo].pW * sizeof(float), s));
@@ -993,6 +995,7 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
         b.slope = y.slope;
         // f16x2f: dgrad and weight gradient read the hi plane of this dY alone (the 3-channel layer's own dy goes to fp32 kernels)
         b.hi_only = (c->bwd_dtype == 4 && !y.first3) ? 1 : 0;
+        b.dA_half = c->dA_half;
         if (c->zero_bias_grad) b.dbias = nullptr;      // stays zero from y2_bind: the bias is not a variable of this graph
         const bool fused1 = y.first3 && conv1_wgrad_fused_ok(y.H, y.W, y.pool, y.ldy, (int)c->sz());
         const bool rec1 = y.first3 && (size_t)l + 1 < c->L.size() && y.ldy == 32 &&
@@ -1120,9 +1123,15 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                     a.bw_slope = z.slope;
                 }
                 int rec = 0;
-                { PROF(CAT_DGRAD); HIPCHK(launch_conv(c->bwd_dtype, a, s, &bp, &rec)); }
+                // f16x2f: dA is consumed once, by the batch-norm backward pass of the layer below, which rounds its own result
+                // to f16 for the next contraction: store it in f16 (launch dtype 5) wherever that consumer is one of the
+                // fp32-wide batch-norm kernels (not the 3-channel layer's own kernels, not an external input gradient)
+                static const bool da32 = getenv("Y2_F16X2F_DA32") != nullptr;      // A/B switch: fp32 dA everywhere
+                const bool half_out = c->bwd_dtype == 4 && !da32 && l > 0 && !z.first3;
+                { PROF(CAT_DGRAD); HIPCHK(launch_conv(half_out ? 5 : c->bwd_dtype, a, s, &bp, &rec)); }
                 if (fuse) fused_P = rec;
                 c->dA_cur ^= 1;
+                c->dA_half = half_out ? 1 : 0;
                 if (l == 0 && c->dinput)   // the stack's input gradient leaves in fp32 NHWC, loss scale divided out
                     HIPCHK(launch_cast_to_f32(c->dtype, c->ext_dx ? (const void*)c->ext_dx : (const void*)dA[c->dA_cur], c->dinput,
                                               (size_t)y.M, y.cin, y.cin, s, inv_gs));

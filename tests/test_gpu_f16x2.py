@@ -254,12 +254,13 @@ def test_f16_mfma_keeps_subnormal_operands():
     """The lo plane of the split-operand mode lives in f16's subnormal range for |v| < 2^-3 (csrc/common.h hsplit_t): the
     design relies on v_mfma_f32_*_f16 NOT flushing subnormal A / B inputs on gfx950 (first measured with
     scripts/probes/mfma_denorm.hip; ADVICE r5: re-checked here on every run, through the product library).  A 1x1
-    convolution of subnormal activations 2^-20 and 3 * 2^-24 with weights of 1024 over 32 channels: the exact sums, not 0."""
+    convolution of subnormal activations 2^-20 and 3 * 2^-24 with weights of 8 over 32 channels: the exact sums, not 0.
+    (Weights stay below 1024 in the split mode: its filter planes hold 64 w in f16, common.h kSplitWScale.)"""
     from tensorflow_yolo2_amd import engine as E
     for a in (2.0 ** -20, 3 * 2.0 ** -24):
         assert 0 < float(np.float16(a)) < 2.0 ** -14                 # subnormal in f16, exactly representable
         x = torch.full((1, 4, 4, 32), a, dtype=torch.float32, device="cuda")
-        w = torch.full((1, 1, 32, 32), 1024.0, dtype=torch.float32, device="cuda")
+        w = torch.full((1, 1, 32, 32), 8.0, dtype=torch.float32, device="cuda")
         for dt in ("f16", "f16x2"):
             y = E.conv2d(x, w, None, dtype=dt).cpu().numpy()
             want = 32 * a * 1024.0
