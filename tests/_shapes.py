@@ -192,7 +192,8 @@ def check_layer_in_network(N, name, k, cin, cout, hw, pool, tag="C4", dtype="f16
     dy1 = hi(net.debug_read(1, 2).cpu().numpy()).astype(np.float64)
     dA = (dy1.reshape(-1, 32) @ hi(params[1]["W"]).reshape(cout, 32).astype(np.float64).T)
     Ho = hw // 2 if pool else hw
-    dA = f16_representable(dA.astype(np.float32)).astype(np.float64).reshape(N, Ho, Ho, cout)   # stored as f16
+    # f16: dA is stored as f16.  f16x2f: so is every dA that feeds one of the fp32-wide batch-norm kernels (launch dtype 5)
+    dA = hi(f16_representable(dA.astype(np.float32))).astype(np.float64).reshape(N, Ho, Ho, cout)
     if pool:
         zz = act.reshape(N, Ho, 2, Ho, 2, cout).transpose(0, 1, 3, 2, 4, 5).reshape(N, Ho, Ho, 4, cout)
         first = zz.argmax(3)                                       # first maximum in row-major window order

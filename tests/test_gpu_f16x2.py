@@ -263,6 +263,6 @@ def test_f16_mfma_keeps_subnormal_operands():
         w = torch.full((1, 1, 32, 32), 8.0, dtype=torch.float32, device="cuda")
         for dt in ("f16", "f16x2"):
             y = E.conv2d(x, w, None, dtype=dt).cpu().numpy()
-            want = 32 * a * 1024.0
+            want = 32 * a * 8.0
             got = float(y[0, 1, 1, 0])
             assert abs(got - want) <= 2.0 ** -11 * want, (dt, a, got, want)
