@@ -392,6 +392,8 @@ int haloq_tile_choice(int W, int row_bytes, int Cout, int M, int elem_size) {
 int conv_filter_layout(int taps, int W, int row_bytes, int Cout, int M, int dgrad, int elem_size, int split) {
     if (taps == 1) {
         if (split) return 0;
+        // round 6: the deep-ring 1x1 kernel (conv_gemm1.hip) reads 32-row fragments, 16-bit types
+        if (elem_size == 2 && conv_gemm1_ok(taps, row_bytes, Cout, M)) return 1;
         // 1x1 on conv_haloq (one tap per K-chunk, compact image): 128-byte K chunks, more than 64 output channels, enough
         // pixels for 384-pixel tiles; 384 x 64 tiles on 32x32 MFMAs (layout 1) where 384 x 128 tiles would leave CUs
         // idle, else 384 x 128 on 16x16 MFMAs (layout 2).  Opt-in (Y2_HALOQ_1X1=1): measured no faster than conv_igemm
@@ -463,7 +465,8 @@ hipError_t launch_conv(int dtype, const ConvArgs& a0, hipStream_t s, int* block_
         if (records) *records = rec;
         return e;
     }
-    if (conv_filter_layout(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad, esz, split)) e = launch_conv_haloq(dtype, a, s, &bp);
+    if (a.taps == 1 && (dtype == 1 || dtype == 2) && conv_gemm1_ok(a.taps, rowb, a.Cout, a.M)) e = launch_conv_gemm1(dtype, a, s, &bp);
+    else if (conv_filter_layout(a.taps, a.W, rowb, a.Cout, a.M, a.is_dgrad, esz, split)) e = launch_conv_haloq(dtype, a, s, &bp);
 #ifdef Y2_DEVBUILD
     else if (a.taps == 9 && dtype == 1 && dev_rule(a.W, a.Cout) >= 0)
         e = launch_conv_halo_variant(dev_rule(a.W, a.Cout), a, s, &bp);

@@ -88,6 +88,9 @@ bool conv_affine_ok(int dtype, const ConvArgs& a);
 // ... and which POOLED layers do (ConvArgs::aff_pool; conv_affine_ok holds too)
 bool conv_affine_pool_ok(int dtype, const ConvArgs& a);
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s);   // per-tap staging (used for 1x1)
+// 1x1 (round 6, conv_gemm1.hip): filter fragments straight from L2 (pack layout 1), the pixel tile in a deep LDS ring
+bool conv_gemm1_ok(int taps, int row_bytes, int Cout, int M);
+hipError_t launch_conv_gemm1(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);
 hipError_t launch_conv_halo(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels);  // 3x3: LDS halo image
 hipError_t launch_conv_haloq(int dtype, const ConvArgs& a, hipStream_t s, int* block_pixels); // + filters via registers
 // filter layout launch_conv expects (0/1/2).  row_bytes = bytes of one operand plane per pixel (dtype_kbytes), elem_size
