@@ -164,7 +164,8 @@ def test_ab_switches_select_equivalent_paths(tmp_path):
                 {"Y2_NO_BN_FIN_FUSE": "1"}, {"Y2_NO_FUSED_TRAIN_OP": "1"}, {"Y2_NO_BNBWD_FUSE": "1"},
                 {"Y2_NO_WGRAD_OVERLAP": "1"}, {"Y2_HALO_COMPACT": "1"}, {"Y2_HALOQ_1X1": "1"}, {"Y2_NO_HALOQ_52": "1"},
                 {"Y2_NO_CONV1_GRAM": "1"}, {"Y2_LEGACY_TILES": "1"}, {"Y2_NO_KSPLIT": "1"},   # round 4: Gram-matrix statistics, tile cost model, K split of small launches
-                {"Y2_CONV1_YSEL": "1"}]     # first layer: arg-max conv outputs kept (ysel) instead of 3 index bits + the linear S2
+                {"Y2_CONV1_YSEL": "1"},     # first layer: arg-max conv outputs kept (ysel) instead of 3 index bits + the linear S2
+                {"Y2_GEMM1": "1"}]          # round 6: the deep-ring 1x1 kernel (conv_gemm1.hip) instead of conv_igemm
     for sw in switches:
         r = run(sw, "_".join(sw), run_seed)
         assert tuple(r["ctrl"]) == (0, 1, 0), sw
