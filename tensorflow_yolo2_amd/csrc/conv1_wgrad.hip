@@ -393,7 +393,9 @@ constexpr int kLinItems = 0;     // items (pooled pixel x chunk) per thread held
 // XS (f16x2 mode, T = float: round 5): the fp32 row images are read as in the exact-fp32 form, split into (hi, lo) halves
 // in registers, and X(dz) / G are three v_mfma_f32_32x32x16_f16 per 16-pixel group and product (common.h mma32_split)
 // instead of eight v_mfma_f32_32x32x2_f32: 15 matrix instructions of 32 cycles per group instead of 40 of 64.
-template <typename T, bool GRAM, bool NOSEL, bool XS = false>
+// XS == 2 (f16x2f, round 6): the same with the HI planes alone -- one product per accumulator, half the LDS row images (no
+// column segments at 416), a third of the matrix instructions: the backward contractions of that mode read f16(dz) and f16(x)
+template <typename T, bool GRAM, bool NOSEL, int XS = 0>
 __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1WgradLinArgs a, float* part) {
     // also the BN-backward REDUCE of this layer, for free: dA and ysel pass through here anyway, and nothing in this
     // kernel needs the sums (S1 = sum g, S2 = sum g * ysel -> psum[block][2][32]; the finalize runs after it)
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
     // XS: the LDS row images are TWO half planes (hi, lo) in the 16-bit types' layout -- dz is split once where it is
     // scattered, x once where it is staged -- and the matrix section is the 16-bit one on plane pairs
     constexpr int LSZ = XS ? 2 : SZ;
+    constexpr int NPLN = XS == 1 ? 2 : 1;          // LDS planes per row image
     constexpr int DYP = 32 * LSZ, XP = 4 * LSZ;
     static_assert(!XS || SZ == 4, "the in-register split reads fp32 operands");
     constexpr int NTH = kLinThreads, NW = NTH / 64;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
     const int dz_bytes = Wp * DYP;
     const int x_bytes = ((Wp + 4) * XP + 15) & ~15;
     char* dz_l = smem;                   // [2 rows][Wp][32]            (XS: [2 planes][2 rows][Wp][32] halves)
-    char* x_l = smem + (XS ? 4 : 2) * dz_bytes;     // [4 rows][x_bytes]  (XS: [2 planes][4 rows][x_bytes])
+    char* x_l = smem + NPLN * 2 * dz_bytes;         // [4 rows][x_bytes]  (XS 1: [2 planes][4 rows][x_bytes])
     const int x_chunks = x_bytes / 16;
     const int dz_plane = 2 * dz_bytes, x_plane = 4 * x_bytes;      // XS: byte distance of the lo plane
     const int Ho = a.H / 2, Wo = a.W / 2;
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
     {   // k-padding pixels of the dz rows: zero, once
         constexpr int LCPP = DYP / 16;      // 16-byte chunks per pixel of an LDS row image
         const int padw = nseg > 1 ? 0 : Wp - a.W;       // (segments: zeroed per unit, below)
-        for (int i = tid; i < (XS ? 4 : 2) * padw * LCPP; i += NTH) {
+        for (int i = tid; i < NPLN * 2 * padw * LCPP; i += NTH) {
             const int r = i / (padw * LCPP), j = i % (padw * LCPP);
             *(u32x4*)(dz_l + r * dz_bytes + a.W * DYP + j * 16) = u32x4{0, 0, 0, 0};
         }
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                 }
                 char* dst = dz_l + (d >> 1) * dz_bytes + (size_t)(2 * wo + (d & 1)) * DYP + ch * 8;
                 *(u32x2*)dst = *(const u32x2*)oh;
-                *(u32x2*)(dst + dz_plane) = *(const u32x2*)ol;
+                if constexpr (XS == 1) *(u32x2*)(dst + dz_plane) = *(const u32x2*)ol;
             }
         } else {
 #pragma unroll
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
         __syncthreads();   // previous row pair fully consumed
         if (nseg > 1 && Wv < Wp) {      // a narrower last segment: its k-padding pixels held the previous unit's dz
             constexpr int LCPP = DYP / 16;
-            for (int i = tid; i < (XS ? 4 : 2) * (Wp - Wv) * LCPP; i += NTH) {
+            for (int i = tid; i < NPLN * 2 * (Wp - Wv) * LCPP; i += NTH) {
                 const int r = i / ((Wp - Wv) * LCPP), j = i % ((Wp - Wv) * LCPP);
                 *(u32x4*)(dz_l + r * dz_bytes + Wv * DYP + j * 16) = u32x4{0, 0, 0, 0};
             }
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                 for (int e = 0; e < 4; ++e) split_f16(f[e], h[e], l[e]);
                 char* dst = x_l + (i / xpix) * x_bytes + (i % xpix) * XP;
                 *(u32x2*)dst = *(const u32x2*)h;
-                *(u32x2*)(dst + x_plane) = *(const u32x2*)l;
+                if constexpr (XS == 1) *(u32x2*)(dst + x_plane) = *(const u32x2*)l;
             };
 #pragma unroll
             for (int k = 0; k < kXB; ++k) {
@@ -650,7 +653,29 @@ __global__ __launch_bounds__(kLinThreads, 2) void conv1_wgrad_lin_kernel(Conv1Wg
                         mma32(g12, fa1, fg2);
                         mma32(g22, fa2, fg2);
                     }
-                } else if constexpr (XS) {
+                } else if constexpr (XS == 2) {
+                    // hi planes only: the 16-bit section as it stands, one product per accumulator
+                    const int pix = w0 + 8 * hh + qq;
+                    const char* pb = dzr + pix * DYP + (16 * g1 + 4 * pp) * 2;
+                    const f16x8 bh = tr_frag<half_t>(pb, pb + 4 * DYP);
+                    const char* pa1 = x_l + (r + g1) * x_bytes + (pix + pp) * XP;
+                    const f16x8 a1h = tr_frag<half_t>(pa1, pa1 + 4 * XP);
+                    const char* pa2 = x_l + (r + 2) * x_bytes + (pix + pp) * XP;
+                    const f16x8 a2h = tr_frag<half_t>(pa2, pa2 + 4 * XP);
+                    mma32(acc1, a1h, bh);
+                    mma32(acc2, a2h, bh);
+                    if constexpr (GRAM) {
+                        f16x8 m1h = a1h, m2h = a2h;
+                        if (w0 + 16 > Wv) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (w0 + 8 * hh + j >= Wv) { m1h[j] = m2h[j] = (half_t)0.f; }
+                        }
+                        mma32(g11, a1h, m1h);
+                        mma32(g12, a1h, m2h);
+                        mma32(g22, a2h, m2h);
+                    }
+                } else if constexpr (XS == 1) {
                     // the 16-bit section on plane pairs: three products per accumulator (common.h mma32_split)
                     const int pix = w0 + 8 * hh + qq;
                     const char* pb = dzr + pix * DYP + (16 * g1 + 4 * pp) * 2;
@@ -1101,12 +1126,13 @@ hipError_t launch_conv1_gram_stats(int dtype, const Conv1GramStatsArgs& a, hipSt
     return hipErrorInvalidValue;
 }
 
-template <typename T, bool XS = false>
+template <typename T, int XS = 0>
 static hipError_t c1lin_T(const Conv1WgradLinArgs& a0, hipStream_t s) {
     constexpr int SZ = sizeof(T);
+    constexpr int ISZ = XS == 2 ? 2 : SZ;        // bytes per element of the LDS row images (XS 1: two half planes = 4)
     Conv1WgradLinArgs a = a0;
     int Wp = (a.W + 15) & ~15;
-    auto images = [](int wp) { return 2 * (size_t)wp * 32 * SZ + 4 * (size_t)((((wp + 4) * 4 * SZ) + 15) & ~15); };
+    auto images = [](int wp) { return 2 * (size_t)wp * 32 * ISZ + 4 * (size_t)((((wp + 4) * 4 * ISZ) + 15) & ~15); };
     size_t lds = images(Wp);
     if (XS && lds > 80 * 1024) {     // fp32-wide row images: column segments, so that two workgroups share a CU
         static const int want = getenv("Y2_CONV1_LIN_NSEG") ? atoi(getenv("Y2_CONV1_LIN_NSEG")) : 2;    // (A/B knob)
@@ -1158,7 +1184,7 @@ size_t conv1_wgrad_lin_scratch_floats() { return (size_t)kLinAcc * (kLinMid + 51
 hipError_t launch_conv1_wgrad_lin(int dtype, const Conv1WgradLinArgs& a, hipStream_t s) {
     dtype = dtype_plain(dtype);      // f16x2: fp32 operands (exact fp32, or Conv1WgradLinArgs::xs)
     switch (dtype) {
-        case 0: return a.xs ? c1lin_T<float, true>(a, s) : c1lin_T<float>(a, s);
+        case 0: return a.xs == 2 ? c1lin_T<float, 2>(a, s) : (a.xs ? c1lin_T<float, 1>(a, s) : c1lin_T<float>(a, s));
         case 1: return c1lin_T<half_t>(a, s);
         case 2: return c1lin_T<bf16_t>(a, s);
     }

@@ -210,7 +210,8 @@ struct Conv1WgradLinArgs {
     float* psum;                // out: BN-backward partial sums [blocks][2][32] (S1, S2) -- the reduce pass rides here
     int* nblocks_out;           // host: number of partial records written
     int N, H, W;
-    int xs = 0;                 // f16x2 mode (T = float kernel): X(dz) and G from split-operand f16 products (Conv1Args::xs)
+    int xs = 0;                 // f16x2 mode (T = float kernel): X(dz) and G from split-operand f16 products (Conv1Args::xs);
+                                // 2 (f16x2f): from the hi planes alone, one product each
     // set by the launcher: a row pair is worked in nseg column segments of ws pixels (a multiple of 16) so that the LDS row
     // images of the fp32-wide form leave room for two workgroups per CU
     int nseg = 1, ws = 0;

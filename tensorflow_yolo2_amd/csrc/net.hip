@@ -1029,7 +1029,9 @@ int y2_backward(y2_ctx* c, const float* dout, int layer_lo, int layer_hi, void* 
                 int nbl = 0;
                 g.nblocks_out = &nbl;
                 g.N = c->N; g.H = y.H; g.W = y.W;
-                g.xs = c->xs1() ? 1 : 0;
+                // f16x2f: this layer's backward contractions on the hi planes too (conv1_wgrad.hip XS == 2); Y2_F16X2F_CONV1_XS3=1: A/B
+                static const bool xs3 = getenv("Y2_F16X2F_CONV1_XS3") != nullptr;
+                g.xs = c->xs1() ? ((c->bwd_dtype == 4 && !xs3) ? 2 : 1) : 0;
                 HIPCHK(launch_conv1_wgrad_lin(c->dtype, g, s));
                 b.P = nbl;
             } else if (rec1) {   // pooled first layer: recompute the conv output instead of reading it (80 -> 24 B/pixel)
