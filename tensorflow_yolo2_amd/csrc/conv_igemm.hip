@@ -280,8 +280,15 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 template <typename T>
 static hipError_t launch_T(const ConvArgs& a, hipStream_t s) {
     const int kb = a.C * (int)sizeof(typename Types<T>::op_t);  // bytes per tap per pixel (of one operand plane)
-    const bool k128 = (kb % 128) == 0;
+    bool k128 = (kb % 128) == 0;
     if (!k128 && (kb % 64) != 0) return hipErrorInvalidValue;
+    // round 6: a two-plane (PL2) chunk of 128 bytes is [64 B hi | 64 B lo] = 32 channels of BOTH planes, so the 32-channel
+    // layer of the split-operand forward (208x208 32 -> 64) takes ONE K step per tap instead of two of half the depth -- half
+    // the barriers and stage waits per matrix instruction.  Y2_IGEMM_PL2_64=1 restores the 64-byte chunks (A/B).
+    if constexpr (Types<T>::kPasses == 3) {
+        static const bool no_pl2 = getenv("Y2_NO_CONV_PL2") != nullptr, keep64 = getenv("Y2_IGEMM_PL2_64") != nullptr;
+        if (!no_pl2 && !keep64 && kb == 64) k128 = true;
+    }
     // 2 LDS stages and two blocks per CU beat deeper rings here (global->LDS fill rate, not
     // latency, bounds this kernel); 8 waves of 64x32 beat 4 waves of 64x64 by ~5-8 %
     if (a.Cout > 64) {
