@@ -388,6 +388,10 @@ class Bordered:
     def __init__(self, n, h, w, c, dtype, device):
         lib = _lib.load()
         dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+        if dt not in (_lib.Y2_F32, _lib.Y2_F16, _lib.Y2_BF16):
+            # (the type map below has no entry for the split-operand modes, whose cells are two half planes;
+            #  y2_link refuses them too)
+            raise ValueError("Bordered: linked tensors exist in f32 / f16 / bf16 (not the split-operand modes f16x2 / f16x2f)")
         off = C.c_size_t(0)
         nbytes = lib.y2_bordered_bytes(n, h, w, c, dt, C.byref(off))
         self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
