@@ -44,7 +44,7 @@ def main():
     # (f16: this toy geometry -- 8 pixels per channel at the top -- overflows the default loss scale of 1024 on its own;
     #  the clean steps run at 8, the overflow below is forced through rank 1's input)
     tr = DetectorTrainer(n, size, dtype=dtype, core_spec=core, head_spec=head, seed=0,
-                         grad_scale=8.0 if dtype in ("f16", "f16x2") else None)
+                         grad_scale=8.0 if dtype in ("f16", "f16x2", "f16x2f") else None)
     assert len(tr.reducer.slices) >= 4, tr.reducer.slices
     p0 = tr.net.params.clone()
 
@@ -91,7 +91,7 @@ def main():
     dist.all_gather(rows, tr.net.params)
     assert torch.equal(rows[0], rows[1])
     assert torch.isfinite(tr.net.params).all()
-    if dtype in ("f16", "f16x2"):
+    if dtype in ("f16", "f16x2", "f16x2f"):
         # 5. an overflow on ONE rank: rank 1's images are scaled until its first conv output leaves f16's range
         sc = tr.opt.scaler
         assert sc is not None and sc.enabled

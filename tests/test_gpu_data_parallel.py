@@ -35,7 +35,7 @@ def l2err(a, b):
 
 # ---------------------------------------------------------------- e: GradReducer at world size 2 on the GPU
 @pytest.mark.parametrize("strategy,dtype", [("allreduce", "f32"), ("rs_ag", "f32"), ("allreduce", "f16"), ("rs_ag", "f16"),
-                                            ("allreduce", "f16x2")])
+                                            ("allreduce", "f16x2"), ("rs_ag", "f16x2f")])
 def test_grad_reducer_two_ranks_on_one_gpu(strategy, dtype):
     """VERDICT r1 weak #8 / ADVICE: backward_marks + comm stream + collective at world > 1, on device tensors.
     Two rank processes share cuda:0 (gloo moves the device tensors; RCCL refuses two ranks on one device).
