@@ -147,3 +147,34 @@ def test_f16x2f_train_steps_follow_the_f32_mode():
     assert rel[0] < 1e-5, rel
     assert all(np.isfinite(losses["f16x2f"])) and losses["f16x2f"][-1] < losses["f16x2f"][0]
     assert cos > 0.9999, cos
+
+
+def test_f16x2f_classifier_and_multi_scale_trainers():
+    """the other two train-step drivers in this mode: darknet19 + softmax-CE + Momentum (src/imagenet/imagenet_train_darknet.py:
+    46-58; average-pool tail) at reduced width, and the multi-scale detector trainer on two sizes -- the first loss is the
+    exact-f32 mode's to 1e-5, the loss falls, everything stays finite"""
+    from tensorflow_yolo2_amd import synthetic
+    from tensorflow_yolo2_amd.trainer import ClassifierTrainer, MultiScaleDetectorTrainer
+    core = [(k, ci, co, int(p)) for (k, ci, co, p) in R.scaled_spec(R.CORE_SPEC, 4)]
+    spec = core + [(1, core[-1][2], 1000, 0)]
+    n, size = 8, 128
+    x = dev(synthetic.images(n, size, 3))
+    lab = torch.as_tensor(np.random.default_rng(5).integers(0, 1000, n).astype(np.int32)).cuda()
+    first = {}
+    for dt in ("f32", "f16x2f"):
+        tr = ClassifierTrainer(n, size, dtype=dt, spec=spec, seed=2)
+        losses = [float(tr.step(x, lab)[0]) for _ in range(6)]
+        assert all(np.isfinite(losses)) and losses[-1] < losses[0], (dt, losses)
+        assert torch.isfinite(tr.net.params).all()
+        first[dt] = losses[0]
+    assert abs(first["f16x2f"] - first["f32"]) < 1e-5 * abs(first["f32"]), first
+    head = [(3, core[-1][2], 128, 0), (1, 128, 30, 0)]
+    ms = MultiScaleDetectorTrainer(4, sizes=(96, 128), period=1, dtype="f16x2f", core_spec=core, head_spec=head, seed=1)
+    data = {s: (dev(synthetic.images(4, s, 10 + s)), dev(synthetic.det_labels(4, s, s // 32, 20 + s))) for s in (96, 128)}
+    hist = {96: [], 128: []}
+    for step in range(8):
+        s = (96, 128)[step % 2]
+        hist[s].append(float(ms.step(*data[s])[0][4]))
+    for s in (96, 128):
+        assert all(np.isfinite(hist[s])) and hist[s][-1] < hist[s][0], hist
+    assert ms.nets[96].params.data_ptr() == ms.nets[128].params.data_ptr()
