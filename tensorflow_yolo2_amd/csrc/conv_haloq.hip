@@ -865,13 +865,32 @@ static int haloq_ks_depth(int M, int Cout, int nchunks) {
     d = d > nchunks / 2 ? nchunks / 2 : d;
     return d < 2 ? 1 : d;
 }
+int conv_igemm_ks_depth(int M, int Cout, int row_bytes);      // conv_igemm.hip: the 1x1 launches' K split (round 6)
 int conv_ks_depth(int taps, int M, int Cout, int row_bytes) {
+    if (taps == 1) return conv_igemm_ks_depth(M, Cout, row_bytes);
     if (taps != 9 || M >= 384 * 8 || (row_bytes % 128) != 0 || Cout <= 64 || halo_compact()) return 1;
     return haloq_ks_depth(M, Cout, row_bytes / 128);
 }
 size_t conv_ks_scratch_floats(int taps, int M, int ldy, int row_bytes) {
-    if (taps != 9 || M >= 384 * 8 || (row_bytes % 128) != 0 || ldy <= 64) return 0;
+    if ((taps != 9 && taps != 1) || M >= 384 * 8 || (row_bytes % 128) != 0 || ldy <= 64) return 0;
     return (size_t)8 * M * ldy;
+}
+// partial tiles -> result (+ statistics records of 128 pixels) of a K-split launch of either kernel family
+template <typename T>
+static hipError_t ks_finish_T(const ConvArgs& a, int depth, hipStream_t s) {
+    const long quads = (long)a.M * (a.ldy / 4);
+    hipLaunchKernelGGL(conv_ks_finish_kernel<T>, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a, depth);
+    if (a.part_mean && !a.aff_out)
+        hipLaunchKernelGGL(conv_ks_stats_kernel<T>, dim3((a.ldy + 63) / 64, (a.M + kKsRec - 1) / kKsRec), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_conv_ks_finish(int dtype, const ConvArgs& a, int depth, hipStream_t s) {
+    switch (dtype) {
+        case 0: return ks_finish_T<float>(a, depth, s);
+        case 1: return ks_finish_T<half_t>(a, depth, s);
+        case 2: return ks_finish_T<bf16_t>(a, depth, s);
+    }
+    return hipErrorInvalidValue;
 }
 template <typename T>
 static hipError_t haloq_ks(const ConvArgs& a0, hipStream_t s, int* bp) {

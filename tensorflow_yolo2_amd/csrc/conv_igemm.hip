@@ -64,7 +64,11 @@ struct ConvCfg {
 // 4 skip MFMAs, 8 skip LDS fragment reads.  0 in every product launch.
 // PL2 (f16x2 mode, round 5; as conv_haloq.hip): a staged row of either operand is [BKB/2 bytes of the hi plane | BKB/2 of the
 // lo plane] of the K chunk, and a K step runs the three plane products on it instead of the K loop running three plane passes
-template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0, bool PL2 = false>
+// KS (round 6; 1x1 launches of fewer than 3072 pixels -- single images, the reference's batch 24 at 7x7, the ResNet swap's 7x7
+// units): the K steps are split over a.ks_splits workgroups per tile, each leaves its fp32 partial tile in a.ks_scratch
+// [split][M][ldy] and conv_ks_finish (conv_haloq.hip) adds them in split order -- as the 3x3 kernels' haloq_ks: such a launch
+// is a handful of workgroups walking a serial K loop at one memory latency per step
+template <typename T, int WP, int WC, int TP, int TC, int BKB, int NS, int ABL = 0, bool PL2 = false, bool KS = false>
 __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     typedef ConvCfg<T, WP, WC, TP, TC, BKB, NS> Cfg;
     typedef typename Elem<T>::frag frag_t;
@@ -86,7 +90,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / WC, wc = w % WC;
     const int nCT = (a.Cout + BC - 1) / BC;
-    const int bx = xcd_block(blockIdx.x, gridDim.x, a.xcd);
+    int bx = xcd_block(blockIdx.x, gridDim.x, a.xcd);
+    int split = 0;
+    if constexpr (KS) {
+        const int tiles = ((a.M + BP - 1) / BP) * nCT;
+        split = bx / tiles;
+        bx -= split * tiles;
+    }
     const int ct = bx % nCT, pt = bx / nCT;
     const int m0 = pt * BP, n0 = ct * BC;
     const int Ktot = a.taps * a.C;  // elements per packed weight row
@@ -119,7 +129,13 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     // k-chunks per tap; f16x2: three passes over the planes, [x hi | x lo | x hi] against [w hi | w hi | w lo]
     const int npl = (a.C * (int)sizeof(OT)) / BKB;
     const int cpt = PL2 ? (a.C * (int)sizeof(OT)) / (BKB / 2) : Types<T>::kPasses * npl;
-    const int nK = a.taps * cpt;
+    int k_begin = 0, nK = a.taps * cpt;          // this workgroup's K steps [k_begin, nK)
+    if constexpr (KS) {
+        const int per = (nK + a.ks_splits - 1) / a.ks_splits;
+        k_begin = split * per;
+        nK = k_begin + per < nK ? k_begin + per : nK;
+        if (k_begin > nK) k_begin = nK;
+    }
     const int rowpitch = (a.W + 1) * a.C * SZ;
 
     auto stage = [&](int kk, int buf) {
@@ -168,9 +184,9 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
     //   used with stage kk+NS-1 -> MFMAs on stage kk.
 #pragma unroll
     for (int s0 = 0; s0 < NS - 1; ++s0)
-        if (s0 < nK) stage(s0, s0);
+        if (k_begin + s0 < nK) stage(k_begin + s0, s0);
     int cbuf = 0, ibuf = NS - 1;
-    for (int kk = 0; kk < nK; ++kk) {
+    for (int kk = k_begin; kk < nK; ++kk) {
         if (kk + NS - 2 < nK) wait_vmcnt<(NS - 2) * Cfg::IPW_MIN>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -235,6 +251,25 @@ __global__ __launch_bounds__(WP* WC * 64) void conv_igemm_kernel(ConvArgs a) {
         ibuf = (ibuf + 1 == NS) ? 0 : ibuf + 1;
     }
     __syncthreads();
+    if constexpr (KS) {
+        // fp32 partial tile: 4 consecutive couts (registers 4 q4 .. 4 q4 + 3) per 16-byte store
+        float* const part = a.ks_scratch + (size_t)split * a.M * a.ldy;
+        const int r32_ = lane & 31, hh_ = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int p = m0 + (wp * TP + j) * 32 + r32_;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int co = n0 + (wc * TC + i) * 32 + 8 * q4 + 4 * hh_;
+                    if (p < a.M && co < a.ldy)
+                        *(f32x4*)(part + (size_t)p * a.ldy + co) =
+                            f32x4{acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                }
+            }
+        return;
+    }
     if (ABL & 16) {   // dev: skip the epilogue (keep the accumulators alive)
         float t = 0.f;
 #pragma unroll
@@ -276,6 +311,46 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// K split of a small 1x1 launch (conv_igemm_kernel<.., KS>): fewer than 128 workgroups of the 128 x 128 tile and at least four
+// K steps; the depth fills about one round of the chip.  < 2: not this form.
+static int igemm_ks_depth(int M, int Cout, int nK) {
+    static const bool off = getenv("Y2_NO_KSPLIT") != nullptr;
+    const int wgs = ((M + 127) / 128) * ((Cout + 127) / 128);
+    if (off || wgs >= 128 || nK < 4) return 1;
+    int d = 256 / wgs;
+    d = d > 8 ? 8 : d;
+    d = d > nK / 2 ? nK / 2 : d;
+    return d < 2 ? 1 : d;
+}
+int conv_igemm_ks_depth(int M, int Cout, int row_bytes) {
+    if (M >= 384 * 8 || (row_bytes % 128) != 0 || Cout <= 64) return 1;
+    return igemm_ks_depth(M, Cout, row_bytes / 128);
+}
+hipError_t launch_conv_ks_finish(int dtype, const ConvArgs& a, int depth, hipStream_t s);      // conv_haloq.hip
+
+template <typename T>
+static hipError_t launch_ks(const ConvArgs& a0, hipStream_t s, int dtype) {
+    typedef ConvCfg<T, 2, 4, 2, 1, 128, 2> Cfg;
+    const int nK = a0.C * (int)sizeof(T) / 128;
+    int depth = igemm_ks_depth(a0.M, a0.Cout, nK);
+    if (depth < 2 || !a0.ks_scratch || a0.bw_psum || a0.nonfinite || (a0.ldy % 4) != 0) return hipErrorNotSupported;
+    while (depth > 1 && (size_t)depth * a0.M * a0.ldy > a0.ks_floats) --depth;
+    if (depth < 2) return hipErrorNotSupported;
+    ConvArgs a = a0;
+    a.ks_splits = depth;
+    void (*kern)(ConvArgs) = conv_igemm_kernel<T, 2, 4, 2, 1, 128, 2, 0, false, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles = ((a.M + Cfg::BP - 1) / Cfg::BP) * ((a.Cout + Cfg::BC - 1) / Cfg::BC);
+    hipLaunchKernelGGL(kern, dim3(tiles * depth), dim3(Cfg::NT), Cfg::LDS, s, a);
+    hipError_t e = hipGetLastError();
+    return e != hipSuccess ? e : launch_conv_ks_finish(dtype, a, depth, s);
+}
+
 // tile choice by output-channel count; rows-per-partial (BP) is reported back
 template <typename T>
 static hipError_t launch_T(const ConvArgs& a, hipStream_t s) {
@@ -305,9 +380,15 @@ int conv_block_couts(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32);
 
 hipError_t launch_conv_igemm(int dtype, const ConvArgs& a, hipStream_t s) {
     switch (dtype) {
-        case 0: return launch_T<float>(a, s);
-        case 1: return launch_T<half_t>(a, s);
-        case 2: return launch_T<bf16_t>(a, s);
+        case 0: case 1: case 2:
+            // small 1x1 launches: K split over workgroups (the batch-norm records of that form cover 128 pixels each, the
+            // default record size of this kernel's 128-cout tiles: launch_conv's record count does not change)
+            if (a.taps == 1 && conv_igemm_ks_depth(a.M, a.Cout, a.C * (int)dtype_size(dtype)) >= 2) {
+                const hipError_t e = dtype == 0 ? launch_ks<float>(a, s, dtype)
+                                                : (dtype == 1 ? launch_ks<half_t>(a, s, dtype) : launch_ks<bf16_t>(a, s, dtype));
+                if (e != hipErrorNotSupported) return e;
+            }
+            return dtype == 0 ? launch_T<float>(a, s) : (dtype == 1 ? launch_T<half_t>(a, s) : launch_T<bf16_t>(a, s));
         case 3: return launch_T<hsplit_t>(a, s);
         case 4: return launch_T<hsplith_t>(a, s);        // f16x2f backward launches: the hi planes of split tensors
         case 5: return launch_T<hsplithh_t>(a, s);       // ... with dA stored in f16 (common.h hsplithh_t)

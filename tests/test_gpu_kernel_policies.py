@@ -135,6 +135,28 @@ def test_small_launches_k_split_vs_float64(N, hw, cin, cout, dtype, tol):
     check_layer_shape(N, "small-M", 3, cin, cout, hw, "K-split", dtype=dtype, tol=tol)
 
 
+SMALL_M_1X1 = [(1, 7, 1024, 512), (1, 14, 512, 256), (24, 7, 1024, 512), (32, 7, 2048, 512), (32, 7, 512, 2048), (4, 14, 512, 256),
+               (1, 13, 1024, 512), (2, 10, 640, 256), (3, 11, 1152, 384), (1, 7, 1024, 1000)]
+
+
+@pytest.mark.parametrize("dtype,tol", [("f16", 1e-3), ("f32", 1e-5)])
+@pytest.mark.parametrize("N,hw,cin,cout", SMALL_M_1X1, ids=["%dx%d^2_%d-%d" % s for s in SMALL_M_1X1])
+def test_small_1x1_launches_k_split_vs_float64(N, hw, cin, cout, dtype, tol):
+    """round 6: 1x1 layers with fewer than 3072 pixels (single-image detection, batch 24 at 7x7, the ResNet swap's 7x7 units:
+    src/yolo2_nets/darknet.py:174,176; src/slim_dir/nets/resnet_v1.py:99-112) run conv_igemm with its K steps split over
+    workgroups (conv_igemm.hip launch_ks), fp32 partial tiles added in split order: forward, dgrad, wgrad against float64"""
+    from _shapes import check_layer_shape
+    check_layer_shape(N, "small-M-1x1", 1, cin, cout, hw, "K-split-1x1", dtype=dtype, tol=tol)
+
+
+@pytest.mark.parametrize("N,hw,cin,cout", [(24, 7, 1024, 512), (1, 14, 512, 256), (32, 7, 512, 2048)])
+def test_small_1x1_launches_k_split_in_network(N, hw, cin, cout):
+    """... and in training mode inside a network: statistics from the stored values (conv_ks_stats_kernel), BN + leaky, the
+    backward pass with the standalone BN-backward reduce (a K-split dgrad does not carry the fused one)"""
+    from _shapes import check_layer_in_network
+    check_layer_in_network(N, "small-M-1x1", 1, cin, cout, hw, 0, "K-split-1x1")
+
+
 @pytest.mark.parametrize("N,hw,cin,cout,pool", [(24, 7, 512, 1024, 0), (1, 14, 256, 512, 1), (2, 13, 1024, 1024, 0)])
 def test_small_launches_k_split_in_network(N, hw, cin, cout, pool):
     """the same as LAYERS in training mode: the batch statistics of a K-split launch come from one record over the stored
