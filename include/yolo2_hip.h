@@ -303,7 +303,9 @@ int y2_fully_connected_backward(const float* x, const float* w, const float* dy,
  * dz [rows,out] (gradient at the pre-activation, times the loss scale), w / m / v [in,out]; ctrl: the control block of
  * y2_adam_step_guarded AFTER that call advanced it for this step (found_inf: nothing moves; lr_t applies).  The caller's
  * overflow scan covers every OTHER gradient (the bias gradient of the same layer is the column sum of dz: a non-finite
- * dz is seen there). */
+ * dz is seen there; round 6: y2_range_check on x and dz makes the guard of THIS product explicit).  rows <= 256 in the 16-bit
+ * types (128 in fp32): the batch -- or, data parallel, the batches of all replicas gathered: every rank then applies the
+ * identical update from the identical operands instead of all-reducing a 1.64 GB gradient (yolo2_nets/tf_resnet.py). */
 int y2_fc_adam_apply_guarded(const float* x, const float* dz, float* w, float* m, float* v, int rows, int in_features,
                              int out_features, int dtype, const void* ctrl, float beta1, float beta2, float eps,
                              float grad_mult, void* stream);
