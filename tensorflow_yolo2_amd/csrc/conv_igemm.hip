@@ -311,12 +311,14 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// K split of a small 1x1 launch (conv_igemm_kernel<.., KS>): fewer than 128 workgroups of the 128 x 128 tile and at least four
-// K steps; the depth fills about one round of the chip.  < 2: not this form.
+// K split of a small 1x1 launch (conv_igemm_kernel<.., KS>): fewer than 48 workgroups of the 128 x 128 tile (single images,
+// the reference's batch 24 at 7x7: 40) and at least four K steps; the depth fills about one round of the chip.  < 2: not this
+// form.  (Measured: at 52 .. 208 workgroups -- the ResNet swap's 7x7 units at batch 32 -- the split is neutral to slightly
+// negative: its partial tiles and the two extra launches cost what the shorter K loops save; configs[0] gains 2.5 %.)
 static int igemm_ks_depth(int M, int Cout, int nK) {
     static const bool off = getenv("Y2_NO_KSPLIT") != nullptr;
     const int wgs = ((M + 127) / 128) * ((Cout + 127) / 128);
-    if (off || wgs >= 128 || nK < 4) return 1;
+    if (off || wgs >= 48 || nK < 4) return 1;
     int d = 256 / wgs;
     d = d > 8 ? 8 : d;
     d = d > nK / 2 ? nK / 2 : d;
