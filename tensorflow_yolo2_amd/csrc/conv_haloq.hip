@@ -936,7 +936,11 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
         hipError_t e = hipErrorOutOfMemory;
         if (a.Cout > 64) {
             *bp = 256;
-            e = haloq_pick<T, 4, 2, 2, 2, 64>(a, s);
+            // (split-operand forward, round 6: the fp32 epilogue patch sizes the LDS either way, so the two-plane form takes
+            //  128-byte chunks -- 32 channels of both planes, half the tap steps of the 64-byte form; Y2_HALOQ_104_K64=1: A/B)
+            static const bool k64 = getenv("Y2_HALOQ_104_K64") != nullptr;
+            if (Types<T>::kPasses == 3 && k128 && !k64) e = haloq_pick<T, 4, 2, 2, 2, 128>(a, s);
+            else e = haloq_pick<T, 4, 2, 2, 2, 64>(a, s);
         } else if (a.Cout > 32) {
             *bp = 512;
             // (64-byte K chunks here, so that the 512-pixel image at W = 104 can be double-buffered, measured 12 %
