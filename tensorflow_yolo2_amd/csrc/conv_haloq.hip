@@ -939,6 +939,8 @@ static hipError_t haloq_T(const ConvArgs& a, hipStream_t s, int* bp) {
             // (split-operand forward, round 6: the fp32 epilogue patch sizes the LDS either way, so the two-plane form takes
             //  128-byte chunks -- 32 channels of both planes, half the tap steps of the 64-byte form; Y2_HALOQ_104_K64=1: A/B)
             static const bool k64 = getenv("Y2_HALOQ_104_K64") != nullptr;
+            // (the hi-plane dgrads of f16x2f keep the 64-byte chunks: one 128-byte chunk is their whole K -- no second image to
+            //  load behind the first -- and measured 216 against 200 us)
             if (Types<T>::kPasses == 3 && k128 && !k64) e = haloq_pick<T, 4, 2, 2, 2, 128>(a, s);
             else e = haloq_pick<T, 4, 2, 2, 2, 64>(a, s);
         } else if (a.Cout > 32) {
