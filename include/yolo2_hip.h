@@ -37,7 +37,9 @@ typedef struct y2_ctx y2_ctx;
  * (4 bytes per element, as fp32); a product is hi*hi + lo*hi + hi*lo on v_mfma_f32_*_f16 with fp32 accumulation
  * (~22 mantissa bits, a third of the f16 rate instead of the exact-f32 MFMA's sixteenth); conv outputs, gradients
  * with respect to activations, statistics, batch norm, loss and optimizer are fp32 as in Y2_F32; the 3-channel image
- * layer runs in exact fp32.  Gradients ride on the f16 loss scale (y2_set_options) with the f16 mode's overflow guard. */
+ * layer runs in exact fp32.  Gradients ride on the f16 loss scale (y2_set_options) with the f16 mode's overflow guard.
+ * Range: the filter planes hold 64 * w in f16 (a power-of-two pre-scale that keeps typical weights' lo plane out of the
+ * subnormals), so |w| must stay below 1024; activations and dY have f16's range. */
 #define Y2_F16X2 3
 /* Round 6: Y2_F16X2 forward, single-product backward.  Tensors, forward pass, batch norm, loss and optimizer are exactly
  * Y2_F16X2's (so every forward DECISION -- leaky branch, pool arg-max, responsible box -- is the reference-precision one);
