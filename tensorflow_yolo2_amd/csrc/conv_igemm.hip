@@ -369,6 +369,16 @@ static hipError_t launch_T(const ConvArgs& a, hipStream_t s) {
     // 2 LDS stages and two blocks per CU beat deeper rings here (global->LDS fill rate, not
     // latency, bounds this kernel); 8 waves of 64x32 beat 4 waves of 64x64 by ~5-8 %
     if (a.Cout > 64) {
+        // round 6: launches of at most one workgroup per CU have nobody to hide a stage's latency behind -- a ring of three
+        // stages keeps two K steps in flight (LDS is free at one workgroup per CU).  Same box, alternating: the ResNet swap's
+        // step 9.90 / 10.00 -> 9.66 / 9.82 ms (its 14x14 / 7x7 units and the 28x28 ones with 128 couts), configs[2] 4.47 -> 4.45;
+        // four stages 9.89 / 9.83.  No configs[3] launch has so few workgroups.  Y2_IGEMM_DEEP=2 | 4: A/B.
+        if constexpr (!Types<T>::kSplit) {
+            static const int deep = getenv("Y2_IGEMM_DEEP") ? atoi(getenv("Y2_IGEMM_DEEP")) : 3;
+            const long wgs = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+            if (k128 && deep >= 3 && wgs <= 256)
+                return deep >= 4 ? launch_cfg<T, 2, 4, 2, 1, 128, 4>(a, s) : launch_cfg<T, 2, 4, 2, 1, 128, 3>(a, s);
+        }
         return k128 ? launch_cfg<T, 2, 4, 2, 1, 128, 2>(a, s) : launch_cfg<T, 2, 4, 2, 1, 64, 2>(a, s);
     } else if (a.Cout > 32) {
         return k128 ? launch_cfg<T, 4, 1, 2, 2, 128, 2>(a, s) : launch_cfg<T, 4, 1, 2, 2, 64, 2>(a, s);
